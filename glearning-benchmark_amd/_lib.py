@@ -1,0 +1,107 @@
+"""ctypes binding of csrc/libgtok.so (the C ABI declared in include/gtok.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no
+gfx950 device is visible, every op raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "csrc", "libgtok.so")
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("gtok_sent.hip", "gtok_ibtt.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "gtok_common.hpp"), os.path.join(_ROOT, "include", "gtok.h")]
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class GtokCsr(ctypes.Structure):
+    _fields_ = [
+        ("num_graphs", ctypes.c_int32), ("max_nodes", ctypes.c_int32),
+        ("max_edges", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("node_ptr", ctypes.c_void_p), ("edge_ptr", ctypes.c_void_p),
+        ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p),
+        ("eorder", ctypes.c_void_p), ("nattr", ctypes.c_void_p),
+        ("eattr", ctypes.c_void_p),
+    ]
+
+
+class GtokVocabTable(ctypes.Structure):
+    _fields_ = [
+        ("capacity", ctypes.c_int32), ("pad_id", ctypes.c_int32),
+        ("key_off", ctypes.c_void_p), ("key_len", ctypes.c_void_p),
+        ("id", ctypes.c_void_p), ("key_bytes", ctypes.c_void_p),
+    ]
+
+
+class GtokSentParams(ctypes.Structure):
+    _fields_ = [
+        ("max_num_nodes", ctypes.c_int32), ("labeled", ctypes.c_int32),
+        ("num_node_types", ctypes.c_int32), ("num_edge_types", ctypes.c_int32),
+        ("max_len", ctypes.c_int32), ("remap_zinc", ctypes.c_int32),
+        ("pad_id", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("seed", ctypes.c_uint64), ("epoch", ctypes.c_uint64),
+        ("graph_base", ctypes.c_int64), ("query", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/gtok.h declares: (restype, argtypes)
+_I, _P = ctypes.c_int32, ctypes.c_void_p
+SYMBOLS = {
+    "gtok_ibtt_zinc": (_I, [ctypes.POINTER(GtokCsr), _P, _I, _I, _I, _P, _I, _P, _P]),
+    "gtok_ibtt_synth": (_I, [ctypes.POINTER(GtokCsr), _P, _I, _P, _I, _I, _P, _I, _P, _P]),
+    "gtok_text_to_ids": (_I, [_P, _P, _I, ctypes.POINTER(GtokVocabTable), _I, _I, _P, _I, _P, _P]),
+    "gtok_sent": (_I, [ctypes.POINTER(GtokCsr), ctypes.POINTER(GtokSentParams), _P, _I, _P, _P]),
+    "gtok_remap_zinc": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "gtok_collate": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P]),
+    "gtok_version": (_I, []),
+    "gtok_target": (ctypes.c_char_p, []),
+}
+
+ERRORS = {-1: "GTOK_E_INVAL", -2: "GTOK_E_TOO_LARGE", -3: "GTOK_E_LAUNCH", -4: "GTOK_E_NO_DEVICE"}
+
+
+class GtokError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into csrc/libgtok.so (hipcc cross-compiles without a GPU)."""
+    deps = SOURCES + HEADERS
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-I" + os.path.join(_ROOT, "include"), "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libgtok.so; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GtokError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise GtokError(f"{what} failed: {ERRORS.get(code, code)}")

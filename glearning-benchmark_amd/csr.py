@@ -1,0 +1,159 @@
+"""Batched CSR container — the form graphs take in HBM (layout: include/gtok.h).
+
+Built once on the host from PyG-style per-graph COO (x, edge_index, edge_attr:
+what graph_data_loader/zinc_dataset_autograph.py:51-73 and
+graph_data_loader/graph_token_dataset_autograph.py:338-348 hand to the
+tokenizer), then resident on the device for every epoch.
+"""
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from ._lib import GtokCsr
+
+
+def _to_u8(a: Optional[np.ndarray]) -> Optional[np.ndarray]:
+    """Type ids live in HBM as uint8; anything outside 0..254 becomes 255 ("other")."""
+    if a is None:
+        return None
+    a = np.asarray(a).reshape(-1).astype(np.int64, copy=False)
+    return np.where((a >= 0) & (a < 255), a, 255).astype(np.uint8)
+
+
+@dataclass
+class GraphBatch:
+    num_graphs: int
+    max_nodes: int
+    max_edges: int
+    node_ptr: torch.Tensor            # int32 [G+1]
+    edge_ptr: torch.Tensor            # int64 [G+1]
+    rowptr: torch.Tensor              # int32 [sum N + G], local per graph
+    col: torch.Tensor                 # int32 [sum E]
+    eorder: Optional[torch.Tensor]    # int32 [sum E] or None (identity)
+    nattr: Optional[torch.Tensor]     # uint8 [sum N]
+    eattr: Optional[torch.Tensor]     # uint8 [sum E]
+
+    @property
+    def device(self) -> torch.device:
+        return self.col.device
+
+    @property
+    def num_nodes_total(self) -> int:
+        return int(self.rowptr.numel()) - self.num_graphs
+
+    @property
+    def num_edges_total(self) -> int:
+        return int(self.col.numel())
+
+    def to(self, device) -> "GraphBatch":
+        mv = lambda t: None if t is None else t.to(device, non_blocking=True)
+        return GraphBatch(self.num_graphs, self.max_nodes, self.max_edges, mv(self.node_ptr), mv(self.edge_ptr),
+                          mv(self.rowptr), mv(self.col), mv(self.eorder), mv(self.nattr), mv(self.eattr))
+
+    def c_struct(self) -> GtokCsr:
+        p = lambda t: None if t is None else t.data_ptr()
+        return GtokCsr(self.num_graphs, self.max_nodes, self.max_edges, 0, p(self.node_ptr), p(self.edge_ptr),
+                       p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr))
+
+    def node_counts(self) -> torch.Tensor:
+        return self.node_ptr[1:] - self.node_ptr[:-1]
+
+    def algorithmic_read_bytes(self, ibtt: bool, labeled: bool) -> int:
+        """4(N+1) rowptr + 4E col (+4E order ids, IBTT) + N + E attrs (labelled)."""
+        n, e, g = self.num_nodes_total, self.num_edges_total, self.num_graphs
+        b = 4 * (n + g) + 4 * e
+        if ibtt:
+            b += 4 * e
+        if labeled:
+            b += n + e
+        return b
+
+    def shard(self, lo: int, hi: int) -> "GraphBatch":
+        """Graphs [lo, hi) as their own batch (contiguous block sharding, host tensors only)."""
+        assert self.col.device.type == "cpu"
+        n0, n1 = int(self.node_ptr[lo]), int(self.node_ptr[hi])
+        e0, e1 = int(self.edge_ptr[lo]), int(self.edge_ptr[hi])
+        sl = lambda t, a, b: None if t is None else t[a:b].clone()
+        nc = (self.node_ptr[lo + 1:hi + 1] - self.node_ptr[lo:hi])
+        ec = (self.edge_ptr[lo + 1:hi + 1] - self.edge_ptr[lo:hi])
+        return GraphBatch(hi - lo, int(nc.max()) if hi > lo else 0, int(ec.max()) if hi > lo else 0,
+                          (self.node_ptr[lo:hi + 1] - n0).clone(), (self.edge_ptr[lo:hi + 1] - e0).clone(),
+                          sl(self.rowptr, n0 + lo, n1 + hi), sl(self.col, e0, e1), sl(self.eorder, e0, e1),
+                          sl(self.nattr, n0, n1), sl(self.eattr, e0, e1))
+
+    # ------------------------------------------------------------------ builders
+    @staticmethod
+    def from_coo(node_counts, edge_counts, src, dst, x=None, edge_attr=None) -> "GraphBatch":
+        """Batched COO -> CSR.  src/dst are LOCAL node ids, edges of graph g are contiguous, in the
+        order the source edge_index lists them (that order is kept in `eorder`)."""
+        node_counts = np.asarray(node_counts, dtype=np.int64).reshape(-1)
+        edge_counts = np.asarray(edge_counts, dtype=np.int64).reshape(-1)
+        src = np.asarray(src, dtype=np.int64).reshape(-1)
+        dst = np.asarray(dst, dtype=np.int64).reshape(-1)
+        G = int(node_counts.size)
+        if edge_counts.size != G:
+            raise ValueError("node_counts and edge_counts differ in length")
+        node_ptr = np.zeros(G + 1, np.int64); np.cumsum(node_counts, out=node_ptr[1:])
+        edge_ptr = np.zeros(G + 1, np.int64); np.cumsum(edge_counts, out=edge_ptr[1:])
+        N, E = int(node_ptr[-1]), int(edge_ptr[-1])
+        if src.size != E or dst.size != E:
+            raise ValueError("src/dst length does not match edge_counts")
+        if N + G >= 2 ** 31:
+            raise ValueError("batch too large for int32 node offsets; shard it")
+        gid_e = np.repeat(np.arange(G, dtype=np.int64), edge_counts)
+        n_e = node_counts[gid_e]
+        if E and ((src < 0).any() or (dst < 0).any() or (src >= n_e).any() or (dst >= n_e).any()):
+            raise ValueError("edge endpoint outside [0, num_nodes)")
+        grow = node_ptr[gid_e] + src                      # global row of every entry
+        if E and np.all(grow[1:] >= grow[:-1]):
+            perm = None                                   # already row-sorted: identity order
+        else:
+            perm = np.argsort(grow, kind="stable")
+        take = (lambda a: a) if perm is None else (lambda a: a[perm])
+        col = take(dst).astype(np.int32)
+        eorder = None if perm is None else (perm - edge_ptr[gid_e[perm]]).astype(np.int32)
+        cnt = np.bincount(grow, minlength=N).astype(np.int64) if E else np.zeros(N, np.int64)
+        gid_n = np.repeat(np.arange(G, dtype=np.int64), node_counts)
+        excl = np.cumsum(cnt) - cnt
+        rowptr = np.empty(N + G, np.int32)
+        rowptr[np.arange(N, dtype=np.int64) + gid_n] = (excl - edge_ptr[gid_n]).astype(np.int32)
+        rowptr[node_ptr[1:] + np.arange(G, dtype=np.int64)] = edge_counts.astype(np.int32)
+        nattr = _to_u8(x)
+        eattr = _to_u8(edge_attr)
+        if nattr is not None and nattr.size != N:
+            raise ValueError("x length does not match node_counts")
+        if eattr is not None:
+            if eattr.size != E:
+                raise ValueError("edge_attr length does not match edge_counts")
+            eattr = take(eattr)
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+        return GraphBatch(G, int(node_counts.max()) if G else 0, int(edge_counts.max()) if G else 0,
+                          t(node_ptr.astype(np.int32)), t(edge_ptr), t(rowptr), t(col), t(eorder), t(nattr), t(eattr))
+
+    @staticmethod
+    def from_data_list(data_list: Sequence, labeled: Optional[bool] = None) -> "GraphBatch":
+        """From PyG-like objects exposing edge_index [2,E], num_nodes (or x), and optionally x / edge_attr."""
+        ncs, ecs, srcs, dsts, xs, eas = [], [], [], [], [], []
+        if labeled is None:
+            labeled = len(data_list) > 0 and getattr(data_list[0], "x", None) is not None \
+                and getattr(data_list[0], "edge_attr", None) is not None
+        for d in data_list:
+            ei = np.asarray(d.edge_index, dtype=np.int64).reshape(2, -1)
+            x = getattr(d, "x", None)
+            n = getattr(d, "num_nodes", None)
+            if n is None:
+                n = int(np.asarray(x).shape[0])
+            ncs.append(int(n)); ecs.append(ei.shape[1]); srcs.append(ei[0]); dsts.append(ei[1])
+            if labeled:
+                xa = np.asarray(x, dtype=np.int64)
+                xs.append(xa.reshape(xa.shape[0], -1)[:, 0] if xa.size else xa.reshape(-1))
+                ea = np.asarray(d.edge_attr, dtype=np.int64).reshape(-1)
+                # zinc_dataset_indexbase.py:183: edges past len(bond_types) read as 'unknown'
+                if ea.size < ei.shape[1]:
+                    ea = np.concatenate([ea, np.zeros(ei.shape[1] - ea.size, np.int64)])
+                eas.append(ea[:ei.shape[1]])
+        cat = lambda l: np.concatenate(l) if l else np.zeros(0, np.int64)
+        return GraphBatch.from_coo(ncs, ecs, cat(srcs), cat(dsts), cat(xs) if labeled else None,
+                                   cat(eas) if labeled else None)

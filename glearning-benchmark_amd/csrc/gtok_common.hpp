@@ -1,0 +1,105 @@
+// gtok_common.hpp — wave-level helpers shared by the gfx950 tokenizer kernels.
+//
+// Execution model used by every kernel in this directory: ONE 64-lane
+// wavefront owns one graph (or one text); the 1..4 waves of a workgroup never
+// synchronise with each other, each carves its own slice out of the
+// workgroup's dynamic LDS.  Cross-lane hand-offs through LDS are ordered by
+// wave_sync() (LDS ops of one wave execute in issue order; the fence pair only
+// stops the compiler from moving a lane's load above another lane's store).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gtok {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t uni(uint64_t v) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// k-th (0-based) set bit of a wave-uniform 64-bit word, ascending bit index:
+// every lane tests its own bit, one ballot + ffs picks the winner.
+__device__ __forceinline__ int kth_bit(uint64_t word, int k) {
+  const int lane = lane_id();
+  const bool hit = ((word >> lane) & 1ull) && (__popcll(word & lanemask_lt()) == k);
+  return __ffsll((unsigned long long)__ballot(hit)) - 1;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give
+// each XCD one CONTIGUOUS range of work units so that the cache lines two
+// neighbouring units share are fetched into one L2 only.  Pure speed: any
+// placement gives the same result.
+__device__ __forceinline__ int virtual_block() {
+  const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+  const int per = nb >> 3, rem = nb & 7, x = b & 7, j = b >> 3;
+  return x * per + (x < rem ? x : rem) + j;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), the counter-based generator of the SENT spec.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// trainer/train_agtt.py:171-244 (remap_zinc_tokens), branch order preserved.
+__device__ __forceinline__ int remap_zinc_token(int t, int idx_off, int node_off, int edge_off) {
+  if (t == 0) return 0;
+  if (t >= 1 && t <= 3) return 2;
+  if (t == 4) return 1;
+  if (t == 5) return 2;
+  if (node_off <= t && t < edge_off) {
+    const int a = t - node_off;
+    return (a >= 0 && a < 9) ? 8 + a : 22 + t;
+  }
+  if (t >= edge_off) {
+    const int b = t - edge_off + 1;
+    return (b >= 1 && b <= 4) ? 16 + b : 22 + t;
+  }
+  if (idx_off <= t && t < node_off) return 22 + (t - idx_off);
+  return 22 + t;
+}
+
+// Stream one output row: ids for i < len come from f(i), the rest is pad.
+// 16-byte stores (1 KiB per wave instruction) when the slab allows it.
+template <typename F>
+__device__ __forceinline__ void write_row(int32_t *__restrict__ row, int ld, int len, int pad, F f) {
+  const int lane = lane_id();
+  if (((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0)) {
+    for (int i = lane * 4; i < ld; i += kWave * 4) {
+      int4 v;
+      v.x = (i + 0 < len) ? f(i + 0) : pad;
+      v.y = (i + 1 < len) ? f(i + 1) : pad;
+      v.z = (i + 2 < len) ? f(i + 2) : pad;
+      v.w = (i + 3 < len) ? f(i + 3) : pad;
+      *reinterpret_cast<int4 *>(row + i) = v;
+    }
+  } else {
+    for (int i = lane; i < ld; i += kWave) row[i] = (i < len) ? f(i) : pad;
+  }
+}
+
+}  // namespace gtok

@@ -1,0 +1,489 @@
+// gtok_ibtt.hip — index-based serialisers (IBTT) for gfx950.
+//
+//   ibtt_zinc_kernel   graph_data_loader/zinc_dataset_indexbase.py:143-227 fused with
+//                      graph_data_loader/data_loader.py:465-484: CSR -> vocab ids, no strings
+//   ibtt_synth_kernel  docs/synthetic_data.md:46-68 grammar + data_loader.py:479-482
+//   text_ids_kernel    data_loader.py:465-484 on raw text bytes (any grammar)
+//
+// One wavefront per graph / text, LDS-staged, closed-form token positions so
+// every lane writes its own tokens; rows leave through write_row() as 16-byte
+// stores.  Bit-exact checkers: oracle/gtok_oracle.c.
+#include "gtok_common.hpp"
+#include "gtok.h"
+
+namespace gtok {
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// largest u in [0, n) with rp[u] <= k (rp in LDS, rp[n] > k guaranteed)
+__device__ __forceinline__ int row_of(const int32_t *rp, int n, int k) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (rp[mid] <= k) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// IBTT molecular serialiser
+// ---------------------------------------------------------------------------------------------
+struct ZincLds { int rp, cc, co, ou, ov, oa, tok, stride; };
+struct ZincArgs {
+  gtok_csr g;
+  const int32_t *lut;
+  int lut_len, max_len, pad_id, maxn, maxe, tcap;
+  ZincLds l;
+  int32_t *out; int ld; int32_t *out_len;
+  int units, upb;
+};
+
+__global__ void __launch_bounds__(256) ibtt_zinc_kernel(const ZincArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+  unsigned char *base = smem + (size_t)wave * a.l.stride;
+  int32_t *rp = reinterpret_cast<int32_t *>(base + a.l.rp);
+  uint16_t *cc = reinterpret_cast<uint16_t *>(base + a.l.cc);  // col, CSR position
+  uint16_t *co = reinterpret_cast<uint16_t *>(base + a.l.co);  // original position, CSR position
+  uint16_t *ou = reinterpret_cast<uint16_t *>(base + a.l.ou);  // src by original position
+  uint16_t *ov = reinterpret_cast<uint16_t *>(base + a.l.ov);  // dst by original position
+  uint8_t *oa = base + a.l.oa;                                  // edge_attr by original position
+  int32_t *tok = reinterpret_cast<int32_t *>(base + a.l.tok);
+  const int32_t *__restrict__ lut = a.lut;
+  const int pad = a.pad_id, tcap = a.tcap;
+
+  auto put = [&](int q, int v) { if (q < tcap) tok[q] = v; };
+  auto node_id = [&](int i) { return (GTOK_ZLUT_NODE0 + i < a.lut_len) ? lut[GTOK_ZLUT_NODE0 + i] : pad; };
+
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * wpb + wave;
+    if (g >= a.g.num_graphs) break;
+    const int nb0 = a.g.node_ptr[g];
+    const int n = min(a.g.node_ptr[g + 1] - nb0, a.maxn);
+    const int64_t e0 = a.g.edge_ptr[g];
+    const int e = min((int)(a.g.edge_ptr[g + 1] - e0), a.maxe);
+    const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
+
+    for (int i = lane; i <= n; i += kWave) rp[i] = rpg[i];
+    wave_sync();
+    // CSR entry k = (u, v, attr) listed at original position p: scatter back to COO order
+    for (int k = lane; k < e; k += kWave) {
+      const int v = a.g.col[e0 + k];
+      const int p = a.g.eorder ? a.g.eorder[e0 + k] : k;
+      const int at = a.g.eattr ? a.g.eattr[e0 + k] : 0;
+      const int u = row_of(rp, n, k);
+      cc[k] = (uint16_t)v; co[k] = (uint16_t)p;
+      if ((unsigned)p < (unsigned)e) { ou[p] = (uint16_t)u; ov[p] = (uint16_t)v; oa[p] = (uint8_t)at; }
+    }
+    wave_sync();
+    // zinc_dataset_indexbase.py:176-184: keep entry p iff no earlier entry joins the same {u,v}
+    int kept = 0;
+    for (int b0 = 0; b0 < e; b0 += kWave) {
+      const int p = b0 + lane;
+      bool keep = false;
+      int u = 0, v = 0, at = 0;
+      if (p < e) {
+        u = ou[p]; v = ov[p]; at = oa[p];
+        keep = true;
+        if (u < n && v < n) {
+          for (int j = rp[u], je = rp[u + 1]; j < je; ++j) keep = keep && !(cc[j] == v && co[j] < p);
+          for (int j = rp[v], je = rp[v + 1]; j < je; ++j) keep = keep && !(cc[j] == u && co[j] < p);
+        }
+      }
+      const uint64_t m = __ballot(keep);
+      if (keep) {
+        const int q = 1 + 2 * n + 4 * (kept + __popcll(m & lanemask_lt()));
+        put(q, lut[GTOK_ZLUT_BOND]);
+        put(q + 1, lut[GTOK_ZLUT_BOND0 + ((at >= 1 && at <= 4) ? at : 0)]);
+        put(q + 2, node_id(u));
+        put(q + 3, node_id(v));
+      }
+      kept += __popcll(m);
+    }
+    for (int i = lane; i < n; i += kWave) {  // :168-169, 'X' for x outside 0..8 (:104)
+      const int x = a.g.nattr ? a.g.nattr[nb0 + i] : 255;
+      put(1 + 2 * i, lut[GTOK_ZLUT_ATOM]);
+      put(2 + 2 * i, lut[GTOK_ZLUT_ATOM0 + (x <= 8 ? x : 9)]);
+    }
+    const int64_t T = 6 + 2 * (int64_t)n + 4 * (int64_t)kept;  // text tokens incl. label and <eos>
+    if (lane == 0) {
+      put(0, lut[GTOK_ZLUT_BOS]);
+      const int q = 1 + 2 * n + 4 * kept;
+      put(q, lut[GTOK_ZLUT_Q]); put(q + 1, lut[GTOK_ZLUT_REGRESSION]); put(q + 2, lut[GTOK_ZLUT_P]);
+    }
+    wave_sync();
+    int len;
+    if (T <= (int64_t)a.max_len + 1) {
+      len = (int)(T - 2);  // everything up to and including <p> (data_loader.py:479-481)
+    } else {               // :217-221 tokens[:max_len-1] + ['<eos>'], <p> was cut off
+      len = a.max_len;
+      if (lane == 0 && a.max_len >= 1) put(a.max_len - 1, lut[GTOK_ZLUT_EOS]);
+      wave_sync();
+    }
+    write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, min(a.ld, tcap)), pad, [=](int i) -> int { return tok[i]; });
+    if (lane == 0) a.out_len[g] = len;
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// graph-token grammar from the edge list
+// ---------------------------------------------------------------------------------------------
+struct SynthLds { int rp, tok, stride; };
+struct SynthArgs {
+  gtok_csr g;
+  const int32_t *lut; const int32_t *query;
+  int lut_len, max_len, pad_id, maxn, tcap;
+  SynthLds l;
+  int32_t *out; int ld; int32_t *out_len;
+  int units, upb;
+};
+
+__global__ void __launch_bounds__(256) ibtt_synth_kernel(const SynthArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+  unsigned char *base = smem + (size_t)wave * a.l.stride;
+  int32_t *rp = reinterpret_cast<int32_t *>(base + a.l.rp);
+  int32_t *tok = reinterpret_cast<int32_t *>(base + a.l.tok);
+  const int32_t *__restrict__ lut = a.lut;
+  const int pad = a.pad_id, tcap = a.tcap;
+  auto put = [&](int64_t q, int v) { if (q < tcap) tok[q] = v; };
+  auto node_id = [&](int i) { return (GTOK_SLUT_NODE0 + i < a.lut_len) ? lut[GTOK_SLUT_NODE0 + i] : pad; };
+
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * wpb + wave;
+    if (g >= a.g.num_graphs) break;
+    const int nb0 = a.g.node_ptr[g];
+    const int nfull = a.g.node_ptr[g + 1] - nb0;
+    const int n = min(nfull, a.maxn);
+    const int64_t e0 = a.g.edge_ptr[g];
+    const int e = (int)(a.g.edge_ptr[g + 1] - e0);
+    const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
+
+    for (int i = lane; i <= n; i += kWave) rp[i] = rpg[i];
+    wave_sync();
+    // "u v <e>" at 1+3p for the edge at original position p; only entries whose
+    // tokens survive the cut are touched when the order is the identity
+    const int elim = a.g.eorder ? e : min(e, (tcap + 1) / 3 + 1);
+    for (int k = lane; k < elim; k += kWave) {
+      const int p = a.g.eorder ? a.g.eorder[e0 + k] : k;
+      const int64_t q = 1 + 3 * (int64_t)p;
+      if (q < tcap) {
+        const int v = a.g.col[e0 + k];
+        const int u = row_of(rp, n, k);
+        put(q, node_id(u)); put(q + 1, node_id(v)); put(q + 2, lut[GTOK_SLUT_E]);
+      }
+    }
+    const int64_t qn = 1 + 3 * (int64_t)e;
+    for (int i = lane; i < nfull; i += kWave) put(qn + 1 + i, node_id(i));
+    int nq = 0;
+    if (a.query) nq = min(max(a.query[4 * (int64_t)g], 0), 3);
+    if (lane == 0) {
+      put(0, lut[GTOK_SLUT_BOS]);
+      put(qn, lut[GTOK_SLUT_N]);
+      const int64_t qq = qn + 1 + nfull;
+      put(qq, lut[GTOK_SLUT_Q]);
+      for (int i = 0; i < nq; ++i) put(qq + 1 + i, a.query[4 * (int64_t)g + 1 + i]);
+      put(qq + 1 + nq, lut[GTOK_SLUT_P]);
+    }
+    wave_sync();
+    const int64_t T = 1 + 3 * (int64_t)e + 1 + nfull + 1 + nq + 1;
+    const int len = (int)min(T, (int64_t)a.max_len);
+    write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, tcap), pad, [=](int i) -> int { return tok[i]; });
+    if (lane == 0) a.out_len[g] = len;
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TokenDataset on raw text
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool py_isspace(uint32_t c) {
+  return c == 32u || (c >= 9u && c <= 13u) || (c >= 28u && c <= 31u);
+}
+
+struct TextArgs {
+  const uint8_t *bytes; const int64_t *text_ptr; int num_texts;
+  gtok_vocab_table v;
+  int strip_label, cap, max_len, pad_id;
+  int32_t *out; int ld; int32_t *out_len;
+  int units, upb, tok_stride;
+};
+
+__global__ void __launch_bounds__(256) text_ids_kernel(const TextArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+  int32_t *tok = reinterpret_cast<int32_t *>(smem + (size_t)wave * a.tok_stride);
+  const int cap = a.cap;
+  const uint32_t mask = (uint32_t)a.v.capacity - 1u;
+
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * wpb + wave;
+    if (g >= a.num_texts) break;
+    const uint8_t *__restrict__ s = a.bytes + a.text_ptr[g];
+    const int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
+    int count = 0;
+    bool prev_sp = true;  // carry: was the byte before this chunk whitespace
+    bool done = false;
+    for (int64_t b0 = 0; b0 < n && count < a.max_len && !done; b0 += kWave) {
+      const int64_t i = b0 + lane;
+      const uint32_t c = (i < n) ? s[i] : 32u;
+      const bool sp = py_isspace(c);
+      const uint64_t spm = __ballot(sp);
+      const bool before = lane == 0 ? prev_sp : ((spm >> (lane - 1)) & 1ull);
+      const bool start = !sp && before;
+      const uint64_t sm = __ballot(start);
+      prev_sp = (spm >> 63) & 1ull;
+      if (sm == 0) continue;
+      int id = a.pad_id;
+      bool is_p = false;
+      const int t = count + __popcll(sm & lanemask_lt());
+      if (start && t < a.max_len) {
+        // hash the token (FNV-1a), then probe the open-addressing table
+        uint32_t h = 2166136261u;
+        int len = 0;
+        for (int64_t j = i; j < n; ++j) {
+          const uint32_t cj = s[j];
+          if (py_isspace(cj)) break;
+          h = (h ^ cj) * 16777619u;
+          ++len;
+        }
+        is_p = (len == 3) && s[i] == '<' && s[i + 1] == 'p' && s[i + 2] == '>';
+        for (uint32_t slot = h & mask, probes = 0; probes <= mask; slot = (slot + 1) & mask, ++probes) {
+          const int off = a.v.key_off[slot];
+          if (off < 0) break;
+          if (a.v.key_len[slot] != len) continue;
+          bool eq = true;
+          for (int j = 0; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == s[i + j];
+          if (eq) { id = a.v.id[slot]; break; }
+        }
+        if (t < cap) tok[t] = id;
+      }
+      uint64_t pm = a.strip_label ? (uint64_t)__ballot(start && is_p) : 0ull;
+      if (pm) {  // data_loader.py:479-481: keep up to and including the first <p>
+        const int first = __ffsll((unsigned long long)pm) - 1;
+        count += __popcll(sm & ((2ull << first) - 1ull));
+        done = true;
+      } else {
+        count += __popcll(sm);
+      }
+    }
+    wave_sync();
+    const int len = min(count, a.max_len);
+    write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, cap), a.pad_id, [=](int i) -> int { return tok[i]; });
+    if (lane == 0) a.out_len[g] = len;
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// remap_zinc_tokens over a slab; batch collate
+// ---------------------------------------------------------------------------------------------
+__global__ void remap_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out, int ld,
+                             const int32_t *__restrict__ len, int rows, int idx_off, int node_off,
+                             int edge_off) {
+  const int64_t total = (int64_t)rows * ld;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld), c = (int)(i - (int64_t)r * ld);
+    const int t = in[i];
+    out[i] = c < len[r] ? remap_zinc_token(t, idx_off, node_off, edge_off) : t;
+  }
+}
+
+__global__ void batch_max_kernel(const int32_t *__restrict__ len, const int64_t *__restrict__ index,
+                                 int batch, int32_t *__restrict__ batch_max) {
+  __shared__ int red[4];
+  int m = 0;
+  for (int b = threadIdx.x; b < batch; b += blockDim.x) m = max(m, len[index[b]]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_down(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = max(m, red[w]);
+    batch_max[0] = m;
+  }
+}
+
+// one wave per batch row: int32 slab row -> int64 ids + bool mask
+__global__ void __launch_bounds__(256) collate_kernel(const int32_t *__restrict__ ids, int ld,
+                                                      const int32_t *__restrict__ len,
+                                                      const int64_t *__restrict__ index, int batch,
+                                                      int pad_id, int64_t *__restrict__ out_x,
+                                                      uint8_t *__restrict__ out_attn, int out_ld) {
+  const int lane = lane_id();
+  const int b = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  if (b >= batch) return;
+  const int64_t src = index[b];
+  const int l = len[src];
+  const int32_t *__restrict__ row = ids + src * (int64_t)ld;
+  for (int i = lane; i < out_ld; i += kWave) {
+    const bool in = i < l && i < ld;
+    out_x[(int64_t)b * out_ld + i] = in ? (int64_t)row[i] : (int64_t)pad_id;
+    out_attn[(int64_t)b * out_ld + i] = in ? 1 : 0;
+  }
+}
+
+struct Launch { int nb, upb, units; };
+static Launch plan(const void *kern, int num_items, int wpb, size_t lds) {
+  int dev = 0, ncu = 256, occ = 1;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, wpb * 64, lds) != hipSuccess || occ < 1) occ = 1;
+  Launch L;
+  L.units = (num_items + wpb - 1) / wpb;
+  int nb = ncu * occ;
+  if (nb > L.units) nb = L.units;
+  L.upb = (L.units + nb - 1) / nb;
+  L.nb = (L.units + L.upb - 1) / L.upb;
+  return L;
+}
+
+static bool csr_ok(const gtok_csr *g) {
+  return g && g->num_graphs >= 0 && g->node_ptr && g->edge_ptr && g->rowptr && (g->max_edges <= 0 || g->col);
+}
+
+}  // namespace gtok
+
+using namespace gtok;
+
+extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut_len, int32_t max_len,
+                              int32_t pad_id, int32_t *out_ids, int32_t ld, int32_t *out_len,
+                              void *stream) {
+  if (!csr_ok(g) || !lut || lut_len < GTOK_ZLUT_NODE0 || max_len < 0 || !out_ids || !out_len || ld <= 0)
+    return GTOK_E_INVAL;
+  if (g->num_graphs == 0) return GTOK_OK;
+  if (g->max_nodes > 65535 || g->max_edges > 65535) return GTOK_E_TOO_LARGE;
+  ZincArgs a;
+  a.g = *g; a.lut = lut; a.lut_len = lut_len; a.max_len = max_len; a.pad_id = pad_id;
+  a.maxn = g->max_nodes > 0 ? g->max_nodes : 1;
+  a.maxe = g->max_edges > 0 ? g->max_edges : 0;
+  const int64_t tmax = 6 + 2 * (int64_t)a.maxn + 4 * (int64_t)a.maxe;
+  int64_t tcap = max_len < ld ? max_len : ld;
+  if (tmax < tcap) tcap = tmax;
+  if (tcap < 4) tcap = 4;
+  a.tcap = (int)tcap;
+  const int me = a.maxe > 0 ? a.maxe : 1;
+  int off = 0;
+  a.l.rp = off; off += align_up((a.maxn + 1) * 4, 8);
+  a.l.cc = off; off += align_up(me * 2, 8);
+  a.l.co = off; off += align_up(me * 2, 8);
+  a.l.ou = off; off += align_up(me * 2, 8);
+  a.l.ov = off; off += align_up(me * 2, 8);
+  a.l.oa = off; off += align_up(me, 8);
+  a.l.tok = off; off += align_up(a.tcap * 4, 16);
+  a.l.stride = align_up(off, 16);
+  if (a.l.stride > 160 * 1024) return GTOK_E_TOO_LARGE;
+  int wpb = 4;
+  while (wpb > 1 && wpb * a.l.stride > 64 * 1024) wpb >>= 1;
+  const size_t lds = (size_t)wpb * a.l.stride;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(ibtt_zinc_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GTOK_E_LAUNCH;
+  const Launch L = plan(reinterpret_cast<const void *>(ibtt_zinc_kernel), g->num_graphs, wpb, lds);
+  a.out = out_ids; a.ld = ld; a.out_len = out_len; a.units = L.units; a.upb = L.upb;
+  hipLaunchKernelGGL(ibtt_zinc_kernel, dim3(L.nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_ibtt_synth(const gtok_csr *g, const int32_t *lut, int32_t lut_len,
+                               const int32_t *query, int32_t max_len, int32_t pad_id,
+                               int32_t *out_ids, int32_t ld, int32_t *out_len, void *stream) {
+  if (!csr_ok(g) || !lut || lut_len < GTOK_SLUT_NODE0 || max_len < 0 || !out_ids || !out_len || ld <= 0)
+    return GTOK_E_INVAL;
+  if (g->num_graphs == 0) return GTOK_OK;
+  SynthArgs a;
+  a.g = *g; a.lut = lut; a.query = query; a.lut_len = lut_len; a.max_len = max_len; a.pad_id = pad_id;
+  a.maxn = g->max_nodes > 0 ? g->max_nodes : 1;
+  const int64_t tmax = 1 + 3 * (int64_t)(g->max_edges > 0 ? g->max_edges : 0) + 1 + a.maxn + 5;
+  int64_t tcap = max_len < ld ? max_len : ld;
+  if (tmax < tcap) tcap = tmax;
+  if (tcap < 4) tcap = 4;
+  a.tcap = (int)tcap;
+  int off = 0;
+  a.l.rp = off; off += align_up((a.maxn + 1) * 4, 16);
+  a.l.tok = off; off += align_up(a.tcap * 4, 16);
+  a.l.stride = align_up(off, 16);
+  if (a.l.stride > 160 * 1024) return GTOK_E_TOO_LARGE;
+  int wpb = 4;
+  while (wpb > 1 && wpb * a.l.stride > 64 * 1024) wpb >>= 1;
+  const size_t lds = (size_t)wpb * a.l.stride;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(ibtt_synth_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GTOK_E_LAUNCH;
+  const Launch L = plan(reinterpret_cast<const void *>(ibtt_synth_kernel), g->num_graphs, wpb, lds);
+  a.out = out_ids; a.ld = ld; a.out_len = out_len; a.units = L.units; a.upb = L.upb;
+  hipLaunchKernelGGL(ibtt_synth_kernel, dim3(L.nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts,
+                                const gtok_vocab_table *vocab, int32_t strip_label, int32_t max_len,
+                                int32_t *out_ids, int32_t ld, int32_t *out_len, void *stream) {
+  if (!text_ptr || !vocab || num_texts < 0 || max_len < 0 || !out_ids || !out_len || ld <= 0)
+    return GTOK_E_INVAL;
+  if (vocab->capacity <= 0 || (vocab->capacity & (vocab->capacity - 1)) || !vocab->key_off ||
+      !vocab->key_len || !vocab->id || !vocab->key_bytes)
+    return GTOK_E_INVAL;
+  if (num_texts == 0) return GTOK_OK;
+  if (!bytes) return GTOK_E_INVAL;
+  TextArgs a;
+  a.bytes = bytes; a.text_ptr = text_ptr; a.num_texts = num_texts; a.v = *vocab;
+  a.strip_label = strip_label; a.pad_id = vocab->pad_id; a.max_len = max_len;
+  a.cap = max_len < ld ? max_len : ld;
+  a.tok_stride = align_up((a.cap > 0 ? a.cap : 1) * 4, 16);
+  if (a.tok_stride > 160 * 1024) return GTOK_E_TOO_LARGE;
+  int wpb = 4;
+  while (wpb > 1 && wpb * a.tok_stride > 64 * 1024) wpb >>= 1;
+  const size_t lds = (size_t)wpb * a.tok_stride;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(text_ids_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GTOK_E_LAUNCH;
+  const Launch L = plan(reinterpret_cast<const void *>(text_ids_kernel), num_texts, wpb, lds);
+  a.out = out_ids; a.ld = ld; a.out_len = out_len; a.units = L.units; a.upb = L.upb;
+  hipLaunchKernelGGL(text_ids_kernel, dim3(L.nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_remap_zinc(const int32_t *in_ids, int32_t *out_ids, int32_t ld, const int32_t *len,
+                               int32_t num_rows, int32_t idx_offset, int32_t node_idx_offset,
+                               int32_t edge_idx_offset, void *stream) {
+  if (!in_ids || !out_ids || !len || ld <= 0 || num_rows < 0) return GTOK_E_INVAL;
+  if (num_rows == 0) return GTOK_OK;
+  const int64_t total = (int64_t)num_rows * ld;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 256 * 8) nb = 256 * 8;
+  hipLaunchKernelGGL(remap_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, in_ids, out_ids, ld, len,
+                     num_rows, idx_offset, node_idx_offset, edge_idx_offset);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len, const int64_t *index,
+                            int32_t batch, int32_t pad_id, int64_t *out_x, uint8_t *out_attn,
+                            int32_t out_ld, int32_t *batch_max, void *stream) {
+  if (!ids || !len || !index || ld <= 0 || batch < 0 || out_ld < 0) return GTOK_E_INVAL;
+  if (batch == 0) return GTOK_OK;
+  if (batch_max)
+    hipLaunchKernelGGL(batch_max_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, len, index, batch, batch_max);
+  if (out_ld > 0) {
+    if (!out_x || !out_attn) return GTOK_E_INVAL;
+    hipLaunchKernelGGL(collate_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, ld, len,
+                       index, batch, pad_id, out_x, out_attn, out_ld);
+  }
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_version(void) { return 1; }
+extern "C" const char *gtok_target(void) { return "gfx950"; }

@@ -1,0 +1,218 @@
+"""Tensor-level entry points over the C ABI (include/gtok.h).
+
+PyTorch is plumbing here: it owns the device buffers and the HIP stream the
+kernels are enqueued on.  Every function raises if libgtok.so is missing or
+the tensors are not on a GPU — there is no CPU path in the product.
+"""
+import ctypes
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GtokSentParams, GtokVocabTable, check, lib
+from .csr import GraphBatch
+
+SENT_SOS, SENT_RESET, SENT_LADJ, SENT_RADJ, SENT_EOS, SENT_PAD, SENT_IDX_OFFSET = 0, 1, 2, 3, 4, 5, 6
+
+ZINC_ATOM_SYMBOLS = ("C", "N", "O", "F", "P", "S", "Cl", "Br", "I", "X")
+ZINC_BOND_NAMES = ("unknown", "single", "double", "triple", "aromatic")
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _need_gpu(t: torch.Tensor, what: str) -> None:
+    if t.device.type != "cuda":
+        raise _lib.GtokError(f"{what}: tensors must live on the GPU (got {t.device}); the tokenizer has no CPU path")
+
+
+def _round4(v: int) -> int:
+    return max(4, (int(v) + 3) // 4 * 4)
+
+
+def _alloc_out(G: int, ld: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    return (torch.empty((G, ld), dtype=torch.int32, device=device),
+            torch.empty((G,), dtype=torch.int32, device=device))
+
+
+# ------------------------------------------------------------------------------------------------
+# LUT builders (vocab is an INPUT: SURVEY.md F5)
+# ------------------------------------------------------------------------------------------------
+def zinc_lut(vocab: Dict[str, int], num_node_ids: int) -> torch.Tensor:
+    """int32 LUT for gtok_ibtt_zinc; a token absent from `vocab` maps to vocab['<pad>'] exactly as
+    TokenDataset does (graph_data_loader/data_loader.py:482)."""
+    pad = vocab["<pad>"]
+    toks = ["<bos>", "<eos>", "<atom>", "<bond>", "<q>", "regression", "<p>"]
+    toks += list(ZINC_ATOM_SYMBOLS) + list(ZINC_BOND_NAMES) + [str(i) for i in range(num_node_ids)]
+    return torch.tensor([vocab.get(t, pad) for t in toks], dtype=torch.int32)
+
+
+def synth_lut(vocab: Dict[str, int], num_node_ids: int) -> torch.Tensor:
+    pad = vocab["<pad>"]
+    toks = ["<bos>", "<e>", "<n>", "<q>", "<p>"] + [str(i) for i in range(num_node_ids)]
+    return torch.tensor([vocab.get(t, pad) for t in toks], dtype=torch.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+# tokenizers
+# ------------------------------------------------------------------------------------------------
+def ibtt_zinc(batch: GraphBatch, lut: torch.Tensor, max_len: int, pad_id: int,
+              ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """CSR -> IBTT molecular ids.  Returns (ids int32 [G, ld], len int32 [G])."""
+    _need_gpu(batch.col, "ibtt_zinc")
+    dev = batch.device
+    lut = lut.to(dev, dtype=torch.int32).contiguous()
+    if ld is None:
+        ld = _round4(min(max_len, 4 + 2 * batch.max_nodes + 4 * batch.max_edges))
+    ids, ln = _alloc_out(batch.num_graphs, ld, dev)
+    cs = batch.c_struct()
+    check(lib().gtok_ibtt_zinc(ctypes.byref(cs), lut.data_ptr(), lut.numel(), max_len, pad_id,
+                               ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)), "gtok_ibtt_zinc")
+    return ids, ln
+
+
+def ibtt_synth(batch: GraphBatch, lut: torch.Tensor, query: Optional[torch.Tensor], max_len: int, pad_id: int,
+               ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """CSR -> graph-token grammar ids.  query: int32 [G,4] = (count, id0, id1, id2) or None."""
+    _need_gpu(batch.col, "ibtt_synth")
+    dev = batch.device
+    lut = lut.to(dev, dtype=torch.int32).contiguous()
+    if query is not None:
+        query = query.to(dev, dtype=torch.int32).contiguous()
+        if tuple(query.shape) != (batch.num_graphs, 4):
+            raise ValueError("query must be [G, 4]")
+    if ld is None:
+        ld = _round4(min(max_len, 3 * batch.max_edges + batch.max_nodes + 7))
+    ids, ln = _alloc_out(batch.num_graphs, ld, dev)
+    cs = batch.c_struct()
+    check(lib().gtok_ibtt_synth(ctypes.byref(cs), lut.data_ptr(), lut.numel(),
+                                None if query is None else query.data_ptr(), max_len, pad_id,
+                                ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)), "gtok_ibtt_synth")
+    return ids, ln
+
+
+def sent_safe_ld(batch: GraphBatch, labeled: bool, max_len: int, with_query: bool = False) -> int:
+    """Width no SENT row of this batch can exceed (length bound)."""
+    n, e = batch.max_nodes, batch.max_edges
+    bound = (2 + 7 * n + 2 * e) if labeled else (2 + 5 * n + e)
+    return _round4(min(max_len, bound) + (3 if with_query else 0))
+
+
+def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: int = 0, labeled: bool = False,
+         num_node_types: int = 0, num_edge_types: int = 0, remap_zinc: bool = False, pad_id: int = SENT_PAD,
+         graph_base: int = 0, query: Optional[torch.Tensor] = None,
+         ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """SENT trail walk.  Returns (ids int32 [G, ld], len int32 [G]); len > ld flags a too-narrow slab."""
+    _need_gpu(batch.col, "sent")
+    dev = batch.device
+    if query is not None:
+        query = query.to(dev, dtype=torch.int32).contiguous()
+        if tuple(query.shape) != (batch.num_graphs, 2):
+            raise ValueError("query must be [G, 2] (query_u, query_v)")
+    if ld is None:
+        ld = sent_safe_ld(batch, labeled, max_len, query is not None)
+    ids, ln = _alloc_out(batch.num_graphs, ld, dev)
+    p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc),
+                       pad_id, 0, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
+                       None if query is None else query.data_ptr())
+    cs = batch.c_struct()
+    check(lib().gtok_sent(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)),
+          "gtok_sent")
+    return ids, ln
+
+
+def remap_zinc(ids: torch.Tensor, ln: torch.Tensor, idx_offset: int, node_idx_offset: int,
+               edge_idx_offset: int) -> torch.Tensor:
+    _need_gpu(ids, "remap_zinc")
+    ids = ids.contiguous()
+    out = torch.empty_like(ids)
+    check(lib().gtok_remap_zinc(ids.data_ptr(), out.data_ptr(), ids.shape[1], ln.data_ptr(), ids.shape[0],
+                                idx_offset, node_idx_offset, edge_idx_offset, _stream(ids.device)),
+          "gtok_remap_zinc")
+    return out
+
+
+def collate(ids: torch.Tensor, ln: torch.Tensor, index: torch.Tensor, pad_id: int,
+            out_ld: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rows `index` of the slab -> (X int64 [B, out_ld], attn bool [B, out_ld])."""
+    _need_gpu(ids, "collate")
+    dev = ids.device
+    index = index.to(dev, dtype=torch.int64).contiguous()
+    B = int(index.numel())
+    X = torch.empty((B, out_ld), dtype=torch.int64, device=dev)
+    A = torch.empty((B, out_ld), dtype=torch.bool, device=dev)
+    check(lib().gtok_collate(ids.data_ptr(), ids.shape[1], ln.data_ptr(), index.data_ptr(), B, pad_id,
+                             X.data_ptr(), A.data_ptr(), out_ld, None, _stream(dev)), "gtok_collate")
+    return X, A
+
+
+# ------------------------------------------------------------------------------------------------
+# text -> ids (TokenDataset)
+# ------------------------------------------------------------------------------------------------
+def _fnv1a(b: bytes) -> int:
+    h = 2166136261
+    for c in b:
+        h = ((h ^ c) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+class VocabTable:
+    """Open-addressing table (FNV-1a, linear probing) for gtok_text_to_ids, built on the host."""
+
+    def __init__(self, vocab: Dict[str, int], device):
+        self.pad_id = int(vocab["<pad>"])
+        cap = 16
+        while cap < 2 * max(1, len(vocab)):
+            cap *= 2
+        key_off = np.full(cap, -1, np.int32); key_len = np.zeros(cap, np.int32); ids = np.zeros(cap, np.int32)
+        blob = bytearray()
+        for tok, i in vocab.items():
+            b = tok.encode("utf-8")
+            if not b or any(c in b" \t\n\r\x0b\x0c\x1c\x1d\x1e\x1f" for c in b):
+                continue  # can never come out of str.split()
+            s = _fnv1a(b) & (cap - 1)
+            while key_off[s] >= 0:
+                s = (s + 1) & (cap - 1)
+            key_off[s], key_len[s], ids[s] = len(blob), len(b), i
+            blob += b
+        self.capacity = cap
+        t = lambda a: torch.from_numpy(a).to(device)
+        self.key_off, self.key_len, self.ids = t(key_off), t(key_len), t(ids)
+        self.key_bytes = torch.frombuffer(bytearray(blob or b"\0"), dtype=torch.uint8).clone().to(device)
+
+    def c_struct(self) -> GtokVocabTable:
+        return GtokVocabTable(self.capacity, self.pad_id, self.key_off.data_ptr(), self.key_len.data_ptr(),
+                              self.ids.data_ptr(), self.key_bytes.data_ptr())
+
+
+def pack_texts(texts: Sequence[str]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Concatenate texts into (bytes uint8 [total], text_ptr int64 [G+1]); ASCII only (str.split() on
+    non-ASCII whitespace is not reproduced on the device)."""
+    enc = []
+    for t in texts:
+        b = t.encode("utf-8")
+        if len(b) != len(t):
+            raise ValueError("gtok text path handles ASCII text only")
+        enc.append(b)
+    ptr = np.zeros(len(enc) + 1, np.int64)
+    np.cumsum([len(b) for b in enc], out=ptr[1:])
+    blob = b"".join(enc) or b"\0"
+    return torch.frombuffer(bytearray(blob), dtype=torch.uint8).clone(), torch.from_numpy(ptr)
+
+
+def text_to_ids(text_bytes: torch.Tensor, text_ptr: torch.Tensor, table: VocabTable, max_len: int,
+                strip_label: bool = True, ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    _need_gpu(text_bytes, "text_to_ids")
+    dev = text_bytes.device
+    text_ptr = text_ptr.to(dev, dtype=torch.int64).contiguous()
+    G = int(text_ptr.numel()) - 1
+    if ld is None:
+        ld = _round4(max_len)
+    ids, ln = _alloc_out(G, ld, dev)
+    vs = table.c_struct()
+    check(lib().gtok_text_to_ids(text_bytes.data_ptr(), text_ptr.data_ptr(), G, ctypes.byref(vs), int(strip_label),
+                                 max_len, ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)), "gtok_text_to_ids")
+    return ids, ln

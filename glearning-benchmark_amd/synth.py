@@ -1,0 +1,171 @@
+"""Synthetic corpora for parity tests and bench.py (no dataset exists offline: SURVEY.md F4).
+
+  zinc_like()        molecules shaped like PyG ZINC: random tree + ring
+                     closures, 28-way atom ids skewed to C, bond ids 1..3 with rare 0/4, so that the
+                     reference's fallback branches ('X', 'unknown', 22+token_id) fire.
+  graph_token_like() graphs in the families docs/synthetic_data.md:10-20 lists, with the task text
+                     docs/synthetic_data.md:46-68 describes.
+Both return plain numpy batched COO (dict), edge lists in the order a PyG / graph-token file would
+list them.
+"""
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+def _ptr(counts: np.ndarray) -> np.ndarray:
+    p = np.zeros(counts.size + 1, np.int64)
+    np.cumsum(counts, out=p[1:])
+    return p
+
+
+def zinc_like(num_graphs: int, seed: int = 0, mean_nodes: float = 23.2, std_nodes: float = 4.5,
+              min_nodes: int = 9, max_nodes: int = 37, coalesced: bool = True) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    G = int(num_graphs)
+    n = np.clip(np.rint(rng.normal(mean_nodes, std_nodes, G)), min_nodes, max_nodes).astype(np.int64)
+    nptr = _ptr(n)
+    N = int(nptr[-1])
+    gid = np.repeat(np.arange(G), n)
+    li = np.arange(N) - nptr[gid]                                  # local node index
+    # spanning tree: mostly chains with occasional branches
+    r = rng.random(N)
+    parent = np.where(r < 0.72, li - 1, np.floor(rng.random(N) * np.maximum(li, 1)).astype(np.int64))
+    has_p = li >= 1
+    tu, tv, tg = parent[has_p], li[has_p], gid[has_p]
+    # ring closures: 1..4 extra bonds a -- a+d (d = 2..6) per molecule
+    k = rng.integers(1, 5, G)
+    rg = np.repeat(np.arange(G), k)
+    a = np.floor(rng.random(rg.size) * n[rg]).astype(np.int64)
+    b = a + rng.integers(2, 7, rg.size)
+    ok = b < n[rg]
+    ru, rv, rgg = a[ok], b[ok], rg[ok]
+    u = np.concatenate([tu, ru]); v = np.concatenate([tv, rv]); g = np.concatenate([tg, rgg])
+    lo, hi = np.minimum(u, v), np.maximum(u, v)
+    key = (g * 64 + lo) * 64 + hi
+    key = np.unique(key)                                          # simple graph
+    g, lo, hi = key // 4096, (key // 64) % 64, key % 64
+    bond = rng.choice(np.array([1, 2, 3, 0, 4]), size=key.size, p=[0.74, 0.19, 0.05, 0.01, 0.01])
+    # both directions, like PyG's undirected edge_index
+    src = np.concatenate([lo, hi]); dst = np.concatenate([hi, lo]); gg = np.concatenate([g, g])
+    ea = np.concatenate([bond, bond])
+    if coalesced:
+        order = np.lexsort((dst, src, gg))                        # row-sorted within each graph
+    else:
+        order = np.lexsort((rng.random(gg.size), gg))             # arbitrary order inside a graph
+    src, dst, gg, ea = src[order], dst[order], gg[order], ea[order]
+    ecount = np.bincount(gg, minlength=G).astype(np.int64)
+    p_atom = np.full(28, 0.02 / 19)
+    p_atom[:9] = [0.70, 0.10, 0.10, 0.02, 0.005, 0.03, 0.015, 0.005, 0.005]
+    p_atom /= p_atom.sum()
+    x = rng.choice(28, size=N, p=p_atom)
+    y = rng.normal(0.0, 2.0, G).astype(np.float32)
+    return dict(node_counts=n, edge_counts=ecount, src=src.astype(np.int64), dst=dst.astype(np.int64),
+                x=x.astype(np.int64), edge_attr=ea.astype(np.int64), y=y)
+
+
+# ------------------------------------------------------------------------------------------------
+def _family_edges(alg: str, n: int, rng: np.random.Generator, p: float) -> np.ndarray:
+    """Undirected simple edge list [m,2] with u<v, in adjacency-iteration order (networkx edges())."""
+    iu, iv = np.triu_indices(n, 1)
+    if alg == "er":
+        keep = rng.random(iu.size) < p
+    elif alg == "complete":
+        keep = np.ones(iu.size, bool)
+    elif alg == "path":
+        keep = iv == iu + 1
+    elif alg == "star":
+        keep = iu == 0
+    elif alg == "sbm":
+        blk = (np.arange(n) * 2) // max(n, 1)
+        same = blk[iu] == blk[iv]
+        keep = rng.random(iu.size) < np.where(same, min(1.0, 2.0 * p), 0.25 * p)
+    elif alg in ("ba", "sfn"):
+        m = max(1, int(round(p * (n - 1) / 2)))
+        deg = np.zeros(n); edges = []
+        for t in range(1, n):
+            w = deg[:t] + 1.0
+            tgt = rng.choice(t, size=min(m, t), replace=False, p=w / w.sum())
+            for s in tgt:
+                edges.append((int(s), t)); deg[s] += 1; deg[t] += 1
+        e = np.array(sorted(set(edges)), np.int64).reshape(-1, 2)
+        return e
+    else:
+        raise ValueError(f"unknown algorithm {alg}")
+    return np.stack([iu[keep], iv[keep]], 1).astype(np.int64)
+
+
+def _has_cycle(n: int, e: np.ndarray) -> bool:
+    par = list(range(n))
+
+    def find(a):
+        while par[a] != a:
+            par[a] = par[par[a]]
+            a = par[a]
+        return a
+    for u, v in e:
+        ru, rv = find(int(u)), find(int(v))
+        if ru == rv:
+            return True
+        par[ru] = rv
+    return False
+
+
+def _bfs_dist(n: int, e: np.ndarray, s: int) -> np.ndarray:
+    adj: List[List[int]] = [[] for _ in range(n)]
+    for u, v in e:
+        adj[int(u)].append(int(v)); adj[int(v)].append(int(u))
+    d = np.full(n, -1); d[s] = 0; q = [s]
+    for a in q:
+        for b in adj[a]:
+            if d[b] < 0:
+                d[b] = d[a] + 1; q.append(b)
+    return d
+
+
+def graph_token_like(num_graphs: int, seed: int = 1234, algorithms: Sequence[str] = ("er", "ba", "sbm", "path", "star", "complete"),
+                     min_nodes: int = 10, max_nodes: int = 49, min_sparsity: float = 0.1, max_sparsity: float = 0.2,
+                     task: Optional[str] = "cycle_check", with_text: bool = True) -> Dict[str, object]:
+    """Per-graph Python loop: fine up to ~1e5 graphs.  task in {None,'cycle_check','shortest_path'}."""
+    rng = np.random.default_rng(seed)
+    ncs, ecs, srcs, dsts, texts, labels, queries, algs = [], [], [], [], [], [], [], []
+    for i in range(num_graphs):
+        alg = algorithms[i % len(algorithms)]
+        n = int(rng.integers(min_nodes, max_nodes + 1))
+        e = _family_edges(alg, n, rng, float(rng.uniform(min_sparsity, max_sparsity)))
+        ncs.append(n); ecs.append(e.shape[0]); srcs.append(e[:, 0]); dsts.append(e[:, 1]); algs.append(alg)
+        q, lab, tail = None, None, ""
+        if task == "cycle_check":
+            lab = int(_has_cycle(n, e)); tail = f"<q> has_cycle <p> {'yes' if lab else 'no'} <eos>"
+        elif task == "shortest_path":
+            u = int(rng.integers(0, n)); v = int(rng.integers(0, n - 1)); v += v >= u
+            d = int(_bfs_dist(n, e, u)[v])
+            q = (u, v); lab = d - 1 if d > 0 else None
+            tail = f"<q> shortest_distance {u} {v} <p> {'len%d' % d if d > 0 else 'INF'} <eos>"
+        labels.append(lab); queries.append(q)
+        if with_text:
+            body = " ".join(f"{a} {b} <e>" for a, b in e)
+            texts.append(" ".join(t for t in ("<bos>", body, "<n>", " ".join(map(str, range(n))), tail) if t))
+    cat = lambda l: np.concatenate(l) if l else np.zeros(0, np.int64)
+    return dict(node_counts=np.asarray(ncs, np.int64), edge_counts=np.asarray(ecs, np.int64), src=cat(srcs),
+                dst=cat(dsts), texts=texts, labels=labels, queries=queries, algorithms=algs)
+
+
+def er_batch(num_graphs: int, seed: int = 0, min_nodes: int = 10, max_nodes: int = 256,
+             min_sparsity: float = 0.1, max_sparsity: float = 0.2, chunk: int = 2048) -> Dict[str, np.ndarray]:
+    """Vectorised Erdős–Rényi corpus for the large-graph roofline run:
+    one direction per undirected edge (u<v), row-sorted, as graph-token files list them."""
+    rng = np.random.default_rng(seed)
+    n = rng.integers(min_nodes, max_nodes + 1, num_graphs).astype(np.int64)
+    p = rng.uniform(min_sparsity, max_sparsity, num_graphs)
+    srcs, dsts, ecs = [], [], np.zeros(num_graphs, np.int64)
+    for c0 in range(0, num_graphs, chunk):
+        nn, pp = n[c0:c0 + chunk], p[c0:c0 + chunk]
+        m = int(nn.max())
+        iu, iv = np.triu_indices(m, 1)
+        for j in range(nn.size):
+            sel = iv < nn[j]
+            keep = rng.random(int(sel.sum())) < pp[j]
+            srcs.append(iu[sel][keep]); dsts.append(iv[sel][keep]); ecs[c0 + j] = int(keep.sum())
+    cat = lambda l: np.concatenate(l).astype(np.int64) if l else np.zeros(0, np.int64)
+    return dict(node_counts=n, edge_counts=ecs, src=cat(srcs), dst=cat(dsts))

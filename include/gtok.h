@@ -1,0 +1,194 @@
+/*
+ * gtok.h — C ABI of libgtok.so, the MI355X (gfx950) graph->sequence tokenizer.
+ *
+ * Every entry point replaces one piece of the reference's Python hot path
+ * (paths relative to the reference checkout):
+ *
+ *   gtok_ibtt_zinc     graph_data_loader/zinc_dataset_indexbase.py:143-227
+ *                      (tokenize_molecule + __getitem__ truncation) fused with
+ *                      graph_data_loader/data_loader.py:465-484 (TokenDataset:
+ *                      strip after <p>, vocab lookup, [:max_len])
+ *   gtok_text_to_ids   graph_data_loader/data_loader.py:465-484 (TokenDataset on
+ *                      arbitrary whitespace-tokenised text, any grammar)
+ *   gtok_ibtt_synth    the graph-token index-based grammar
+ *                      (docs/synthetic_data.md:46-68) emitted straight from the
+ *                      edge list, then data_loader.py:479-482
+ *   gtok_sent          autograph Graph2TrailTokenizer.__call__ as called at
+ *                      trainer/train_agtt.py:250 (SENT walk; spec in DESIGN.md,
+ *                      upstream parity unpinned), optionally fused with
+ *                      remap_zinc_tokens (:171-244) and the query append (:257-267)
+ *   gtok_remap_zinc    trainer/train_agtt.py:171-244 on an existing token slab
+ *   gtok_collate       data_loader.py:488-497 and trainer/train_agtt.py:276-302
+ *                      (gather rows of a batch, pad to the batch max, bool mask)
+ *
+ * Conventions: all pointers are DEVICE pointers borrowed from the caller
+ * (never freed or retained), `stream` is a hipStream_t passed as void*, the
+ * call only enqueues work on that stream (no allocation, no synchronisation:
+ * safe under hipGraph capture), outputs are caller-allocated.  Return value is
+ * 0 or a negative GTOK_E_* code; nothing throws across the ABI.  Re-entrant.
+ *
+ * Output convention of every tokenizer entry point: out_ids is a row-major
+ * [rows, ld] int32 slab; row g receives its first min(out_len[g], ld) ids and
+ * pad_id after them; out_len[g] is the TRUE sequence length (already cut at
+ * max_len as the reference does), so out_len[g] > ld tells the caller that
+ * the slab was too narrow for that row.
+ *
+ * Batched CSR layout (gtok_csr), G graphs, graph g has N_g nodes and E_g
+ * directed adjacency entries exactly as the source edge_index lists them:
+ *   node_ptr[G+1]  int32  prefix sum of N_g
+ *   edge_ptr[G+1]  int64  prefix sum of E_g
+ *   rowptr[sum(N_g)+G] int32  graph g's N_g+1 LOCAL row pointers start at
+ *                             node_ptr[g]+g; entry k of row u lives at
+ *                             edge_ptr[g] + rowptr_g[u] + k
+ *   col[sum E_g]   int32  local neighbour id
+ *   eorder[sum E_g] int32 position of the entry in the graph's original COO
+ *                         edge list (NULL = identity, i.e. edge_index was
+ *                         already row-sorted); IBTT's first-occurrence rule
+ *                         needs it
+ *   nattr[sum N_g] uint8  node type (x); NULL for unlabelled graphs
+ *   eattr[sum E_g] uint8  edge type (edge_attr); NULL for unlabelled graphs
+ */
+#ifndef GTOK_H
+#define GTOK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTOK_OK 0
+#define GTOK_E_INVAL (-1)     /* null pointer / negative size / bad flag        */
+#define GTOK_E_TOO_LARGE (-2) /* a graph exceeds the LDS-resident limits        */
+#define GTOK_E_LAUNCH (-3)    /* hipLaunchKernel reported an error              */
+#define GTOK_E_NO_DEVICE (-4) /* no gfx950 device visible                       */
+
+#define GTOK_MAX_NODES 512 /* SENT adjacency bit-matrix rows per wave (LDS)  */
+
+typedef struct gtok_csr {
+  int32_t num_graphs;
+  int32_t max_nodes; /* max N_g over the batch (host-known)                 */
+  int32_t max_edges; /* max E_g over the batch (host-known)                 */
+  int32_t reserved;
+  const int32_t *node_ptr;
+  const int64_t *edge_ptr;
+  const int32_t *rowptr;
+  const int32_t *col;
+  const int32_t *eorder;
+  const uint8_t *nattr;
+  const uint8_t *eattr;
+} gtok_csr;
+
+/* LUT layout for gtok_ibtt_zinc (int32 vocab ids; an absent token holds pad_id
+ * exactly as TokenDataset's vocab.get(tok, vocab['<pad>']) would give):
+ *   [0] <bos> [1] <eos> [2] <atom> [3] <bond> [4] <q> [5] regression [6] <p>
+ *   [7..16]  atom symbols C N O F P S Cl Br I, then 'X'   (x outside 0..8)
+ *   [17..21] 'unknown', single, double, triple, aromatic  (index = attr if 1..4 else 0)
+ *   [22..22+n) decimal strings "0".."n-1"                  (node indices) */
+#define GTOK_ZLUT_BOS 0
+#define GTOK_ZLUT_EOS 1
+#define GTOK_ZLUT_ATOM 2
+#define GTOK_ZLUT_BOND 3
+#define GTOK_ZLUT_Q 4
+#define GTOK_ZLUT_REGRESSION 5
+#define GTOK_ZLUT_P 6
+#define GTOK_ZLUT_ATOM0 7
+#define GTOK_ZLUT_BOND0 17
+#define GTOK_ZLUT_NODE0 22
+
+/* IBTT molecular serialiser -> ids.
+ * lut_len = 22 + number of node-index entries (must cover max_nodes).      */
+int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut_len,
+                   int32_t max_len, int32_t pad_id, int32_t *out_ids,
+                   int32_t ld, int32_t *out_len, void *stream);
+
+/* LUT layout for gtok_ibtt_synth:
+ *   [0] <bos> [1] <e> [2] <n> [3] <q> [4] <p>  [5..5+n) "0".."n-1"           */
+#define GTOK_SLUT_BOS 0
+#define GTOK_SLUT_E 1
+#define GTOK_SLUT_N 2
+#define GTOK_SLUT_Q 3
+#define GTOK_SLUT_P 4
+#define GTOK_SLUT_NODE0 5
+
+/* graph-token grammar "<bos> u v <e> ... <n> 0 1 .. N-1 <q> q0 [q1 q2] <p>":
+ * edges in ORIGINAL order (needs eorder unless identity), query[g*4+0] =
+ * number of query ids (0..3), query[g*4+1..3] = the vocab ids after <q>.     */
+int gtok_ibtt_synth(const gtok_csr *g, const int32_t *lut, int32_t lut_len,
+                    const int32_t *query, int32_t max_len, int32_t pad_id,
+                    int32_t *out_ids, int32_t ld, int32_t *out_len,
+                    void *stream);
+
+/* Open-addressing vocab table for gtok_text_to_ids, built on the host by
+ * the Python mirror (capacity a power of two): slot s holds key_off[s] (byte
+ * offset of the token string in key_bytes, -1 = empty), key_len[s], id[s].
+ * Hash = 32-bit FNV-1a of the token bytes; probe linearly.                   */
+typedef struct gtok_vocab_table {
+  int32_t capacity;
+  int32_t pad_id;
+  const int32_t *key_off;
+  const int32_t *key_len;
+  const int32_t *id;
+  const uint8_t *key_bytes;
+} gtok_vocab_table;
+
+/* TokenDataset: texts are concatenated ASCII bytes, text g = bytes
+ * [text_ptr[g], text_ptr[g+1]).  Splits on Python str.split() ASCII
+ * whitespace, keeps tokens up to and including the first "<p>" when
+ * strip_label != 0, maps through the table (miss -> pad_id), cuts at
+ * max_len.                                                                   */
+int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr,
+                     int32_t num_texts, const gtok_vocab_table *vocab,
+                     int32_t strip_label, int32_t max_len, int32_t *out_ids,
+                     int32_t ld, int32_t *out_len, void *stream);
+
+#define GTOK_SENT_SOS 0
+#define GTOK_SENT_RESET 1
+#define GTOK_SENT_LADJ 2
+#define GTOK_SENT_RADJ 3
+#define GTOK_SENT_EOS 4
+#define GTOK_SENT_PAD 5
+#define GTOK_SENT_IDX_OFFSET 6
+
+typedef struct gtok_sent_params {
+  int32_t max_num_nodes;  /* tokenizer.set_num_nodes()                      */
+  int32_t labeled;        /* labeled_graph: emit node/edge type tokens      */
+  int32_t num_node_types; /* set_num_node_and_edge_types()                  */
+  int32_t num_edge_types;
+  int32_t max_len;        /* max_length == truncation_length                */
+  int32_t remap_zinc;     /* fuse TokenizedGraphDataset.remap_zinc_tokens   */
+  int32_t pad_id;         /* slab fill (Graph2TrailTokenizer.pad = 5)       */
+  int32_t reserved;
+  uint64_t seed;          /* Philox key                                     */
+  uint64_t epoch;         /* a new trail every epoch                        */
+  int64_t graph_base;     /* global index of graph 0 (shard-invariant RNG)  */
+  const int32_t *query;   /* NULL, or [G,2] (query_u, query_v): appends
+                             idx_off+N, idx_off+u, idx_off+v after the trail */
+} gtok_sent_params;
+
+/* SENT trail walk -> ids.  out_len[g] = min(trail, max_len) (+3 if query). */
+int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids,
+              int32_t ld, int32_t *out_len, void *stream);
+
+/* remap_zinc_tokens over the first len[g] ids of every row, in place or not. */
+int gtok_remap_zinc(const int32_t *in_ids, int32_t *out_ids, int32_t ld,
+                    const int32_t *len, int32_t num_rows, int32_t idx_offset,
+                    int32_t node_idx_offset, int32_t edge_idx_offset,
+                    void *stream);
+
+/* Batch collate: rows index[b] of the [*, ld] slab -> X[B, out_ld] int64
+ * (pad_id beyond the row length; columns >= the batch max stay pad) and
+ * attn[B, out_ld] uint8 (bool).  batch_max[0] receives max length.          */
+int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len,
+                 const int64_t *index, int32_t batch, int32_t pad_id,
+                 int64_t *out_x, uint8_t *out_attn, int32_t out_ld,
+                 int32_t *batch_max, void *stream);
+
+/* Library/ABI version and build target string ("gfx950").                   */
+int gtok_version(void);
+const char *gtok_target(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTOK_H */

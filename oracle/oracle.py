@@ -1,0 +1,203 @@
+"""numpy/ctypes front end of the CPU oracle (oracle/gtok_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; the product package never imports this module.
+Inputs are PyG-style batched COO (what the reference's Python iterates over).
+SENT parity vs upstream AutoGraph is UNPINNED (see the C file's header).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgtok_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "gtok_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libgtok_oracle.so"], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def num_threads() -> int:
+    return int(lib().oracle_num_threads())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np.int32)
+
+
+def _i64(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np.int64)
+
+
+class Coo:
+    """Batched COO: per-graph node/edge counts + concatenated local-id edge lists and raw int attrs."""
+
+    def __init__(self, node_counts, edge_counts, src, dst, x=None, edge_attr=None):
+        self.node_counts = _i64(node_counts)
+        self.edge_counts = _i64(edge_counts)
+        self.G = int(self.node_counts.size)
+        self.node_ptr = np.zeros(self.G + 1, np.int32); self.node_ptr[1:] = np.cumsum(self.node_counts)
+        self.edge_ptr = np.zeros(self.G + 1, np.int64); self.edge_ptr[1:] = np.cumsum(self.edge_counts)
+        self.src, self.dst = _i32(src), _i32(dst)
+        self.x, self.edge_attr = _i32(x), _i32(edge_attr)
+
+    def slice(self, lo, hi):
+        n0, n1, e0, e1 = self.node_ptr[lo], self.node_ptr[hi], self.edge_ptr[lo], self.edge_ptr[hi]
+        s = lambda a, i, j: None if a is None else a[i:j]
+        return Coo(self.node_counts[lo:hi], self.edge_counts[lo:hi], self.src[e0:e1], self.dst[e0:e1],
+                   s(self.x, n0, n1), s(self.edge_attr, e0, e1))
+
+
+def ibtt_zinc(coo: Coo, lut, max_len, pad_id, ld, nthreads=1):
+    lut = _i32(lut)
+    out = np.empty((coo.G, ld), np.int32); ln = np.empty(coo.G, np.int32)
+    x = coo.x if coo.x is not None else np.full(int(coo.node_ptr[-1]), 255, np.int32)
+    lib().oracle_ibtt_zinc(ctypes.c_int32(coo.G), _p(coo.node_ptr), _p(coo.edge_ptr), _p(x), _p(coo.src), _p(coo.dst),
+                           _p(coo.edge_attr), _p(lut), ctypes.c_int32(lut.size), ctypes.c_int32(max_len),
+                           ctypes.c_int32(pad_id), _p(out), ctypes.c_int32(ld), _p(ln), ctypes.c_int32(nthreads))
+    return out, ln
+
+
+def ibtt_synth(coo: Coo, lut, query, max_len, pad_id, ld, nthreads=1):
+    lut = _i32(lut)
+    q = None if query is None else np.ascontiguousarray(query, dtype=np.int32)
+    out = np.empty((coo.G, ld), np.int32); ln = np.empty(coo.G, np.int32)
+    lib().oracle_ibtt_synth(ctypes.c_int32(coo.G), _p(coo.node_ptr), _p(coo.edge_ptr), _p(coo.src), _p(coo.dst),
+                            _p(lut), ctypes.c_int32(lut.size), _p(q), ctypes.c_int32(max_len), ctypes.c_int32(pad_id),
+                            _p(out), ctypes.c_int32(ld), _p(ln), ctypes.c_int32(nthreads))
+    return out, ln
+
+
+def text_to_ids(texts, vocab, max_len, ld, strip_label=True, nthreads=1):
+    enc = [t.encode("utf-8") for t in texts]
+    ptr = np.zeros(len(enc) + 1, np.int64); ptr[1:] = np.cumsum([len(b) for b in enc])
+    blob = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy()
+    keys = [k.encode("utf-8") for k in vocab]
+    voff = np.zeros(len(keys) + 1, np.int32); voff[1:] = np.cumsum([len(k) for k in keys])
+    vbytes = np.frombuffer(b"".join(keys) + b"\0", dtype=np.uint8).copy()
+    vid = np.asarray(list(vocab.values()), np.int32)
+    out = np.empty((len(enc), ld), np.int32); ln = np.empty(len(enc), np.int32)
+    lib().oracle_text_to_ids(_p(blob), _p(ptr), ctypes.c_int32(len(enc)), _p(vbytes), _p(voff), _p(vid),
+                             ctypes.c_int32(len(keys)), ctypes.c_int32(vocab["<pad>"]), ctypes.c_int32(int(strip_label)),
+                             ctypes.c_int32(max_len), _p(out), ctypes.c_int32(ld), _p(ln), ctypes.c_int32(nthreads))
+    return out, ln
+
+
+def collate(ids, ln, index, pad_id, out_ld):
+    ids = np.ascontiguousarray(ids, np.int32); ln = _i32(ln); index = _i64(index)
+    B = index.size
+    X = np.empty((B, out_ld), np.int64); A = np.empty((B, out_ld), np.uint8); m = np.zeros(1, np.int32)
+    lib().oracle_collate(_p(ids), ctypes.c_int32(ids.shape[1]), _p(ln), _p(index), ctypes.c_int32(B),
+                         ctypes.c_int32(pad_id), _p(X), _p(A), ctypes.c_int32(out_ld), _p(m))
+    return X, A.astype(bool), int(m[0])
+
+
+def remap_zinc(ids, ln, idx_off, node_off, edge_off):
+    ids = np.ascontiguousarray(ids, np.int32); ln = _i32(ln)
+    out = np.empty_like(ids)
+    lib().oracle_remap_zinc(_p(ids), _p(out), ctypes.c_int32(ids.shape[1]), _p(ln), ctypes.c_int32(ids.shape[0]),
+                            ctypes.c_int32(idx_off), ctypes.c_int32(node_off), ctypes.c_int32(edge_off))
+    return out
+
+
+def philox4x32_10(ctr, key):
+    c = np.asarray(ctr, np.uint32); k = np.asarray(key, np.uint32); o = np.zeros(4, np.uint32)
+    lib().oracle_philox4x32_10(_p(c), _p(k), _p(o))
+    return o
+
+
+def sent(coo: Coo, max_num_nodes, max_len, seed, epoch=0, labeled=False, num_node_types=0, num_edge_types=0,
+         remap_zinc=False, pad_id=5, graph_base=0, query=None, ld=None, nthreads=1):
+    if ld is None:
+        ld = max_len + (3 if query is not None else 0)
+    q = None if query is None else np.ascontiguousarray(query, dtype=np.int32)
+    out = np.empty((coo.G, ld), np.int32); ln = np.empty(coo.G, np.int32)
+    lib().oracle_sent(ctypes.c_int32(coo.G), _p(coo.node_ptr), _p(coo.edge_ptr), _p(coo.x), _p(coo.src), _p(coo.dst),
+                      _p(coo.edge_attr), ctypes.c_int32(int(labeled)), ctypes.c_int32(max_num_nodes),
+                      ctypes.c_int32(num_node_types), ctypes.c_int32(num_edge_types), ctypes.c_int32(max_len),
+                      ctypes.c_int32(int(remap_zinc)), ctypes.c_int32(pad_id), ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                      ctypes.c_uint64(epoch & (2 ** 64 - 1)), ctypes.c_int64(graph_base), _p(q), _p(out),
+                      ctypes.c_int32(ld), _p(ln), ctypes.c_int32(nthreads))
+    return out, ln
+
+
+# ------------------------------------------------------------------------------------------------
+# SENT decoder (pure Python, small cases): token stream -> graph, used for the losslessness and
+# reference-visible-invariant property tests.
+# ------------------------------------------------------------------------------------------------
+def sent_decode(tokens, max_num_nodes, labeled=False, num_node_types=0):
+    """Returns (num_nodes, set of frozenset edges, node_types dict by visit idx, edge_types dict)."""
+    idx_off, node_off = 6, 6 + max_num_nodes
+    edge_off = node_off + num_node_types
+    toks = list(tokens)
+    assert toks[0] == 0, "must start with SOS"
+    i, prev, nseen = 1, None, 0
+    edges, ntypes, etypes = set(), {}, {}
+    pending_et = None
+
+    def is_pos(t):
+        return idx_off <= t < node_off
+
+    while i < len(toks):
+        t = toks[i]
+        if t == 4:  # EOS
+            i += 1
+            break
+        if t == 1:  # RESET
+            prev, pending_et = None, None
+            i += 1
+            continue
+        if t == 2:  # LADJ ... RADJ: edges from the current node to earlier nodes
+            i += 1
+            while toks[i] != 3:
+                et = None
+                if labeled:
+                    et = toks[i] - edge_off; i += 1
+                a = toks[i] - idx_off; i += 1
+                e = frozenset((prev, a))
+                assert e not in edges, "edge encoded twice"
+                edges.add(e)
+                if labeled:
+                    etypes[e] = et
+            i += 1
+            continue
+        if labeled and not is_pos(t):  # edge type preceding a trail step
+            pending_et = t - edge_off
+            i += 1
+            continue
+        assert is_pos(t), f"unexpected token {t}"
+        k = t - idx_off
+        i += 1
+        if k == nseen:  # first visit
+            nseen += 1
+            if labeled:
+                ntypes[k] = toks[i] - node_off; i += 1
+        else:
+            assert k < nseen
+        if prev is not None:
+            e = frozenset((prev, k))
+            assert e not in edges, "edge encoded twice"
+            edges.add(e)
+            if labeled:
+                etypes[e] = pending_et
+        pending_et = None
+        prev = k
+    return nseen, edges, ntypes, etypes, i

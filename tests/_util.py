@@ -1,0 +1,59 @@
+"""Shared helpers for the parity tests: one synthetic corpus -> (product GraphBatch, oracle Coo)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+gtok = importlib.import_module("glearning-benchmark_amd")
+import oracle as orc  # noqa: E402
+
+FIXED_ZINC_VOCAB = {t: i for i, t in enumerate(
+    ["<bos>", "<eos>", "<pad>", "<unk>", "<q>", "<p>", "<atom>", "<bond>", "C", "N", "O", "F", "P", "S", "Cl",
+     "Br", "I", "single", "double", "triple", "aromatic", "regression"])}
+
+
+def zinc_vocab(num_node_ids=40, with_fallbacks=True):
+    v = dict(FIXED_ZINC_VOCAB)
+    for i in range(num_node_ids):
+        v[str(i)] = len(v)
+    if with_fallbacks:
+        v["X"] = len(v); v["unknown"] = len(v)
+    return v
+
+
+def both(d, labeled=True):
+    x = d.get("x") if labeled else None
+    ea = d.get("edge_attr") if labeled else None
+    batch = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], x, ea)
+    coo = orc.Coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], x, ea)
+    return batch, coo
+
+
+def edge_case_graphs():
+    """Hand-made graphs: empty, single node, isolated nodes, self loops, duplicate and reversed-first
+    edges, two components, out-of-range types (what the reference's fallbacks handle)."""
+    graphs = [
+        dict(n=0, e=[], x=[], a=[]),
+        dict(n=1, e=[], x=[3], a=[]),
+        dict(n=5, e=[], x=[0, 1, 2, 9, 27], a=[]),
+        dict(n=3, e=[(2, 0), (0, 2), (1, 1), (1, 2), (0, 2)], x=[12, 5, 8], a=[3, 3, 0, 2, 1]),   # SURVEY Mol B
+        dict(n=4, e=[(0, 1), (1, 0), (1, 2), (2, 1), (2, 3), (3, 2)], x=[0, 1, 2, 0], a=[1, 1, 2, 2, 4, 4]),  # Mol A
+        dict(n=4, e=[(0, 0), (0, 1), (1, 0), (0, 1), (3, 3)], x=[0, 0, 0, 0], a=[1, 2, 3, 4, 0]),
+        dict(n=6, e=[(0, 1), (1, 2), (2, 0), (3, 4), (4, 5), (5, 3)], x=[1] * 6, a=[1, 2, 3, 1, 2, 3]),
+        dict(n=7, e=[(6, 5), (5, 4), (4, 3), (3, 2), (2, 1), (1, 0), (0, 6)], x=[8] * 7, a=[4] * 7),
+        dict(n=2, e=[(1, 0)], x=[200, 254], a=[77]),
+    ]
+    k = 8
+    graphs.append(dict(n=k, e=[(i, j) for i in range(k) for j in range(k) if i != j], x=list(range(k)),
+                       a=[(i + j) % 6 for i in range(k) for j in range(k) if i != j]))
+    return dict(node_counts=np.array([g["n"] for g in graphs]), edge_counts=np.array([len(g["e"]) for g in graphs]),
+                src=np.array([u for g in graphs for u, _ in g["e"]], np.int64),
+                dst=np.array([v for g in graphs for _, v in g["e"]], np.int64),
+                x=np.array([t for g in graphs for t in g["x"]], np.int64),
+                edge_attr=np.array([t for g in graphs for t in g["a"]], np.int64))

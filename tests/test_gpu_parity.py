@@ -1,0 +1,162 @@
+"""GPU parity: every HIP entry point, called through the C ABI, against the CPU oracle — bit-exact
+(integer work).  Sizes are what the oracle finishes in seconds; corpus-scale properties live in
+test_gpu_properties.py."""
+import numpy as np
+import pytest
+import torch
+
+from _util import both, edge_case_graphs, gtok, orc, zinc_vocab
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cmp(ids, ln, ref_ids, ref_ln, what):
+    ids, ln = ids.cpu().numpy(), ln.cpu().numpy()
+    assert np.array_equal(ln, ref_ln), f"{what}: lengths differ at {np.nonzero(ln != ref_ln)[0][:5]}"
+    bad = np.nonzero((ids != ref_ids).any(1))[0]
+    assert bad.size == 0, f"{what}: rows differ {bad[:5]}: {ids[bad[0]].tolist()} vs {ref_ids[bad[0]].tolist()}"
+
+
+@pytest.mark.parametrize("coalesced", [True, False])
+@pytest.mark.parametrize("max_len,ld", [(1024, None), (64, 64), (10, 12), (1, 4), (0, 4), (1024, 40)])
+def test_ibtt_zinc(coalesced, max_len, ld):
+    d = gtok.synth.zinc_like(3000, seed=3, coalesced=coalesced)
+    batch, coo = both(d)
+    vocab = zinc_vocab(40)
+    lut = gtok.ops.zinc_lut(vocab, 40)
+    ids, ln = gtok.ops.ibtt_zinc(batch.to(DEV), lut, max_len, vocab["<pad>"], ld=ld)
+    ref, rln = orc.ibtt_zinc(coo, lut.numpy(), max_len, vocab["<pad>"], ids.shape[1])
+    _cmp(ids, ln, ref, rln, "ibtt_zinc")
+
+
+def test_ibtt_zinc_edge_cases_and_missing_vocab():
+    d = edge_case_graphs()
+    batch, coo = both(d)
+    vocab = zinc_vocab(4, with_fallbacks=False)      # most node ids, 'X', 'unknown' fall back to <pad>
+    lut = gtok.ops.zinc_lut(vocab, 4)
+    for max_len in (1024, 7, 3):
+        ids, ln = gtok.ops.ibtt_zinc(batch.to(DEV), lut, max_len, vocab["<pad>"])
+        ref, rln = orc.ibtt_zinc(coo, lut.numpy(), max_len, vocab["<pad>"], ids.shape[1])
+        _cmp(ids, ln, ref, rln, f"ibtt_zinc edge max_len={max_len}")
+
+
+SENT_CASES = [
+    dict(name="zinc_labeled", gen=lambda: gtok.synth.zinc_like(4000, seed=5), labeled=True, nn=37),
+    dict(name="zinc_uncoalesced", gen=lambda: gtok.synth.zinc_like(1000, seed=6, coalesced=False), labeled=True, nn=37),
+    dict(name="zinc_unlabeled", gen=lambda: gtok.synth.zinc_like(2000, seed=7), labeled=False, nn=40),
+    dict(name="graph_token", gen=lambda: gtok.synth.graph_token_like(600, seed=8, with_text=False), labeled=False, nn=49),
+    dict(name="er_128", gen=lambda: gtok.synth.er_batch(150, seed=9, min_nodes=65, max_nodes=128), labeled=False, nn=128),
+    dict(name="er_256", gen=lambda: gtok.synth.er_batch(100, seed=10, min_nodes=10, max_nodes=256), labeled=False, nn=256),
+    dict(name="er_400", gen=lambda: gtok.synth.er_batch(24, seed=11, min_nodes=300, max_nodes=400,
+                                                        min_sparsity=0.02, max_sparsity=0.05), labeled=False, nn=400),
+    dict(name="edge_cases", gen=edge_case_graphs, labeled=True, nn=8),
+    dict(name="edge_cases_unlabeled", gen=edge_case_graphs, labeled=False, nn=8),
+]
+
+
+@pytest.mark.parametrize("case", SENT_CASES, ids=[c["name"] for c in SENT_CASES])
+@pytest.mark.parametrize("max_len", [1024, 48])
+def test_sent(case, max_len):
+    d = case["gen"]()
+    batch, coo = both(d, case["labeled"])
+    kw = dict(labeled=case["labeled"], num_node_types=28 if case["labeled"] else 0,
+              num_edge_types=5 if case["labeled"] else 0)
+    dbatch = batch.to(DEV)
+    for seed, epoch, base in ((0, 0, 0), (12345678901234567, 3, 10 ** 10)):
+        ids, ln = gtok.ops.sent(dbatch, case["nn"], max_len, seed, epoch, graph_base=base, **kw)
+        ref, rln = orc.sent(coo, case["nn"], max_len, seed, epoch, graph_base=base, ld=ids.shape[1], **kw)
+        _cmp(ids, ln, ref, rln, f"sent {case['name']} seed={seed}")
+
+
+def test_sent_remap_query_and_narrow_slab():
+    d = gtok.synth.zinc_like(1500, seed=21)
+    batch, coo = both(d)
+    dbatch = batch.to(DEV)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4)
+    ids, ln = gtok.ops.sent(dbatch, 37, 1024, 99, 1, remap_zinc=True, **kw)
+    ref, rln = orc.sent(coo, 37, 1024, 99, 1, remap_zinc=True, ld=ids.shape[1], **kw)
+    _cmp(ids, ln, ref, rln, "sent+remap")
+    # stand-alone remap kernel == fused remap
+    raw, rl = gtok.ops.sent(dbatch, 37, 1024, 99, 1, **kw)
+    re = gtok.ops.remap_zinc(raw, rl, 6, 6 + 37, 6 + 37 + 9)
+    mask = (torch.arange(raw.shape[1], device=DEV)[None, :] < rl[:, None])
+    assert torch.equal(torch.where(mask, re, ids), ids)
+    # query append on unlabelled graphs (shortest_path), incl. a slab narrower than some rows
+    g = gtok.synth.graph_token_like(500, seed=22, task="shortest_path", with_text=False)
+    b2, c2 = both(g, False)
+    q = np.array([qq if qq is not None else (0, 0) for qq in g["queries"]], np.int32)
+    for ld in (None, 40):
+        ids, ln = gtok.ops.sent(b2.to(DEV), 49, 600, 5, 2, query=torch.from_numpy(q), ld=ld)
+        ref, rln = orc.sent(c2, 49, 600, 5, 2, query=q, ld=ids.shape[1])
+        _cmp(ids, ln, ref, rln, f"sent+query ld={ld}")
+        if ld is not None:
+            assert (ln.cpu().numpy() > ld).any(), "test should exercise the too-narrow-slab signal"
+
+
+def test_sent_is_shard_invariant():
+    d = gtok.synth.zinc_like(1001, seed=30)
+    batch, _ = both(d)
+    full, fl = gtok.ops.sent(batch.to(DEV), 37, 256, 4, 0, labeled=True, num_node_types=28, num_edge_types=5, ld=256)
+    parts = []
+    for lo, hi in ((0, 334), (334, 668), (668, 1001)):
+        ids, ln = gtok.ops.sent(batch.shard(lo, hi).to(DEV), 37, 256, 4, 0, labeled=True, num_node_types=28,
+                                num_edge_types=5, graph_base=lo, ld=256)
+        parts.append(ids)
+    assert torch.equal(torch.cat(parts), full)
+
+
+def test_ibtt_synth_and_text():
+    g = gtok.synth.graph_token_like(800, seed=40, task="shortest_path")
+    batch, coo = both(g, False)
+    from collections import Counter
+    cnt = Counter(t for s in g["texts"] for t in s.split())
+    vocab = {t: i for i, t in enumerate(["<pad>", "<bos>", "<e>", "<n>", "<q>", "<p>", "<eos>", "yes", "no"])}
+    for t, _ in cnt.most_common():
+        if t not in vocab and len(vocab) < 45:       # small vocab: some node ids fall back to <pad>
+            vocab[t] = len(vocab)
+    pad = vocab["<pad>"]
+    lut = gtok.ops.synth_lut(vocab, 64)
+    q = np.zeros((batch.num_graphs, 4), np.int32)
+    for i, qq in enumerate(g["queries"]):
+        q[i] = (3, vocab.get("shortest_distance", pad), vocab.get(str(qq[0]), pad), vocab.get(str(qq[1]), pad))
+    for max_len in (600, 100):
+        ids, ln = gtok.ops.ibtt_synth(batch.to(DEV), lut, torch.from_numpy(q), max_len, pad)
+        ref, rln = orc.ibtt_synth(coo, lut.numpy(), q, max_len, pad, ids.shape[1])
+        _cmp(ids, ln, ref, rln, "ibtt_synth")
+        # the same ids must come out of the generic text path (TokenDataset semantics)
+        tb, tp = gtok.ops.pack_texts(g["texts"])
+        table = gtok.ops.VocabTable(vocab, DEV)
+        tids, tln = gtok.ops.text_to_ids(tb.to(DEV), tp, table, max_len, ld=ids.shape[1])
+        tref, trln = orc.text_to_ids(g["texts"], vocab, max_len, ids.shape[1])
+        _cmp(tids, tln, tref, trln, "text_to_ids")
+        _cmp(tids, tln, ref, rln, "text_to_ids vs ibtt_synth")
+
+
+def test_text_to_ids_odd_whitespace_and_no_label():
+    texts = ["", "   ", "<bos> 1 2\t<e>\n\n3  4 <e> <n> 1 2 3 4 <q> has_cycle <p> yes <eos>", "<p>", "a<p> <p>x <p> tail",
+             "x" * 300 + " y " + "z" * 70, "\x1c<bos>\x1f1\x0b2\x0c<e>\r", " ".join(str(i) for i in range(700))]
+    vocab = {"<pad>": 0, "<bos>": 1, "<e>": 2, "<n>": 3, "<q>": 4, "<p>": 5, "<eos>": 6, "yes": 7, "no": 8,
+             "1": 9, "2": 10, "3": 11, "has_cycle": 12, "x" * 300: 13, "z" * 70: 14, "699": 15, "a<p>": 16}
+    table = gtok.ops.VocabTable(vocab, DEV)
+    tb, tp = gtok.ops.pack_texts(texts)
+    for strip in (True, False):
+        for max_len in (600, 5):
+            ids, ln = gtok.ops.text_to_ids(tb.to(DEV), tp, table, max_len, strip_label=strip)
+            ref, rln = orc.text_to_ids(texts, vocab, max_len, ids.shape[1], strip_label=strip)
+            _cmp(ids, ln, ref, rln, f"text strip={strip} max_len={max_len}")
+
+
+def test_collate():
+    d = gtok.synth.zinc_like(300, seed=50)
+    batch, _ = both(d)
+    vocab = zinc_vocab(40)
+    ids, ln = gtok.ops.ibtt_zinc(batch.to(DEV), gtok.ops.zinc_lut(vocab, 40), 1024, 2)
+    rng = np.random.default_rng(0)
+    index = rng.permutation(300)[:128]
+    lmax = int(ln.cpu().numpy()[index].max())
+    for out_ld in (lmax, lmax + 5):
+        X, A = gtok.ops.collate(ids, ln, torch.from_numpy(index), 2, out_ld)
+        rX, rA, m = orc.collate(ids.cpu().numpy(), ln.cpu().numpy(), index, 2, out_ld)
+        assert m == lmax and X.dtype == torch.int64 and A.dtype == torch.bool
+        assert np.array_equal(X.cpu().numpy(), rX) and np.array_equal(A.cpu().numpy(), rA)
