@@ -261,7 +261,8 @@ __global__ void __launch_bounds__(256) sent_kernel(const SentArgs a) {
     s.n = n; s.pos = 0; s.d = 0; s.nvis = 0;
     s.gid_lo = (uint32_t)gid; s.gid_hi = (uint32_t)(gid >> 32);
 
-    for (int i = lane; i < n * W + W; i += kWave) s.adj[i] = 0;  // rows + vis (contiguous)
+    for (int i = lane; i < n * W; i += kWave) s.adj[i] = 0;
+    if (lane < W) s.vis[lane] = 0;
     s.fill_rng(0);
     if (LAB) {
       for (int i = lane; i <= n; i += kWave) s.rp[i] = rpg[i];

@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 gtok = importlib.import_module("glearning-benchmark_amd")
+gtok.build()  # no-op unless csrc/ is newer than libgtok.so (hipcc cross-compiles without a GPU)
 import oracle as orc  # noqa: E402
 
 FIXED_ZINC_VOCAB = {t: i for i, t in enumerate(

@@ -15,7 +15,12 @@ def _cmp(ids, ln, ref_ids, ref_ln, what):
     ids, ln = ids.cpu().numpy(), ln.cpu().numpy()
     assert np.array_equal(ln, ref_ln), f"{what}: lengths differ at {np.nonzero(ln != ref_ln)[0][:5]}"
     bad = np.nonzero((ids != ref_ids).any(1))[0]
-    assert bad.size == 0, f"{what}: rows differ {bad[:5]}: {ids[bad[0]].tolist()} vs {ref_ids[bad[0]].tolist()}"
+    if bad.size:
+        r = bad[0]
+        c = int(np.nonzero(ids[r] != ref_ids[r])[0][0])
+        lo = max(0, c - 12)
+        raise AssertionError(f"{what}: {bad.size} rows differ, first row {r} col {c}: "
+                             f"{ids[r, lo:c + 8].tolist()} vs {ref_ids[r, lo:c + 8].tolist()}")
 
 
 @pytest.mark.parametrize("coalesced", [True, False])
