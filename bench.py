@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py — graphs tokenized/sec + emitted tokens/sec on the ZINC-full-shaped corpus (BASELINE.json).
+
+A "step" is one epoch pass of the AGTT hot path over the rank's resident corpus: labelled SENT trail
+walk fused with the fixed-vocab ZINC remap (trainer/train_agtt.py:246-254), CSR already in HBM.
+One process per GPU; ranks hold their own 249,456-graph shard (weak scaling, no data-path
+collective; the optional all-gather of the padded slab is timed separately and reported beside it).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+gtok = importlib.import_module("glearning-benchmark_amd")
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+ZINC_FULL_GRAPHS = 249456      # 220,011 / 24,445 / 5,000
+WORKLOADS = {
+    "zinc_full": dict(graphs=ZINC_FULL_GRAPHS, desc="AGTT labelled SENT + fused ZINC remap, ZINC-full-shaped synthetic molecules"),
+    "zinc_subset": dict(graphs=12000, desc="AGTT labelled SENT + fused ZINC remap, ZINC-subset-shaped synthetic molecules"),
+}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(msg, file=sys.stderr, flush=True)
+
+
+def event_ms(pairs):
+    return [s.elapsed_time(e) for s, e in pairs]
+
+
+def timed_loop(fn, steps, world):
+    """barrier + synchronize on both sides, K launches between, HIP events around every launch
+    (recorded on the stream the kernels run on)."""
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        pairs[k][0].record()
+        fn(k)
+        pairs[k][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, event_ms(pairs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="zinc_full", choices=sorted(WORKLOADS))
+    ap.add_argument("--graphs", type=int, default=None, help="graphs per rank (default: the workload's size)")
+    ap.add_argument("--ld", default="tight", choices=["tight", "safe"],
+                    help="slab width: measured max length + margin (verified after the run) or the a-priori bound")
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="graphs in the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ibtt", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the tokenizer has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    G = args.graphs or wl["graphs"]
+    max_len, ntypes, etypes = 1024, 9, 4
+    t_gen = time.perf_counter()
+    d = gtok.synth.zinc_like(G, seed=1000 + rank)
+    host = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+    batch = host.to(dev)
+    torch.cuda.synchronize()
+    log(f"[bench] rank corpus: {G} graphs, {host.num_nodes_total} nodes, {host.num_edges_total} CSR entries "
+        f"({time.perf_counter() - t_gen:.1f}s to generate + upload)")
+    max_nodes = gtok.dist.all_reduce_max_int(host.max_nodes, dev)   # tokenizer.set_num_nodes (train_agtt.py:534)
+    graph_base = rank * G
+    kw = dict(labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True, graph_base=graph_base)
+
+    # slab width
+    safe_ld = gtok.ops.sent_safe_ld(batch, True, max_len)
+    if args.ld == "tight":
+        _, ln0 = gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=0, ld=safe_ld, **kw)
+        ld = min(safe_ld, (int(ln0.max().item()) * 5 // 4 + 8 + 3) // 4 * 4)
+        ld = gtok.dist.all_reduce_max_int(ld, dev)
+    else:
+        ld = gtok.dist.all_reduce_max_int(safe_ld, dev)
+    ids = torch.empty((G, ld), dtype=torch.int32, device=dev)
+    lens = [torch.empty((G,), dtype=torch.int32, device=dev) for _ in range(args.steps)]
+    scratch_len = torch.empty((G,), dtype=torch.int32, device=dev)
+
+    def step(k, ln):
+        gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(ids, ln), **kw)
+
+    for w in range(args.warmup):
+        step(w, scratch_len)
+    wall, kern_ms = timed_loop(lambda k: step(args.warmup + k, lens[k]), args.steps, world)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+
+    all_len = torch.stack(lens)
+    if int(all_len.max().item()) > ld:
+        raise SystemExit(f"slab width {ld} too narrow for a timed step (max len {int(all_len.max())}): rerun with --ld safe")
+    tok_total = torch.tensor([float(all_len.sum().item())], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tok_total)
+    tokens_per_step_rank = float(all_len.sum().item()) / args.steps
+    value = world * G * args.steps / wall
+    tokens_per_sec = float(tok_total.item()) / wall
+
+    # roofline of the dominant kernel (sent_kernel<1,true>): algorithmic bytes / launch duration
+    read_b = host.algorithmic_read_bytes(ibtt=False, labeled=True)
+    write_b = 4.0 * tokens_per_step_rank + 4.0 * G
+    kern_s = float(np.mean(kern_ms)) * 1e-3
+    achieved = (read_b + write_b) / kern_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        rec = json.load(open(tpath)).get(f"sent:{args.workload}:{G}:{args.ld}")
+        if rec:
+            traffic = rec["hbm_bytes_per_launch"]
+    roofline = dict(bound="hbm", kernel="sent_kernel<W=1,labelled>", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    algorithmic_bytes_per_launch=int(read_b + write_b), kernel_ms=round(kern_s * 1e3, 4),
+                    padded_slab_bytes_per_launch=int(4 * G * ld))
+
+    out = dict(metric="graphs_tokenized_per_sec", value=round(value, 1), unit="graphs/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 4),
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
+               tokens_per_sec=round(tokens_per_sec, 1),
+               config=dict(workload=f"{args.workload}: {wl['desc']}", graphs_per_gpu=G, max_len=max_len,
+                           slab_width=ld, slab_width_mode=args.ld, avg_tokens_per_graph=round(tokens_per_step_rank / G, 2),
+                           parallelism=f"graph-sharded x{world}, no data-path collective"),
+               roofline=roofline)
+
+    # IBTT molecular serialiser on the same corpus (second half of the metric; outside the timed region)
+    if not args.no_ibtt:
+        vocab = {t: i for i, t in enumerate(
+            ["<bos>", "<eos>", "<pad>", "<unk>", "<q>", "<p>", "<atom>", "<bond>", "C", "N", "O", "F", "P", "S", "Cl",
+             "Br", "I", "single", "double", "triple", "aromatic", "regression"]
+            + [str(i) for i in range(max_nodes)] + ["X", "unknown"])}
+        lut = gtok.ops.zinc_lut(vocab, max_nodes).to(dev)
+        ild = (min(max_len, 4 + 2 * host.max_nodes + 4 * host.max_edges) + 3) // 4 * 4
+        iids = torch.empty((G, ild), dtype=torch.int32, device=dev)
+        iln = torch.empty((G,), dtype=torch.int32, device=dev)
+        f = lambda k: gtok.ops.ibtt_zinc(batch, lut, max_len, vocab["<pad>"], ld=ild, out=(iids, iln))
+        for _ in range(args.warmup):
+            f(0)
+        iwall, ik_ms = timed_loop(f, args.steps, world)
+        itok = float(iln.sum().item())
+        ib = host.algorithmic_read_bytes(ibtt=True, labeled=True) + 4.0 * itok + 4.0 * G
+        ik = float(np.mean(ik_ms)) * 1e-3
+        out["ibtt"] = dict(graphs_per_sec_per_gpu=round(G * args.steps / iwall, 1),
+                           tokens_per_sec_per_gpu=round(itok * args.steps / iwall, 1), kernel_ms=round(ik * 1e3, 4),
+                           slab_width=ild, roofline=dict(bound="hbm", achieved=round(ib / ik / 1e9, 2), peak=HBM_PEAK_GBS,
+                                                         unit="GB/s", frac=round(ib / ik / 1e9 / HBM_PEAK_GBS, 5)))
+
+    # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
+    if world > 1:
+        gtok.dist.gather_tokens(ids, lens[-1], world * G, 5)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            gtok.dist.gather_tokens(ids, lens[-1], world * G, 5)
+        torch.cuda.synchronize(); dist.barrier()
+        ag = (time.perf_counter() - t0) / reps
+        agt = torch.tensor([ag], dtype=torch.float64, device=dev)
+        dist.all_reduce(agt, op=dist.ReduceOp.MAX)
+        recv = (world - 1) * G * (ld + 1) * 4
+        out["allgather"] = dict(ms=round(float(agt.item()) * 1e3, 3), bytes_received_per_gpu=recv,
+                                GBps_per_gpu=round(recv / float(agt.item()) / 1e9, 2))
+
+    # CPU baseline: the oracle (a port, not the reference's Python) on a bounded sample, rank 0, N=1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc
+        S = min(G, args.cpu_sample)
+        coo = orc.Coo(d["node_counts"][:S], d["edge_counts"][:S], d["src"][:int(host.edge_ptr[S])],
+                      d["dst"][:int(host.edge_ptr[S])], d["x"][:int(host.node_ptr[S])],
+                      d["edge_attr"][:int(host.edge_ptr[S])])
+        cores = orc.num_threads()
+        okw = dict(labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True, ld=ld, nthreads=cores)
+        orc.sent(coo.slice(0, min(S, 2000)), max_nodes, max_len, 0, 0, **okw)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or time.perf_counter() - t0 < 10.0:
+            ref, rln = orc.sent(coo, max_nodes, max_len, 0, args.warmup + reps, **okw)
+            reps += 1
+        cpu_s = (time.perf_counter() - t0) / reps
+        # the sample doubles as an end-of-run parity check on the very buffers that were timed
+        chk = min(S, 4096)
+        step(args.warmup + reps - 1, scratch_len)
+        torch.cuda.synchronize()
+        same = np.array_equal(ids[:chk].cpu().numpy(), ref[:chk]) and np.array_equal(scratch_len[:chk].cpu().numpy(), rln[:chk])
+        out["cpu_baseline"] = dict(value=round(S / cpu_s, 1), unit="graphs/s", cores=cores, kind="port",
+                                   sample=f"first {S} graphs of the same corpus, oracle/gtok_oracle.c:oracle_sent "
+                                          f"(OpenMP, {cores} threads), {reps} passes",
+                                   tokens_per_sec=round(float(rln.sum()) / cpu_s, 1), parity_with_gpu=bool(same))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

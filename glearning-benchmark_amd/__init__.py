@@ -7,7 +7,7 @@ Putting this directory itself on ``sys.path`` exposes the drop-in ``graph_data_l
 """
 import sys as _sys
 
-from . import _lib, csr, ops, synth  # noqa: F401
+from . import _lib, csr, dist, ops, synth  # noqa: F401
 from ._lib import GtokError, build, lib  # noqa: F401
 from .csr import GraphBatch  # noqa: F401
 

@@ -33,7 +33,14 @@ def _round4(v: int) -> int:
     return max(4, (int(v) + 3) // 4 * 4)
 
 
-def _alloc_out(G: int, ld: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+def _alloc_out(G: int, ld: int, device, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fresh [G, ld] int32 slab + [G] lengths, or the caller's preallocated pair (`out`)."""
+    if out is not None:
+        ids, ln = out
+        if ids.dtype != torch.int32 or ln.dtype != torch.int32 or tuple(ids.shape) != (G, ld) \
+                or ln.numel() != G or not ids.is_contiguous() or ids.device != torch.device(device):
+            raise ValueError("out must be (int32 [G, ld] contiguous, int32 [G]) on the batch's device")
+        return ids, ln
     return (torch.empty((G, ld), dtype=torch.int32, device=device),
             torch.empty((G,), dtype=torch.int32, device=device))
 
@@ -60,14 +67,14 @@ def synth_lut(vocab: Dict[str, int], num_node_ids: int) -> torch.Tensor:
 # tokenizers
 # ------------------------------------------------------------------------------------------------
 def ibtt_zinc(batch: GraphBatch, lut: torch.Tensor, max_len: int, pad_id: int,
-              ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+              ld: Optional[int] = None, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """CSR -> IBTT molecular ids.  Returns (ids int32 [G, ld], len int32 [G])."""
     _need_gpu(batch.col, "ibtt_zinc")
     dev = batch.device
     lut = lut.to(dev, dtype=torch.int32).contiguous()
     if ld is None:
         ld = _round4(min(max_len, 4 + 2 * batch.max_nodes + 4 * batch.max_edges))
-    ids, ln = _alloc_out(batch.num_graphs, ld, dev)
+    ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
     cs = batch.c_struct()
     check(lib().gtok_ibtt_zinc(ctypes.byref(cs), lut.data_ptr(), lut.numel(), max_len, pad_id,
                                ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)), "gtok_ibtt_zinc")
@@ -75,7 +82,7 @@ def ibtt_zinc(batch: GraphBatch, lut: torch.Tensor, max_len: int, pad_id: int,
 
 
 def ibtt_synth(batch: GraphBatch, lut: torch.Tensor, query: Optional[torch.Tensor], max_len: int, pad_id: int,
-               ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+               ld: Optional[int] = None, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """CSR -> graph-token grammar ids.  query: int32 [G,4] = (count, id0, id1, id2) or None."""
     _need_gpu(batch.col, "ibtt_synth")
     dev = batch.device
@@ -86,7 +93,7 @@ def ibtt_synth(batch: GraphBatch, lut: torch.Tensor, query: Optional[torch.Tenso
             raise ValueError("query must be [G, 4]")
     if ld is None:
         ld = _round4(min(max_len, 3 * batch.max_edges + batch.max_nodes + 7))
-    ids, ln = _alloc_out(batch.num_graphs, ld, dev)
+    ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
     cs = batch.c_struct()
     check(lib().gtok_ibtt_synth(ctypes.byref(cs), lut.data_ptr(), lut.numel(),
                                 None if query is None else query.data_ptr(), max_len, pad_id,
@@ -104,7 +111,7 @@ def sent_safe_ld(batch: GraphBatch, labeled: bool, max_len: int, with_query: boo
 def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: int = 0, labeled: bool = False,
          num_node_types: int = 0, num_edge_types: int = 0, remap_zinc: bool = False, pad_id: int = SENT_PAD,
          graph_base: int = 0, query: Optional[torch.Tensor] = None,
-         ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+         ld: Optional[int] = None, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """SENT trail walk.  Returns (ids int32 [G, ld], len int32 [G]); len > ld flags a too-narrow slab."""
     _need_gpu(batch.col, "sent")
     dev = batch.device
@@ -114,7 +121,7 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
             raise ValueError("query must be [G, 2] (query_u, query_v)")
     if ld is None:
         ld = sent_safe_ld(batch, labeled, max_len, query is not None)
-    ids, ln = _alloc_out(batch.num_graphs, ld, dev)
+    ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
     p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc),
                        pad_id, 0, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
                        None if query is None else query.data_ptr())
