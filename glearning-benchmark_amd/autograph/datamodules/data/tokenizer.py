@@ -1,0 +1,95 @@
+"""`Graph2TrailTokenizer` with the interface trainer/train_agtt.py uses (ctor kwargs :514-530,
+set_num_nodes :535, set_num_node_and_edge_types :540, idx/node/edge offsets :189-191, class attr `pad`
+:286, `tokenizer(data) -> 1-D LongTensor` :250), backed by the gfx950 SENT kernel.
+
+This is NOT upstream AutoGraph: the walk follows the spec in DESIGN.md §SENT (upstream is un-vendored and
+un-pinned in the reference, so token-for-token parity with it is unpinned — SURVEY.md §8c).
+"""
+from typing import Optional, Sequence
+
+import torch
+
+# the root package is found by path, so this file works both as glearning-benchmark_amd.autograph... and as
+# the top-level `autograph` package trainer/train_agtt.py:21 imports (drop-in sys.path layout)
+import importlib
+import os
+import sys
+
+_PKG_DIR = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+if os.path.basename(_PKG_DIR) in sys.modules:
+    _pkg = sys.modules[os.path.basename(_PKG_DIR)]
+else:
+    sys.path.insert(0, os.path.dirname(_PKG_DIR))
+    _pkg = importlib.import_module(os.path.basename(_PKG_DIR))
+_ops, GtokError, GraphBatch = _pkg.ops, _pkg.GtokError, _pkg.GraphBatch
+
+
+class Graph2TrailTokenizer:
+    sos, reset, ladj, radj, eos, pad = 0, 1, 2, 3, 4, 5
+
+    def __init__(self, dataset_names: Optional[Sequence[str]] = None, max_length: int = -1,
+                 truncation_length: Optional[int] = None, labeled_graph: bool = False, undirected: bool = True,
+                 seed: int = 0, device=None, **unused):
+        if dataset_names:
+            raise ValueError("dataset-name tokens are not supported (the reference always passes dataset_names=[])")
+        if not undirected:
+            raise ValueError("only undirected=True is implemented (what the reference uses)")
+        self.max_length = max_length
+        self.truncation_length = truncation_length if truncation_length is not None else max_length
+        self.labeled_graph = labeled_graph
+        self.undirected = True
+        self.idx_offset = 6
+        self.max_num_nodes = None
+        self.node_idx_offset = None
+        self.edge_idx_offset = None
+        self.num_node_types = 0
+        self.num_edge_types = 0
+        self.seed = seed
+        self.device = device
+        self._calls = 0
+
+    # ---- configuration (same call order as train_agtt.py:534-540)
+    def set_num_nodes(self, max_num_nodes: int) -> None:
+        self.max_num_nodes = int(max_num_nodes)
+        self.node_idx_offset = self.idx_offset + self.max_num_nodes
+        self.edge_idx_offset = self.node_idx_offset + self.num_node_types
+
+    def set_num_node_and_edge_types(self, num_node_types: int, num_edge_types: int) -> None:
+        if self.max_num_nodes is None:
+            raise RuntimeError("call set_num_nodes() first")
+        self.num_node_types, self.num_edge_types = int(num_node_types), int(num_edge_types)
+        self.edge_idx_offset = self.node_idx_offset + self.num_node_types
+
+    def __len__(self) -> int:
+        """Size of the raw (un-remapped) id space."""
+        return (self.edge_idx_offset or self.idx_offset) + self.num_edge_types
+
+    def _max_len(self) -> int:
+        m = self.truncation_length if self.truncation_length and self.truncation_length > 0 else self.max_length
+        return int(m) if m and m > 0 else 1 << 20
+
+    def _device(self):
+        if self.device is not None:
+            return torch.device(self.device)
+        if not torch.cuda.is_available():
+            raise GtokError("Graph2TrailTokenizer runs on the GPU and no GPU is visible; there is no CPU path")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    # ---- batched fast path: one launch for a whole split / epoch
+    def tokenize_batch(self, batch: "GraphBatch", epoch: int = 0, graph_base: int = 0, remap_zinc: bool = False,
+                       query: Optional[torch.Tensor] = None, ld: Optional[int] = None, out=None):
+        """(ids int32 [G, ld], len int32 [G]) on the device; trail g is a function of (seed, epoch, graph_base+g)."""
+        if self.max_num_nodes is None:
+            raise RuntimeError("call set_num_nodes() first")
+        return _ops.sent(batch, self.max_num_nodes, self._max_len(), self.seed, epoch, labeled=self.labeled_graph,
+                         num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
+                         remap_zinc=remap_zinc, pad_id=self.pad, graph_base=graph_base, query=query, ld=ld, out=out)
+
+    # ---- reference call site: one Data in, one 1-D LongTensor out, a fresh random trail per call
+    def tokenize(self, data) -> torch.Tensor:
+        batch = GraphBatch.from_data_list([data], labeled=self.labeled_graph).to(self._device())
+        ids, ln = self.tokenize_batch(batch, epoch=0, graph_base=self._calls)
+        self._calls += 1
+        return ids[0, :int(ln[0])].to(torch.long).cpu()
+
+    __call__ = tokenize

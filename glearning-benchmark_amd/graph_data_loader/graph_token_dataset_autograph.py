@@ -1,0 +1,207 @@
+"""graph-token JSON -> graphs for the SENT tokenizer — mirror of the reference's
+graph_data_loader/graph_token_dataset_autograph.py (parsers :14-158, dataset :161-408).
+
+No torch_geometric here: items are light `Data` objects with the fields the trainer reads
+(edge_index [2,E] long, y, num_nodes, query_u, query_v) and `graph_batch()` is the batched CSR the
+kernels consume.  Edge lists keep the text order, one direction per undirected edge, like the reference.
+"""
+import json
+import os
+import random
+from glob import glob
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ._root import root as _root
+
+GraphBatch = _root().GraphBatch
+
+_STOP = ("<q>", "<p>", "<eos>")
+
+
+class Data:
+    """Stand-in for torch_geometric.data.Data: plain attribute bag."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def __repr__(self):
+        return "Data(" + ", ".join(f"{k}={getattr(v, 'shape', v)}" for k, v in self.__dict__.items()) + ")"
+
+
+def parse_graph_from_text(text: str) -> Tuple[List[int], List[Tuple[int, int]]]:
+    """'... u v <e> ... <n> a b c' -> (nodes, edges).  Edges are `int int <e>` triples scanned left to right;
+    the scan ends at '<n>', whose integer list (up to <q>/<p>/<eos> or a non-integer) is the node list."""
+    toks = text.split()
+    nodes: List[int] = []
+    edges: List[Tuple[int, int]] = []
+    i, n = 0, len(toks)
+    while i < n:
+        if i + 2 < n and toks[i + 2] == "<e>":
+            try:
+                edges.append((int(toks[i]), int(toks[i + 1])))
+                i += 3
+            except ValueError:
+                i += 1
+            continue
+        if toks[i] == "<n>" and i + 1 < n:
+            for t in toks[i + 1:]:
+                if t in _STOP:
+                    break
+                try:
+                    nodes.append(int(t))
+                except ValueError:
+                    break
+            break
+        i += 1
+    return nodes, edges
+
+
+def parse_query_nodes_from_text(text: str) -> Optional[Tuple[int, int]]:
+    toks = text.split()
+    for i in range(len(toks) - 3):
+        if toks[i] == "<q>" and toks[i + 1] == "shortest_distance":
+            try:
+                return int(toks[i + 2]), int(toks[i + 3])
+            except ValueError:
+                pass
+    return None
+
+
+def parse_label_from_text(text: str, task: str = "cycle_check") -> Optional[int]:
+    """'<p> yes|no' -> 1|0, '<p> lenK' -> K-1, '<p> INF' -> None (reference :80-113)."""
+    toks = text.split()
+    for i in range(len(toks) - 1):
+        if toks[i] != "<p>":
+            continue
+        lab = toks[i + 1].upper()
+        if lab in ("YES", "NO"):
+            return int(lab == "YES")
+        if lab.startswith("LEN"):
+            try:
+                return int(lab[3:]) - 1
+            except ValueError:
+                pass
+        if lab in ("INF", "INFINITY"):
+            return None
+    return None
+
+
+def parse_graph_from_json(record: dict, task: str = "cycle_check"):
+    """(edges, num_nodes, label): explicit 'nodes'/'edges'/'label' fields win, the text fills the gaps;
+    num_nodes = max(node list)+1, else max endpoint+1 (reference :116-158)."""
+    nodes = record.get("nodes", [])
+    edges = record.get("edges", [])
+    text = record.get("text", "")
+    if not edges and text:
+        nodes, edges = parse_graph_from_text(text)
+    label = record.get("label")
+    if label is None and text:
+        label = parse_label_from_text(text, task=task)
+    if nodes:
+        num_nodes = max(nodes) + 1
+    elif edges:
+        num_nodes = max(max(s, t) for s, t in edges) + 1
+    else:
+        num_nodes = 0
+    return edges, num_nodes, label
+
+
+class GraphTokenDatasetForAutoGraph:
+    """Same constructor arguments and sampling rules as the reference class; holds the graphs in memory
+    (no processed/*.pt cache: that file format belongs to PyG) and exposes them both as items and as CSR."""
+
+    def __init__(self, root: str, task: str = "cycle_check", algorithm=None, split: str = "train",
+                 use_split_tasks_dirs: bool = True, seed: int = 0, num_graphs: Optional[int] = None,
+                 num_pairs_per_graph: Optional[int] = None, transform=None, pre_transform=None, pre_filter=None):
+        self.task = task
+        self.algorithms = [algorithm] if isinstance(algorithm, str) else (["er"] if algorithm is None else list(algorithm))
+        self.algorithm = self.algorithms[0]
+        self.split, self.use_split_tasks_dirs, self.seed = split, use_split_tasks_dirs, seed
+        self.num_graphs, self.num_pairs_per_graph = num_graphs, num_pairs_per_graph
+        self._root, self.transform, self.pre_transform, self.pre_filter = root, transform, pre_transform, pre_filter
+        self._data_list = self.process()
+        self._batch = None
+
+    def _split_dir(self, algo: str) -> str:
+        if self.use_split_tasks_dirs:
+            top = "tasks_test" if self.split in ("val", "test") else "tasks_train"
+            base = os.path.join(self._root, top, self.task, algo)
+        else:
+            base = os.path.join(self._root, "tasks", self.task, algo)
+        d = os.path.join(base, self.split)
+        if self.split == "val" and self.use_split_tasks_dirs and not glob(os.path.join(d, "*.json")):
+            d = os.path.join(base, "test")
+        return d
+
+    def _make(self, edges, num_nodes, label, query):
+        ei = torch.tensor(edges, dtype=torch.long).t().contiguous() if len(edges) else torch.empty((2, 0), dtype=torch.long)
+        d = Data(edge_index=ei, y=torch.tensor([label], dtype=torch.long), num_nodes=num_nodes)
+        if query is not None:
+            d.query_u, d.query_v = query
+        if self.pre_filter is not None and not self.pre_filter(d):
+            return None
+        return self.pre_transform(d) if self.pre_transform is not None else d
+
+    def process(self) -> List[Data]:
+        files: List[str] = []
+        for algo in self.algorithms:
+            pattern = os.path.join(self._split_dir(algo), "*.json")
+            af = sorted(glob(pattern))
+            if self.num_graphs is not None and len(af) > self.num_graphs:
+                total = len(af)
+                af = sorted(random.Random(self.seed + hash(algo) % 10000).sample(af, self.num_graphs))
+                print(f"  [{algo}] Sampled {self.num_graphs}/{total} graph files")
+            files += af
+        if not files:
+            raise RuntimeError(f"No JSON files found for algorithms {self.algorithms}. "
+                               f"Did you run the graph-token task generator?")
+        print(f"[GraphTokenDatasetForAutoGraph] Processing {len(files)} graph files from {len(self.algorithms)} algorithm(s)")
+        out: List[Data] = []
+        rng = random.Random(self.seed)
+        pairs_mode = self.task == "shortest_path" and self.num_pairs_per_graph is not None
+        for fp in files:
+            with open(fp, "r") as f:
+                content = json.load(f)
+            recs = content if isinstance(content, list) else [content]
+            parsed = []
+            for r in recs:
+                edges, n, label = parse_graph_from_json(r, task=self.task)
+                if n == 0 or label is None:
+                    continue
+                text = r.get("text", "")
+                q = parse_query_nodes_from_text(text) if (self.task == "shortest_path" and text) else None
+                if pairs_mode and q is None:
+                    continue
+                parsed.append((edges, n, label, q))
+            if pairs_mode and len(parsed) > self.num_pairs_per_graph:
+                parsed = rng.sample(parsed, self.num_pairs_per_graph)
+            for p in parsed:
+                d = self._make(*p)
+                if d is not None:
+                    out.append(d)
+        print(f"[GraphTokenDatasetForAutoGraph] Processed {len(out)} data samples")
+        return out
+
+    def __len__(self):
+        return len(self._data_list)
+
+    def __getitem__(self, idx):
+        d = self._data_list[idx]
+        return self.transform(d) if self.transform is not None else d
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def graph_batch(self) -> GraphBatch:
+        if self._batch is None:
+            self._batch = GraphBatch.from_data_list(self._data_list, labeled=False)
+        return self._batch
+
+    def queries(self) -> Optional[np.ndarray]:
+        """[G,2] (query_u, query_v) when every item carries a query, else None."""
+        if not self._data_list or not all(hasattr(d, "query_u") for d in self._data_list):
+            return None
+        return np.array([[d.query_u, d.query_v] for d in self._data_list], np.int32)

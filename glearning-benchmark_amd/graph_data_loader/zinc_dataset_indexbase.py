@@ -1,0 +1,107 @@
+"""ZINC source for IBTT — mirror of the reference's graph_data_loader/zinc_dataset_indexbase.py.
+
+`__getitem__` keeps the reference's {'text','label','graph_id'} contract (the trainer builds its dynamic
+vocab from the strings, trainer/train_ibtt.py:364-369); `tokenize()` is the string-free path: the whole
+split goes CSR -> vocab ids in one gtok_ibtt_zinc launch.
+"""
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from ._root import root as _root
+from .zinc_vocab import ZINC_ATOM_TYPES as ATOM_TYPE_LIST
+
+_ops = _root().ops
+GraphBatch = _root().GraphBatch
+
+ZINC_ATOM_TYPES = dict(enumerate(ATOM_TYPE_LIST))
+ZINC_BOND_TYPES = {0: "single", 1: "single", 2: "double", 3: "triple", 4: "aromatic"}
+_BOND_NAME = {1: "single", 2: "double", 3: "triple", 4: "aromatic"}
+
+
+def _label_token(label: float) -> str:
+    """4.23 -> val_4_23, -2.1 -> val_neg2_10 (reference :192)."""
+    return f"val_{label:.2f}".replace(".", "_").replace("-", "neg")
+
+
+class ZINCTokenizationDataset(Dataset):
+    """Same constructor as the reference (:63-81).  Offline there is no PyG/ZINC download, so a sequence
+    of PyG-like Data objects (x [N,1], edge_index [2,E], edge_attr [E], y) can be handed in directly with
+    `zinc_dataset=`; otherwise torch_geometric.datasets.ZINC is used exactly as the reference does."""
+
+    def __init__(self, zinc_root: str = "./data/ZINC", split: str = "train", subset: bool = True,
+                 max_vocab: int = 10000, max_len: int = 2048, zinc_dataset: Optional[Sequence] = None):
+        super().__init__()
+        self.zinc_root, self.split, self.subset, self.max_len = zinc_root, split, subset, max_len
+        if zinc_dataset is None:
+            from torch_geometric.datasets import ZINC  # needs PyG + network on first use, like the reference
+            zinc_dataset = ZINC(root=zinc_root, subset=subset, split=split)
+        self.zinc_dataset = zinc_dataset
+        self._batch: Optional[GraphBatch] = None
+        print(f"Loaded ZINC {split} split: {len(self.zinc_dataset)} molecules")
+
+    def __len__(self):
+        return len(self.zinc_dataset)
+
+    # -- string interface --------------------------------------------------------------------
+    def decode_atom_features(self, node_features):
+        idx = np.asarray(node_features).reshape(len(node_features), -1)[:, 0] if len(node_features) else []
+        return [ZINC_ATOM_TYPES.get(int(i), "X") for i in idx]
+
+    def decode_bond_features(self, edge_attr):
+        return [_BOND_NAME.get(int(b), "unknown") for b in np.asarray(edge_attr).reshape(-1)]
+
+    def tokenize_molecule(self, data, label):
+        """'<bos> <atom> C ... <bond> single 0 1 ... <q> regression <p> val_x_xx <eos>' (reference :143-195):
+        one <bond> group per undirected pair, taken from its first directed occurrence."""
+        toks = ["<bos>"]
+        for sym in self.decode_atom_features(data.x):
+            toks += ["<atom>", sym]
+        bonds = self.decode_bond_features(data.edge_attr)
+        ei = np.asarray(data.edge_index).reshape(2, -1)
+        seen = set()
+        for i, (u, v) in enumerate(zip(ei[0].tolist(), ei[1].tolist())):
+            key = (u, v) if u <= v else (v, u)
+            if key in seen:
+                continue
+            seen.add(key)
+            toks += ["<bond>", bonds[i] if i < len(bonds) else "unknown", str(u), str(v)]
+        toks += ["<q>", "regression", "<p>", _label_token(label), "<eos>"]
+        return " ".join(toks)
+
+    def __getitem__(self, idx):
+        data = self.zinc_dataset[idx]
+        label = data.y.item()
+        text = self.tokenize_molecule(data, label)
+        toks = text.split()
+        if len(toks) > self.max_len:                       # reference :217-221
+            text = " ".join(toks[:self.max_len - 1] + ["<eos>"])
+        return {"text": text, "label": label, "graph_id": f"zinc_{self.split}_{idx}"}
+
+    # -- device interface --------------------------------------------------------------------
+    def graph_batch(self) -> GraphBatch:
+        if self._batch is None:
+            self._batch = GraphBatch.from_data_list([self.zinc_dataset[i] for i in range(len(self))], labeled=True)
+        return self._batch
+
+    def labels(self) -> torch.Tensor:
+        return torch.tensor([float(self.zinc_dataset[i].y.item()) for i in range(len(self))], dtype=torch.float32)
+
+    def tokenize(self, vocab: Dict[str, int], max_len: Optional[int] = None, device=None,
+                 ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """ids int32 [G, ld] + lengths on the device, equal to TokenDataset(self[i]..., vocab, max_len) row by row."""
+        max_len = self.max_len if max_len is None else max_len
+        batch = self.graph_batch()
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if batch.device != torch.device(device):
+            batch = self._batch = batch.to(device)
+        lut = _ops.zinc_lut(vocab, max(batch.max_nodes, 1))
+        return _ops.ibtt_zinc(batch, lut, max_len, vocab["<pad>"], ld=ld)
+
+
+def collate_zinc_batch(batch, pad_id):
+    """Unused in the reference too (:230-252): returns the texts and float labels of a batch."""
+    return [b["text"] for b in batch], torch.tensor([b["label"] for b in batch], dtype=torch.float32)

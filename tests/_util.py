@@ -58,3 +58,51 @@ def edge_case_graphs():
                 dst=np.array([v for g in graphs for _, v in g["e"]], np.int64),
                 x=np.array([t for g in graphs for t in g["x"]], np.int64),
                 edge_attr=np.array([t for g in graphs for t in g["a"]], np.int64))
+
+
+# ------------------------------------------------------------------------------------------------ golden fixtures
+import json  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+_golden = None
+
+
+def golden():
+    """(arrays, meta) captured from the reference's own Python by tests/golden/make_golden.py."""
+    global _golden
+    if _golden is None:
+        arr = dict(np.load(os.path.join(GOLDEN_DIR, "reference_vectors.npz")))
+        with open(os.path.join(GOLDEN_DIR, "reference_vectors.json")) as f:
+            meta = json.load(f)
+        _golden = (arr, meta)
+    return _golden
+
+
+def golden_zinc_coo():
+    arr, _ = golden()
+    d = {k: arr["zinc_" + k] for k in ("node_counts", "edge_counts", "src", "dst", "x", "edge_attr", "y")}
+    return d
+
+
+class PygLike:
+    """Attribute bag standing in for torch_geometric.data.Data in tests."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def zinc_data_list(d):
+    import torch
+    nptr = np.concatenate([[0], np.cumsum(d["node_counts"])]); eptr = np.concatenate([[0], np.cumsum(d["edge_counts"])])
+    out = []
+    for g in range(len(d["node_counts"])):
+        n0, n1, e0, e1 = nptr[g], nptr[g + 1], eptr[g], eptr[g + 1]
+        out.append(PygLike(x=torch.tensor(d["x"][n0:n1], dtype=torch.long).view(-1, 1),
+                           edge_index=torch.tensor(np.stack([d["src"][e0:e1], d["dst"][e0:e1]]), dtype=torch.long).view(2, -1),
+                           edge_attr=torch.tensor(d["edge_attr"][e0:e1], dtype=torch.long),
+                           y=torch.tensor([float(d["y"][g])], dtype=torch.float32), num_nodes=int(n1 - n0)))
+    return out
+
+
+def unpad(ids2d, lens):
+    return [ids2d[i, :l].tolist() for i, l in enumerate(lens)]

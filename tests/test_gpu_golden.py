@@ -1,0 +1,138 @@
+"""GPU: the product (HIP kernels behind the reference-shaped classes) against golden vectors captured from
+the reference's own Python — the drop-in claim, end to end."""
+import numpy as np
+import pytest
+import torch
+
+from _util import PygLike, golden, golden_zinc_coo, gtok, unpad, zinc_data_list
+
+pytestmark = pytest.mark.gpu
+gdl = gtok.graph_data_loader
+DEV = "cuda:0"
+
+
+def _rows(ids, ln):
+    return unpad(ids.cpu().numpy(), ln.cpu().numpy())
+
+
+@pytest.mark.parametrize("max_len", [1024, 48])
+def test_zinc_ibtt_both_routes_equal_reference(max_len):
+    arr, meta = golden()
+    vocab = dict(meta[f"zinc_L{max_len}_vocab"])
+    want = unpad(arr[f"zinc_L{max_len}_ids"], arr[f"zinc_L{max_len}_len"])
+    ds = gdl.ZINCTokenizationDataset(split="train", max_len=max_len, zinc_dataset=zinc_data_list(golden_zinc_coo()))
+    # route 1 (what train_ibtt.py does): strings -> TokenDataset (GPU text kernel)
+    ex = [ds[i] for i in range(len(ds))]
+    td = gdl.TokenDataset(ex, vocab, max_len)
+    assert [s.tolist() for s in td.seqs] == want
+    assert [int(y) for y in td.labels] == arr[f"zinc_L{max_len}_y"].tolist()
+    s0, y0 = td[0]
+    assert s0.dtype == torch.long and y0.dtype == torch.long and y0.dim() == 0
+    # route 2: CSR -> ids, no strings
+    ids, ln = ds.tokenize(vocab, device=DEV)
+    assert _rows(ids, ln) == want
+    # reference collate on the items, and the device collate over the slab
+    X, A, Y = gdl.collate([td[i] for i in range(16)], vocab["<pad>"])
+    assert np.array_equal(X.numpy(), arr[f"zinc_L{max_len}_collate_X"]) and np.array_equal(Y.numpy(), arr[f"zinc_L{max_len}_collate_Y"])
+    Xd, Ad, Yd = next(td.device_batches(16))
+    assert Xd.is_cuda and torch.equal(Xd.cpu(), X) and torch.equal(Ad.cpu(), A) and torch.equal(Yd.cpu(), Y)
+
+
+@pytest.mark.parametrize("task", ["cycle_check", "shortest_path"])
+def test_synthetic_token_dataset_equals_reference(task):
+    arr, meta = golden()
+    tag = "synth_" + task
+    ex = meta[tag + "_examples"]
+    for vname, vkey in (("", "_vocab"), ("_v40", "_vocab40")):
+        vocab = dict(meta[tag + vkey])
+        for max_len in (600, 64):
+            td = gdl.TokenDataset(ex, vocab, max_len)
+            assert [s.tolist() for s in td.seqs] == unpad(arr[f"{tag}{vname}_L{max_len}_ids"], arr[f"{tag}{vname}_L{max_len}_len"])
+            assert [int(y) for y in td.labels] == arr[f"{tag}{vname}_L{max_len}_y"].tolist()
+    td = gdl.TokenDataset(ex, dict(meta[tag + "_vocab"]), 600)
+    X, A, Y = gdl.collate([td[i] for i in range(16)], 0)
+    assert np.array_equal(X.numpy(), arr[tag + "_collate_X"]) and np.array_equal(A.numpy(), arr[tag + "_collate_A"])
+    assert np.array_equal(Y.numpy(), arr[tag + "_collate_Y"])
+    # the graph route: parse the same records into graphs, emit the grammar on the GPU, same ids
+    vocab = dict(meta[tag + "_vocab"])
+    kept = [e for e in ex if e["label"] is not None]
+    graphs = [gdl.parse_graph_from_json({"text": e["text"]}, task=task) for e in kept]
+    datas = [PygLike(edge_index=np.array(g[0], np.int64).reshape(-1, 2).T, num_nodes=g[1]) for g in graphs]
+    batch = gtok.GraphBatch.from_data_list(datas, labeled=False).to(DEV)
+    pad = vocab["<pad>"]
+    q = np.zeros((len(kept), 4), np.int32)
+    for i, e in enumerate(kept):
+        toks = e["text"].split()
+        qt = toks[toks.index("<q>") + 1: toks.index("<p>")]
+        q[i, 0] = len(qt); q[i, 1:1 + len(qt)] = [vocab.get(t, pad) for t in qt]
+    ids, ln = gtok.ops.ibtt_synth(batch, gtok.ops.synth_lut(vocab, 64), torch.from_numpy(q), 600, pad)
+    assert _rows(ids, ln) == unpad(arr[f"{tag}_L600_ids"], arr[f"{tag}_L600_len"])
+
+
+class _Replay:
+    """Stub tokenizer replaying the fixture's token tensors (what make_golden.py fed the reference)."""
+    pad = 5
+
+    def __init__(self, seqs, idx_offset, max_nodes, ntypes):
+        self.seqs, self.i, self.idx_offset = seqs, 0, idx_offset
+        self.node_idx_offset = idx_offset + max_nodes
+        self.edge_idx_offset = self.node_idx_offset + ntypes
+        self.labeled_graph = ntypes > 0
+
+    def __call__(self, data):
+        s = self.seqs[self.i % len(self.seqs)]
+        self.i += 1
+        return s.clone()
+
+
+def test_agtt_dataset_glue_equals_reference():
+    arr, meta = golden()
+    seqs = [torch.tensor(r) for r in unpad(arr["agtt_remap_in"], arr["agtt_remap_len"])]
+    datas = [PygLike(y=torch.tensor([0.5]), num_nodes=5) for _ in seqs]
+    ds = gtok.agtt.TokenizedGraphDataset(datas, _Replay(seqs, 6, 37, 9), task="zinc", remap_to_fixed_vocab=True, device=DEV)
+    items = [ds[i] for i in range(len(ds))]
+    assert [it[0].tolist() for it in items] == unpad(arr["agtt_remap_out"], arr["agtt_remap_len"])
+    assert all(it[0].dtype == torch.long and it[1].dtype == torch.bool and it[1].all() for it in items)
+    assert isinstance(items[0][2], float)
+    # shortest_path query append, including the items that carry no query fields
+    seqs2 = [torch.tensor(r) for r in unpad(arr["agtt_sp_in"], arr["agtt_sp_in_len"])]
+    datas2 = []
+    for n, (u, v), y in zip(arr["agtt_sp_num_nodes"], arr["agtt_sp_query"], arr["agtt_sp_labels"]):
+        d = PygLike(y=torch.tensor([int(y)]), num_nodes=int(n))
+        if u >= 0:
+            d.query_u, d.query_v = int(u), int(v)
+        datas2.append(d)
+    ds2 = gtok.agtt.TokenizedGraphDataset(datas2, _Replay(seqs2, 6, 49, 0), task="shortest_path", device=DEV)
+    items2 = [ds2[i] for i in range(len(ds2))]
+    assert [it[0].tolist() for it in items2] == unpad(arr["agtt_sp_out"], arr["agtt_sp_out_len"])
+    X, A, Y, dl = gtok.agtt.collate_fn(items2[:16])
+    assert np.array_equal(X.numpy(), arr["agtt_sp_collate_X"]) and np.array_equal(A.numpy(), arr["agtt_sp_collate_A"])
+    assert np.array_equal(Y.numpy(), arr["agtt_sp_collate_Y"]) and len(dl) == 16
+
+
+def test_agtt_end_to_end_with_the_gpu_tokenizer():
+    """The train_agtt.py flow with our Graph2TrailTokenizer: per-item fetches serve the epoch slab, a second
+    fetch of the same item gives a NEW trail, ids stay inside the fixed-vocab ranges, device batches == collate_fn."""
+    Graph2TrailTokenizer = gtok.Graph2TrailTokenizer
+    datas = zinc_data_list(golden_zinc_coo())
+    src = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=datas)
+    tok = Graph2TrailTokenizer(dataset_names=[], max_length=1024, truncation_length=1024, labeled_graph=True, undirected=True)
+    max_nodes = max(d.num_nodes for d in src)
+    tok.set_num_nodes(max_nodes); tok.set_num_node_and_edge_types(*gdl.get_zinc_num_types())
+    ds = gtok.agtt.TokenizedGraphDataset(src, tok, task="zinc", remap_to_fixed_vocab=True, device=DEV)
+    first = [ds[i] for i in range(len(ds))]
+    vocab_size = 22 + max_nodes + 100                                    # train_agtt.py:561
+    for t, m, y, d in first:
+        assert t[0] == 0 and t[-1] == 1 and m.all() and isinstance(y, float)
+        if int(d.x.max()) <= 27 and (d.edge_attr.numel() == 0 or int(d.edge_attr.max()) <= 4):   # real ZINC ranges
+            assert int(t.max()) < vocab_size
+    assert ds._epoch == 0
+    again = [ds[i][0] for i in range(len(ds))]                            # second pass over the data: epoch 1
+    assert ds._epoch == 1 and any(not torch.equal(a, f[0]) for a, f in zip(again, first))
+    X, A, Y, dl = gtok.agtt.collate_fn(first[:16])
+    ds3 = gtok.agtt.TokenizedGraphDataset(src, tok, task="zinc", remap_to_fixed_vocab=True, device=DEV)
+    Xd, Ad, Yd, dld = next(ds3.device_batches(16, epoch=0))
+    assert torch.equal(Xd.cpu(), X) and torch.equal(Ad.cpu(), A) and torch.equal(Yd.cpu(), Y) and Yd.dtype == torch.float32
+    # single-item call site (tokenizer(data)): a valid SENT of that molecule
+    one = tok(datas[3])
+    assert one.dtype == torch.long and one[0] == 0 and one[-1] == 4

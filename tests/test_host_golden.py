@@ -1,0 +1,204 @@
+"""CPU: host-side mirror of the reference interface (strings, parsers, vocab builders, file loading, CSR
+builder, C-ABI surface) against the golden vectors captured from the reference's own Python."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from _util import ROOT, edge_case_graphs, golden, golden_zinc_coo, gtok, orc, zinc_data_list
+
+gdl = gtok.graph_data_loader
+
+
+def test_fixed_vocab_and_id_helpers():
+    _, meta = golden()
+    v, itos = gdl.build_fixed_zinc_vocab()
+    assert list(v.items()) == [tuple(p) for p in meta["fixed_zinc_vocab"]]
+    assert itos == {i: t for t, i in v.items()}
+    assert gdl.SPECIAL == meta["special"]
+    assert [gdl.get_atom_type_id(i) for i in range(9)] == meta["atom_ids"]
+    assert [gdl.get_bond_type_id(i) for i in range(1, 5)] == meta["bond_ids"]
+    assert list(gdl.get_zinc_num_types()) == meta["zinc_num_types"]
+    for bad in (-1, 9, 100):
+        with pytest.raises(ValueError):
+            gdl.get_atom_type_id(bad)
+    for bad in (0, 5):
+        with pytest.raises(ValueError):
+            gdl.get_bond_type_id(bad)
+    assert gdl.get_atom_type_from_id(14) == "Cl" and gdl.get_bond_type_from_id(20) == "aromatic"
+    for t, isn, ise, want in meta["map_autograph_token"]:
+        try:
+            got = gdl.map_autograph_token_to_fixed_id(t, 43, 52, is_node_type=bool(isn), is_edge_type=bool(ise))
+        except ValueError:
+            got = "ValueError"
+        assert got == want, (t, isn, ise)
+    ext = gdl.extend_vocab_with_dynamic_tokens(v, ["7", "C", "X", "7", "val_0_50"])
+    assert (ext["7"], ext["X"], ext["val_0_50"], ext["C"]) == (22, 23, 24, 8) and len(ext) == 25
+
+
+@pytest.mark.parametrize("max_len", [1024, 48])
+def test_zinc_texts_match_reference(max_len):
+    _, meta = golden()
+    ds = gdl.ZINCTokenizationDataset(split="train", max_len=max_len, zinc_dataset=zinc_data_list(golden_zinc_coo()))
+    items = [ds[i] for i in range(len(ds))]
+    assert [it["text"] for it in items] == meta[f"zinc_L{max_len}_texts"]
+    assert [it["label"] for it in items] == meta[f"zinc_L{max_len}_labels"]
+    assert [it["graph_id"] for it in items] == meta[f"zinc_L{max_len}_graph_ids"]
+
+
+def test_vocab_builders_match_reference():
+    _, meta = golden()
+    for c in meta["vocab_cases"]:
+        v, itos = gdl.build_vocab_from_texts(c["texts"], min_freq=c["min_freq"], max_tokens=c["max_tokens"])
+        assert list(v.items()) == [tuple(p) for p in c["vocab"]]
+    for task in ("cycle_check", "shortest_path"):
+        ex = meta[f"synth_{task}_examples"]
+        v, _ = gdl.build_vocab_from_texts([e["text"] for e in ex], max_tokens=600)
+        assert list(v.items()) == [tuple(p) for p in meta[f"synth_{task}_vocab"]]
+        v40, _ = gdl.build_vocab_from_texts([e["text"] for e in ex], max_tokens=40)
+        assert list(v40.items()) == [tuple(p) for p in meta[f"synth_{task}_vocab40"]]
+
+
+def test_parsers_match_reference():
+    _, meta = golden()
+    out = iter(meta["parser_out"])
+    for r in meta["parser_records"]:
+        for task in ("cycle_check", "shortest_path"):
+            want = next(out)
+            edges, n, lab = gdl.parse_graph_from_json(r, task=task)
+            q = gdl.graph_token_dataset_autograph.parse_query_nodes_from_text(r.get("text", ""))
+            assert [list(map(int, e)) for e in edges] == want["edges"] and n == want["num_nodes"] and lab == want["label"]
+            assert (None if q is None else list(q)) == want["query"]
+    for task in ("cycle_check", "shortest_path"):
+        for e, want in zip(meta[f"synth_{task}_examples"], meta[f"synth_{task}_parsed"]):
+            edges, n, lab = gdl.parse_graph_from_json({"text": e["text"]}, task=task)
+            assert [list(p) for p in edges] == want["edges"] and n == want["num_nodes"] and lab == want["label"]
+            assert gdl.parse_label_from_text(e["text"], task) == want["label_from_text"]
+            q = gdl.parse_query_nodes_from_text(e["text"])
+            assert (None if q is None else list(q)) == want["query"]
+
+
+def test_load_examples_matches_reference(tmp_path):
+    """Same files on disk -> same example dicts as the reference's load_examples (order, labels, queries)."""
+    _, meta = golden()
+    for task in ("cycle_check", "shortest_path"):
+        g = gtok.synth.graph_token_like(60, seed=1234, task=task)     # the corpus the fixture was made from
+        for i, (txt, alg) in enumerate(zip(g["texts"], g["algorithms"])):
+            dd = tmp_path / task / "tasks_train" / task / alg / "train"
+            dd.mkdir(parents=True, exist_ok=True)
+            (dd / f"{i:04d}.json").write_text(json.dumps([{"text": txt}]))
+        ex = []
+        for alg in sorted(set(g["algorithms"])):
+            ex += gdl.load_examples(str(tmp_path / task / "tasks_train" / task / alg / "train" / "*.json"), task=task)
+        assert ex == meta[f"synth_{task}_examples"]
+        # the multi-algorithm wrapper walks the same directories
+        allx = gdl.load_examples_multi_algorithm(str(tmp_path / task), task, sorted(set(g["algorithms"])), "train")
+        assert allx == ex
+        assert gdl.determine_num_classes(ex, task) == (2 if task == "cycle_check" else
+                                                      max(e["label"] for e in ex if e["label"] is not None) + 1)
+    # line-oriented / raw-text / malformed files, file sampling, per-file pair sampling, data_fraction
+    d = tmp_path / "misc"; d.mkdir()
+    for name, body in meta["loader_misc_files"].items():
+        (d / name).write_text(body)
+    for kw, want in zip(meta["loader_misc_calls"], meta["loader_misc_out"]):
+        assert gdl.load_examples(str(d / "*.json"), **kw) == want, kw
+
+
+def test_host_collates_match_reference():
+    arr, meta = golden()
+    ids, ln = arr["zinc_L1024_ids"], arr["zinc_L1024_len"]
+    batch = [(torch.tensor(ids[i, :ln[i]]), torch.tensor(int(arr["zinc_L1024_y"][i]))) for i in range(16)]
+    X, A, Y = gdl.collate(batch, 2)
+    assert X.dtype == torch.int64 and A.dtype == torch.bool and Y.dtype == torch.int64
+    assert np.array_equal(X.numpy(), arr["zinc_L1024_collate_X"]) and np.array_equal(A.numpy(), arr["zinc_L1024_collate_A"])
+    assert np.array_equal(Y.numpy(), arr["zinc_L1024_collate_Y"])
+    out, oln = arr["agtt_remap_out"], arr["agtt_remap_len"]
+    items = [(torch.tensor(out[i, :oln[i]]), torch.ones(int(oln[i]), dtype=torch.bool), meta["agtt_zinc_labels"][i], None)
+             for i in range(16)]
+    X, A, Y, dl = gtok.agtt.collate_fn(items)
+    assert np.array_equal(X.numpy(), arr["agtt_zinc_collate_X"]) and np.array_equal(A.numpy(), arr["agtt_zinc_collate_A"])
+    assert str(Y.dtype) == meta["agtt_zinc_collate_Y_dtype"] and np.allclose(Y.numpy(), arr["agtt_zinc_collate_Y"])
+    items = [(torch.tensor(arr["agtt_sp_out"][i, :arr["agtt_sp_out_len"][i]]),
+              torch.ones(int(arr["agtt_sp_out_len"][i]), dtype=torch.bool), int(arr["agtt_sp_labels"][i]), None) for i in range(16)]
+    X, A, Y, dl = gtok.agtt.collate_fn(items)
+    assert np.array_equal(X.numpy(), arr["agtt_sp_collate_X"]) and str(Y.dtype) == meta["agtt_sp_collate_Y_dtype"]
+    assert np.array_equal(Y.numpy(), arr["agtt_sp_collate_Y"])
+
+
+def test_tokenizer_object_interface():
+    T = gtok.Graph2TrailTokenizer
+    assert (T.sos, T.reset, T.ladj, T.radj, T.eos, T.pad) == (0, 1, 2, 3, 4, 5)
+    t = T(dataset_names=[], max_length=1024, truncation_length=1024, labeled_graph=True, undirected=True)
+    assert t.idx_offset == 6
+    with pytest.raises(RuntimeError):
+        t.set_num_node_and_edge_types(9, 4)
+    t.set_num_nodes(37); t.set_num_node_and_edge_types(9, 4)
+    assert (t.node_idx_offset, t.edge_idx_offset) == (43, 52)
+    u = T(dataset_names=[], max_length=600, truncation_length=600, labeled_graph=False, undirected=True)
+    u.set_num_nodes(49)
+    assert u.idx_offset + 49 + 1 == 56          # vocab_size formula of train_agtt.py:586
+    with pytest.raises(ValueError):
+        T(dataset_names=["zinc"])
+
+
+def test_csr_builder():
+    d = edge_case_graphs()
+    b = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+    nptr, eptr = b.node_ptr.numpy(), b.edge_ptr.numpy()
+    assert b.num_graphs == len(d["node_counts"]) and b.max_nodes == 8 and b.max_edges == 56
+    assert b.eorder is not None                      # Mol B & co. are not row-sorted
+    for g in range(b.num_graphs):
+        n, e0, e1 = nptr[g + 1] - nptr[g], eptr[g], eptr[g + 1]
+        rp = b.rowptr.numpy()[nptr[g] + g: nptr[g] + g + n + 1]
+        assert rp[0] == 0 and rp[-1] == e1 - e0 and (np.diff(rp) >= 0).all()
+        src, dst = d["src"][e0:e1], d["dst"][e0:e1]
+        for u in range(n):
+            ks = np.arange(rp[u], rp[u + 1])
+            orig = b.eorder.numpy()[e0 + ks]
+            assert (src[orig] == u).all() and (dst[orig] == b.col.numpy()[e0 + ks]).all()
+            assert (np.diff(orig) > 0).all()          # stable: original order kept inside a row
+            assert (b.eattr.numpy()[e0 + ks] == np.minimum(d["edge_attr"][e0:e1][orig], 255)).all()
+    z = gtok.synth.zinc_like(50, seed=1)
+    bz = gtok.GraphBatch.from_coo(z["node_counts"], z["edge_counts"], z["src"], z["dst"], z["x"], z["edge_attr"])
+    assert bz.eorder is None                          # coalesced input: identity order is not stored
+    sh = bz.shard(10, 30)
+    assert sh.num_graphs == 20 and int(sh.edge_ptr[-1]) == sh.col.numel() and int(sh.node_ptr[0]) == 0
+    with pytest.raises(ValueError):
+        gtok.GraphBatch.from_coo([2], [1], [0], [2])
+    dl = gtok.GraphBatch.from_data_list(zinc_data_list(golden_zinc_coo()))
+    g = golden_zinc_coo()
+    ref = gtok.GraphBatch.from_coo(g["node_counts"], g["edge_counts"], g["src"], g["dst"], g["x"], g["edge_attr"])
+    assert torch.equal(dl.col, ref.col) and torch.equal(dl.rowptr, ref.rowptr) and torch.equal(dl.eattr, ref.eattr)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gtok.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(gtok_\w+)\(", hdr, flags=re.M))
+    assert declared == set(gtok._lib.SYMBOLS), declared ^ set(gtok._lib.SYMBOLS)
+    lib = ctypes.CDLL(gtok._lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert gtok.lib().gtok_version() == 1 and gtok.lib().gtok_target() == b"gfx950"
+
+
+def test_product_has_no_cpu_path():
+    z = gtok.synth.zinc_like(4, seed=0)
+    b = gtok.GraphBatch.from_coo(z["node_counts"], z["edge_counts"], z["src"], z["dst"], z["x"], z["edge_attr"])
+    with pytest.raises(gtok.GtokError):
+        gtok.ops.sent(b, 37, 1024, 0)                # host tensors: refused, never silently tokenized on the CPU
+    with pytest.raises(gtok.GtokError):
+        gtok.ops.ibtt_zinc(b, torch.zeros(64, dtype=torch.int32), 1024, 2)
+    if not torch.cuda.is_available():
+        with pytest.raises(gtok.GtokError):
+            gdl.TokenDataset([{"text": "<bos> yes", "label": 1}], {t: i for i, t in enumerate(gdl.SPECIAL)})
+    # nothing under the product package imports, links or loads the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "glearning-benchmark_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "libgtok_oracle", "oracle.py", "#include \"../../oracle"):
+                    assert needle not in src, (f, needle)

@@ -1,0 +1,191 @@
+"""CPU: the oracle (oracle/gtok_oracle.c) against golden vectors produced by the reference's own Python,
+plus the reference-visible invariants of the SENT spec (the only thing that can pin it: SURVEY.md §8c)."""
+import numpy as np
+import pytest
+
+from _util import both, edge_case_graphs, golden, golden_zinc_coo, gtok, orc, unpad
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32-10
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert orc.philox4x32_10(ctr, key).tolist() == want
+
+
+@pytest.mark.parametrize("max_len", [1024, 48])
+def test_ibtt_zinc_matches_reference(max_len):
+    arr, meta = golden()
+    d = golden_zinc_coo()
+    coo = orc.Coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+    vocab = dict(meta[f"zinc_L{max_len}_vocab"])
+    lut = gtok.ops.zinc_lut(vocab, int(d["node_counts"].max())).numpy()
+    want_len = arr[f"zinc_L{max_len}_len"]
+    ids, ln = orc.ibtt_zinc(coo, lut, max_len, vocab["<pad>"], int(want_len.max()) + 3, nthreads=2)
+    assert ln.tolist() == want_len.tolist()
+    assert unpad(ids, ln) == unpad(arr[f"zinc_L{max_len}_ids"], want_len)
+
+
+@pytest.mark.parametrize("task", ["cycle_check", "shortest_path"])
+@pytest.mark.parametrize("vname,max_len", [("", 600), ("", 64), ("_v40", 600), ("_v40", 64)])
+def test_text_to_ids_matches_reference(task, vname, max_len):
+    arr, meta = golden()
+    tag = "synth_" + task
+    ex = meta[tag + "_examples"]
+    vocab = dict(meta[tag + ("_vocab40" if vname else "_vocab")])
+    kept = [e for e in ex if e["label"] is not None]          # TokenDataset(require_label=True) drops the rest
+    want_len = arr[f"{tag}{vname}_L{max_len}_len"]
+    ids, ln = orc.text_to_ids([e["text"] for e in kept], vocab, max_len, max(int(want_len.max()), 4))
+    assert ln.tolist() == want_len.tolist()
+    assert unpad(ids, ln) == unpad(arr[f"{tag}{vname}_L{max_len}_ids"], want_len)
+    assert [int(e["label"]) for e in kept] == arr[f"{tag}{vname}_L{max_len}_y"].tolist()
+
+
+def test_zinc_text_path_equals_graph_path():
+    """TokenDataset over the reference's ZINC strings == the string-free serialiser (two oracle routes, one answer)."""
+    arr, meta = golden()
+    vocab = dict(meta["zinc_L1024_vocab"])
+    want_len = arr["zinc_L1024_len"]
+    ids, ln = orc.text_to_ids(meta["zinc_L1024_texts"], vocab, 1024, int(want_len.max()))
+    assert unpad(ids, ln) == unpad(arr["zinc_L1024_ids"], want_len)
+
+
+def test_remap_and_collate_match_reference():
+    arr, meta = golden()
+    io, no, eo = meta["agtt_remap_offsets"]
+    out = orc.remap_zinc(arr["agtt_remap_in"].astype(np.int32), arr["agtt_remap_len"], io, no, eo)
+    assert unpad(out, arr["agtt_remap_len"]) == unpad(arr["agtt_remap_out"], arr["agtt_remap_len"])
+    # IBTT collate (pad = vocab['<pad>'] = 2) and AGTT collate_fn (pad = 5 even after the remap)
+    for tag, pad, n in (("zinc_L1024", 2, 16), ("agtt_zinc", 5, 16), ("agtt_sp", 5, 16)):
+        if tag == "zinc_L1024":
+            ids, ln = arr["zinc_L1024_ids"], arr["zinc_L1024_len"]
+        elif tag == "agtt_zinc":
+            ids, ln = arr["agtt_remap_out"], arr["agtt_remap_len"]
+        else:
+            ids, ln = arr["agtt_sp_out"], arr["agtt_sp_out_len"]
+        X = arr[tag + "_collate_X"]
+        gotX, gotA, m = orc.collate(np.where(ids < 0, 0, ids).astype(np.int32), ln, np.arange(n), pad, X.shape[1])
+        assert m == X.shape[1]
+        assert np.array_equal(gotX, X) and np.array_equal(gotA, arr[tag + "_collate_A"])
+
+
+def test_query_append_matches_reference():
+    """trainer/train_agtt.py:257-267 appends [idx_off+N, idx_off+u, idx_off+v] after the trail: the oracle's
+    tail on a real walk must be the tail the reference code produced for the same (N, u, v)."""
+    arr, _ = golden()
+    q = arr["agtt_sp_query"]; nn = arr["agtt_sp_num_nodes"]
+    has = q[:, 0] >= 0
+    want_tail = [arr["agtt_sp_out"][i, arr["agtt_sp_out_len"][i] - 3: arr["agtt_sp_out_len"][i]].tolist()
+                 for i in np.nonzero(has)[0]]
+    assert want_tail == [[6 + int(nn[i]), 6 + int(q[i, 0]), 6 + int(q[i, 1])] for i in np.nonzero(has)[0]]
+    # and the oracle, on path graphs with those sizes and queries
+    sel = np.nonzero(has)[0]
+    ncs = nn[sel]; ecs = ncs - 1
+    src = np.concatenate([np.arange(n - 1) for n in ncs]); dst = src + 1
+    coo = orc.Coo(ncs, ecs, src, dst)
+    ids, ln = orc.sent(coo, 49, 600, 1, 0, query=q[sel].astype(np.int32))
+    assert [ids[i, ln[i] - 3: ln[i]].tolist() for i in range(len(sel))] == want_tail
+    assert all(ids[i, ln[i] - 4] == 4 for i in range(len(sel)))     # appended after the EOS
+
+
+def _sent_cases():
+    yield "zinc", gtok.synth.zinc_like(300, seed=11), True, 37
+    yield "zinc_uncoalesced", gtok.synth.zinc_like(100, seed=12, coalesced=False), True, 37
+    yield "graph_token", gtok.synth.graph_token_like(120, seed=13, with_text=False), False, 49
+    yield "er_large", gtok.synth.er_batch(12, seed=14, min_nodes=100, max_nodes=256), False, 256
+    yield "edge_cases", edge_case_graphs(), True, 8
+    yield "edge_cases_unlabeled", edge_case_graphs(), False, 8
+
+
+@pytest.mark.parametrize("name,d,labeled,nn", list(_sent_cases()), ids=[c[0] for c in _sent_cases()])
+def test_sent_invariants(name, d, labeled, nn):
+    """starts with SOS, ends with EOS, ids inside the documented ranges, L <= max_length,
+    lossless (decoding gives back exactly the input edge set, every undirected edge once, and the labels),
+    node-position ids handed out in first-visit order."""
+    _, coo = both(d, labeled)
+    nt = 28 if labeled else 0
+    ids, ln = orc.sent(coo, nn, 100000, seed=3, epoch=1, labeled=labeled, num_node_types=nt, num_edge_types=6,
+                       ld=int(2 + 7 * coo.node_counts.max() + 2 * coo.edge_counts.max()) + 8)
+    for g in range(coo.G):
+        t = ids[g, :ln[g]].tolist()
+        assert t[0] == 0 and t[-1] == 4 and 5 not in t
+        n, edges, ntypes, etypes, used = orc.sent_decode(t, nn, labeled, nt)
+        assert used == len(t)
+        e0, e1, n0 = coo.edge_ptr[g], coo.edge_ptr[g + 1], coo.node_ptr[g]
+        assert n == coo.node_counts[g]
+        want = {frozenset((int(u), int(v))) for u, v in zip(coo.src[e0:e1], coo.dst[e0:e1])}
+        # position ids are handed out 0,1,2,... in first-visit order; every undirected edge appears once
+        assert _visit_order(t, nn, labeled) == list(range(n))
+        assert len(edges) == len(want)
+        if not labeled:
+            assert max(t) < 6 + nn
+        else:
+            x = coo.x[n0:n0 + n]
+            assert sorted(ntypes.values()) == sorted(int(v) for v in x)
+    # isomorphism check through degree multisets (cheap, permutation invariant)
+    for g in range(min(coo.G, 50)):
+        t = ids[g, :ln[g]].tolist()
+        n, edges, *_ = orc.sent_decode(t, nn, labeled, nt)
+        e0, e1 = coo.edge_ptr[g], coo.edge_ptr[g + 1]
+        want = {frozenset((int(u), int(v))) for u, v in zip(coo.src[e0:e1], coo.dst[e0:e1])}
+        deg_w = sorted(sum(1 for e in want if v in e) for v in range(n))
+        deg_g = sorted(sum(1 for e in edges if v in e) for v in range(n))
+        assert deg_w == deg_g
+
+
+def _visit_order(tokens, nn, labeled):
+    """visit index k for first appearances, in order: [0, 1, 2, ...] by construction of a valid SENT."""
+    seen = []
+    for t in tokens:
+        if 6 <= t < 6 + nn and (t - 6) not in seen and (t - 6) == len(seen):
+            seen.append(t - 6)
+    return seen
+
+
+def test_sent_exact_reconstruction_with_known_relabelling():
+    """Losslessness proper: run the walk on a graph whose node ids we then recover through the node types
+    (all distinct), and compare the decoded, relabelled edge set and edge types with the input."""
+    rng = np.random.default_rng(5)
+    ncs, ecs, src, dst, xs, eas = [], [], [], [], [], []
+    for _ in range(60):
+        n = int(rng.integers(2, 60))
+        iu, iv = np.triu_indices(n, 1)
+        keep = rng.random(iu.size) < 0.15
+        u, v = iu[keep], iv[keep]
+        loops = np.nonzero(rng.random(n) < 0.05)[0]
+        u = np.concatenate([u, loops]); v = np.concatenate([v, loops])
+        a = rng.integers(0, 7, u.size)
+        ncs.append(n); ecs.append(2 * u.size)
+        src += [u, v]; dst += [v, u]; eas += [a, a]; xs.append(rng.permutation(n))      # x = a unique id per node
+    coo = orc.Coo(ncs, ecs, np.concatenate(src), np.concatenate(dst), np.concatenate(xs), np.concatenate(eas))
+    ids, ln = orc.sent(coo, 64, 100000, seed=9, epoch=0, labeled=True, num_node_types=64, num_edge_types=7, ld=4000)
+    for g in range(coo.G):
+        n, edges, ntypes, etypes, _ = orc.sent_decode(ids[g, :ln[g]].tolist(), 64, True, 64)
+        e0, e1, n0 = coo.edge_ptr[g], coo.edge_ptr[g + 1], coo.node_ptr[g]
+        x = coo.x[n0:n0 + n]
+        back = {k: int(np.nonzero(x == ntypes[k])[0][0]) for k in range(n)}            # visit index -> original node
+        got = {frozenset(back[a] for a in e): etypes[e] for e in edges}
+        want = {}
+        for u, v, a in zip(coo.src[e0:e1], coo.dst[e0:e1], coo.edge_attr[e0:e1]):
+            want.setdefault(frozenset((int(u), int(v))), int(a))
+        assert got == want
+
+
+def test_sent_truncation_is_a_prefix_and_epochs_differ():
+    d = gtok.synth.zinc_like(200, seed=21)
+    _, coo = both(d)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4)
+    full, fl = orc.sent(coo, 37, 1024, 5, 0, ld=512, **kw)
+    cut, cl = orc.sent(coo, 37, 40, 5, 0, ld=512, **kw)
+    assert (cl == np.minimum(fl, 40)).all()
+    assert all(np.array_equal(cut[i, :cl[i]], full[i, :cl[i]]) for i in range(coo.G))
+    nxt, nl = orc.sent(coo, 37, 1024, 5, 1, ld=512, **kw)
+    assert (nxt != full).any(), "a new epoch must give new trails"
+    again, al = orc.sent(coo, 37, 1024, 5, 0, ld=512, nthreads=4, **kw)
+    assert np.array_equal(again, full) and np.array_equal(al, fl)
+    # shard invariance: graph_base continues the global index
+    part, pl = orc.sent(coo.slice(100, 200), 37, 1024, 5, 0, ld=512, graph_base=100, **kw)
+    assert np.array_equal(part, full[100:]) and np.array_equal(pl, fl[100:])
