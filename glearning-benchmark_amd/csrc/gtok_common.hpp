@@ -21,6 +21,10 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// wave index inside the workgroup, as a SCALAR: threadIdx.x >> 6 is the same in all 64 lanes but the
+// compiler cannot see that, and everything derived from it (graph index, sizes, loop control) would
+// otherwise be computed per lane with exec-mask branches
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -41,7 +41,7 @@ struct ZincArgs {
 __global__ void __launch_bounds__(256) ibtt_zinc_kernel(const ZincArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
   unsigned char *base = smem + (size_t)wave * a.l.stride;
   int32_t *rp = reinterpret_cast<int32_t *>(base + a.l.rp);
   uint16_t *cc = reinterpret_cast<uint16_t *>(base + a.l.cc);  // col, CSR position
@@ -145,7 +145,7 @@ struct SynthArgs {
 __global__ void __launch_bounds__(256) ibtt_synth_kernel(const SynthArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
   unsigned char *base = smem + (size_t)wave * a.l.stride;
   int32_t *rp = reinterpret_cast<int32_t *>(base + a.l.rp);
   int32_t *tok = reinterpret_cast<int32_t *>(base + a.l.tok);
@@ -219,7 +219,7 @@ struct TextArgs {
 __global__ void __launch_bounds__(256) text_ids_kernel(const TextArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
   int32_t *tok = reinterpret_cast<int32_t *>(smem + (size_t)wave * a.tok_stride);
   const int cap = a.cap;
   const uint32_t mask = (uint32_t)a.v.capacity - 1u;

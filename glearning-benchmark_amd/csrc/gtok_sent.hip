@@ -16,27 +16,13 @@
 //   (labelled) rp int32[maxN+1], col uint16[maxE], eat uint8[maxE], nat uint8[maxN]
 // Wave primitives: __ballot + __ffsll pick the k-th remaining edge / restart
 // node; __ballot + __popcll rank the members of a neighbourhood bracket.
+#include <cstdlib>
+
 #include "gtok_common.hpp"
 #include "gtok.h"
+#include "gtok_sent_reg.hpp"
 
 namespace gtok {
-
-struct SentLds {  // byte offsets inside a wave's slice, computed on the host
-  int adj, vis, vidx, order, rng, tok, rp, col, eat, nat, stride;
-};
-
-struct SentArgs {
-  gtok_csr g;
-  gtok_sent_params p;
-  SentLds l;
-  int cap;        // min(max_len, ld): trail tokens kept
-  int maxn;       // adjacency rows per slice
-  int32_t *out;
-  int ld;
-  int32_t *out_len;
-  int units;      // ceil(G / waves_per_block)
-  int upb;        // units per block
-};
 
 template <int W, bool LAB>
 struct SentWave {
@@ -223,7 +209,7 @@ template <int W, bool LAB>
 __global__ void __launch_bounds__(256) sent_kernel(const SentArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
   unsigned char *base = smem + (size_t)wave * a.l.stride;
 
   SentWave<W, LAB> s;
@@ -287,27 +273,22 @@ __global__ void __launch_bounds__(256) sent_kernel(const SentArgs a) {
     wave_sync();
 
     s.walk();
-    wave_sync();
 
-    const int ltrail = min(s.pos, a.p.max_len);  // true trail length; stored part is < cap
+    const int ltrail = min(s.pos, a.p.max_len);  // true trail length; tokens beyond `cap` were not stored
     int len = ltrail;
-    int q0 = 0, q1 = 0, q2 = 0;
-    if (a.p.query) {  // trainer/train_agtt.py:257-267, original node ids, after any EOS
-      q0 = s.idx_off + (a.g.node_ptr[g + 1] - nb0);
-      q1 = s.idx_off + a.p.query[2 * (int64_t)g];
-      q2 = s.idx_off + a.p.query[2 * (int64_t)g + 1];
+    if (a.p.query) {  // trainer/train_agtt.py:257-267, original node ids, after any EOS, not remapped
+      if (lane < 3 && ltrail + lane < a.cap + 3)
+        s.tok[ltrail + lane] = (uint16_t)(s.idx_off + (lane == 0 ? a.g.node_ptr[g + 1] - nb0
+                                                                 : a.p.query[2 * (int64_t)g + lane - 1]));
       len = ltrail + 3;
     }
+    wave_sync();
     const bool remap = a.p.remap_zinc != 0;
     const int io = s.idx_off, no = s.node_off, eo = s.edge_off;
     const uint16_t *tok = s.tok;
     write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, a.ld), a.p.pad_id, [=](int i) -> int {
-      if (i < ltrail) {
-        const int t = tok[i];
-        return remap ? remap_zinc_token(t, io, no, eo) : t;
-      }
-      const int j = i - ltrail;
-      return j == 0 ? q0 : (j == 1 ? q1 : q2);
+      const int t = tok[i];
+      return (remap && i < ltrail) ? remap_zinc_token(t, io, no, eo) : t;
     });
     if (lane == 0) a.out_len[g] = len;
     wave_sync();
@@ -336,22 +317,44 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   const int maxn = g->max_nodes > 0 ? g->max_nodes : 1;
   const int W = maxn <= 64 ? 1 : maxn <= 128 ? 2 : maxn <= 256 ? 4 : 8;
   const int cap = p->max_len < ld ? p->max_len : ld;
+  const int maxe = g->max_edges > 0 ? g->max_edges : 1;
+  // register-resident walk for graphs of at most 64 nodes (placeholders need bit 15 of a token free);
+  // GTOK_SENT_GENERIC=1 forces the LDS bit-matrix kernel (A/B runs, tests of both paths)
+  const char *force = std::getenv("GTOK_SENT_GENERIC");
+  const bool reg_path = W == 1 && !(force && force[0] == '1') &&
+                        GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < kEdgeRef &&
+                        (!p->labeled || g->max_edges <= 65535);
 
   SentArgs a;
   a.g = *g; a.p = *p; a.cap = cap; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
   int off = 0;
-  a.l.adj = off; off += maxn * W * 8;
-  a.l.vis = off; off += W * 8;
-  a.l.rng = off; off += 256 * 4;
-  a.l.vidx = off; off += align_up(maxn * 2, 8);
-  a.l.order = off; off += align_up(maxn * 2, 8);
-  a.l.tok = off; off += align_up((cap > 0 ? cap : 1) * 2, 8);
-  a.l.rp = a.l.col = a.l.eat = a.l.nat = off;
-  if (p->labeled) {
-    a.l.rp = off; off += align_up((maxn + 1) * 4, 8);
-    a.l.col = off; off += align_up((g->max_edges > 0 ? g->max_edges : 1) * 2, 8);
-    a.l.eat = off; off += align_up(g->max_edges > 0 ? g->max_edges : 1, 8);
-    a.l.nat = off; off += align_up(maxn, 8);
+  if (reg_path) {
+    a.l.adj = off; off += 64 * 8;
+    a.l.vis = a.l.rng = a.l.vidx = a.l.order = a.l.nat = 0;
+    // no store of the walk is bounds-checked: room for the longest possible trail (or max_len) + one iteration
+    const int64_t bound = p->labeled ? 2 + 7 * (int64_t)maxn + 2 * (int64_t)maxe : 2 + 5 * (int64_t)maxn + (int64_t)maxe;
+    const int tokcap = (int)(bound < p->max_len ? bound : p->max_len) + kSentSlack;
+    a.l.tok = off; off += align_up(tokcap * 2, 8);
+    a.l.rp = a.l.col = a.l.eat = off;
+    if (p->labeled) {
+      a.l.rp = off; off += align_up((64 + 1) * 4, 8);
+      a.l.col = off; off += align_up(maxe * 2, 8);
+      a.l.eat = off; off += align_up(maxe, 8);
+    }
+  } else {
+    a.l.adj = off; off += maxn * W * 8;
+    a.l.vis = off; off += W * 8;
+    a.l.rng = off; off += 256 * 4;
+    a.l.vidx = off; off += align_up(maxn * 2, 8);
+    a.l.order = off; off += align_up(maxn * 2, 8);
+    a.l.tok = off; off += align_up((cap + 4) * 2, 8);
+    a.l.rp = a.l.col = a.l.eat = a.l.nat = off;
+    if (p->labeled) {
+      a.l.rp = off; off += align_up((maxn + 1) * 4, 8);
+      a.l.col = off; off += align_up(maxe * 2, 8);
+      a.l.eat = off; off += align_up(maxe, 8);
+      a.l.nat = off; off += align_up(maxn, 8);
+    }
   }
   a.l.stride = align_up(off, 16);
   if (a.l.stride > 160 * 1024) return GTOK_E_TOO_LARGE;
@@ -363,11 +366,20 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
 #define PICK(w)                                                                   \
   kern = p->labeled ? (void (*)(const SentArgs))sent_kernel<w, true>             \
                     : (void (*)(const SentArgs))sent_kernel<w, false>
-  switch (W) {
-    case 1: PICK(1); break;
-    case 2: PICK(2); break;
-    case 4: PICK(4); break;
-    default: PICK(8); break;
+  if (reg_path) {
+    // no truncation test in the walk when max_len can hold the longest possible trail of this batch
+    const int64_t bound = p->labeled ? 2 + 7 * (int64_t)maxn + 2 * (int64_t)maxe : 2 + 5 * (int64_t)maxn + (int64_t)maxe;
+    const bool nolim = bound <= p->max_len;
+    typedef void (*K)(const SentArgs);
+    kern = p->labeled ? (nolim ? (K)sent_reg_kernel<true, true> : (K)sent_reg_kernel<true, false>)
+                      : (nolim ? (K)sent_reg_kernel<false, true> : (K)sent_reg_kernel<false, false>);
+  } else {
+    switch (W) {
+      case 1: PICK(1); break;
+      case 2: PICK(2); break;
+      case 4: PICK(4); break;
+      default: PICK(8); break;
+    }
   }
 #undef PICK
   if (lds > 64 * 1024) {

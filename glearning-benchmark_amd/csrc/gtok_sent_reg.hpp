@@ -1,0 +1,259 @@
+// gtok_sent_reg.hpp — SENT walk for graphs with at most 64 nodes (every ZINC molecule), walk state in
+// REGISTERS: lane v owns adjacency row v (one 64-bit word of uncovered-edge bits), its visit index and
+// its node type; lane k owns the k-th visited node and Philox block k.  Per trail step the wave does
+//   v_readlane (row of the current node) -> s_bcnt1 -> Philox word by v_readlane -> s_mul_hi ->
+//   v_mbcnt + ballot + s_ff1 (k-th uncovered edge) -> two predicated bit clears
+// with no LDS round trip on the dependency chain: tokens go to LDS as fire-and-forget writes, and the
+// edge-type tokens of labelled graphs are written as (a,b) placeholders that the row writer resolves for
+// all lanes in parallel at the end.  Same spec, same token stream as sent_kernel<1,*>.
+#pragma once
+#include "gtok_common.hpp"
+#include "gtok.h"
+
+namespace gtok {
+
+struct SentLds {  // byte offsets inside a wave's LDS slice, computed on the host
+  int adj, vis, vidx, order, rng, tok, rp, col, eat, nat, stride;
+};
+
+struct SentArgs {
+  gtok_csr g;
+  gtok_sent_params p;
+  SentLds l;
+  int cap;        // min(max_len, ld): trail tokens stored
+  int maxn;       // adjacency rows per slice
+  int32_t *out;
+  int ld;
+  int32_t *out_len;
+  int units;      // ceil(G / waves_per_block)
+  int upb;        // units per block
+};
+
+constexpr int kEdgeRef = 0x8000;  // tok entry = kEdgeRef | a << 6 | b : "edge type of (a,b)", resolved by the writer
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+// number of set bits of a wave-uniform mask below this lane
+__device__ __forceinline__ int mbcnt64(uint64_t m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// k-th (0-based) set bit of a wave-uniform word: the lanes whose below-count equals k form the run that
+// ends at that bit, so one compare + scalar AND + s_ff1 finds it
+__device__ __forceinline__ int kth_bit_reg(uint64_t word, int k) {
+  const uint64_t eq = (uint64_t)__ballot(mbcnt64(word) == k);
+  return __ffsll((unsigned long long)(eq & word)) - 1;
+}
+
+// How much a single walk iteration can append past `lim`: edge + position + type + LADJ + 64 x 2 + RADJ,
+// plus RESET/position and EOS.  The token buffer is sized min(lim, bound) + kSentSlack, so no store in the
+// walk needs a bounds check.
+constexpr int kSentSlack = 144;
+
+// LAB: labelled graphs.  NOLIM: the host proved min(max_len) >= the longest possible trail of this
+// batch, so the walk needs no per-iteration truncation test.
+template <bool LAB, bool NOLIM>
+__global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
+  unsigned char *base = smem + (size_t)wave * a.l.stride;
+  uint64_t *adjT = reinterpret_cast<uint64_t *>(base + a.l.adj);   // [64] transposed bits (symmetric closure)
+  uint16_t *tok = reinterpret_cast<uint16_t *>(base + a.l.tok);
+  int32_t *rp = reinterpret_cast<int32_t *>(base + a.l.rp);
+  uint16_t *colL = reinterpret_cast<uint16_t *>(base + a.l.col);
+  uint8_t *eatL = base + a.l.eat;
+
+  const int lim = a.p.max_len;
+  const int idx_off = GTOK_SENT_IDX_OFFSET;
+  const int node_off = idx_off + a.p.max_num_nodes;
+  const int edge_off = node_off + a.p.num_node_types;
+  const uint32_t k0 = (uint32_t)a.p.seed, k1 = (uint32_t)(a.p.seed >> 32), epoch = (uint32_t)a.p.epoch;
+  const bool remap = a.p.remap_zinc != 0;
+  constexpr int per = LAB ? 2 : 1;
+  const bool is0 = lane == 0, is1 = lane == 1;
+
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * wpb + wave;
+    if (g >= a.g.num_graphs) break;
+    const int nb0 = a.g.node_ptr[g];
+    const int nfull = a.g.node_ptr[g + 1] - nb0;
+    const int n = min(nfull, 64);
+    const int64_t e0 = a.g.edge_ptr[g];
+    const int e = LAB ? min((int)(a.g.edge_ptr[g + 1] - e0), a.g.max_edges) : (int)(a.g.edge_ptr[g + 1] - e0);
+    const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
+    const int32_t *__restrict__ colg = a.g.col + e0;
+    const uint64_t gid = (uint64_t)(a.p.graph_base + g);
+    const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
+
+    // ---- load: this lane's row bounds, node-type TOKEN; (labelled) stage the neighbour lists for the writer
+    int rs = 0, re = 0, nat = 0;
+    if (lane < n) {
+      rs = rpg[lane]; re = rpg[lane + 1];
+      if (LAB) nat = node_off + a.g.nattr[nb0 + lane];
+    }
+    adjT[lane] = 0;
+    if (LAB) {
+      if (lane < n) { rp[lane] = rs; if (lane == n - 1) rp[n] = re; }
+      for (int i = lane; i < e; i += kWave) {
+        colL[i] = (uint16_t)colg[i];
+        eatL[i] = a.g.eattr[e0 + i];
+      }
+    }
+    // decision-major Philox: lane j holds the word of decision d0 + j (block (d0+j)>>2, word (d0+j)&3).
+    // A graph of n <= 64 nodes takes at most 2n <= 128 decisions: two registers cover every walk.
+    auto draws = [&](int d0) -> uint32_t {
+      uint32_t o[4];
+      philox4x32_10((uint32_t)((d0 + lane) >> 2), epoch, gid_lo, gid_hi, k0, k1, o);
+      const int w = lane & 3;
+      uint32_t x = o[3];
+      x = w == 2 ? o[2] : x;
+      x = w == 1 ? o[1] : x;
+      x = w == 0 ? o[0] : x;
+      return x;
+    };
+    uint32_t R = draws(0);
+    wave_sync();
+    // ---- undirected=True: own row in a register, transposed bits through LDS atomics.  The adjacency is
+    // never modified afterwards: for a visited node c the uncovered edges are exactly adj[c] & ~vis.
+    uint64_t adj = 0;
+    for (int k = rs; k < re; ++k) {
+      const int v = LAB ? (int)colL[k] : colg[k];
+      if ((unsigned)v < (unsigned)n) {
+        adj |= 1ull << v;
+        atomicOr(reinterpret_cast<unsigned long long *>(&adjT[v]), 1ull << lane);
+      }
+    }
+    wave_sync();
+    adj |= adjT[lane];
+
+    // ---- walk (all control values wave-uniform, kept in SGPRs)
+    uint64_t vis = 0;
+    int pos = 1, d = 0, nvis = 0, ord = 0;
+    uint16_t *tokl = tok + lane;   // this lane's slot relative to the running position
+
+    auto below = [&](uint32_t nchoices) -> uint32_t {
+      const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)R, d & 63);
+      ++d;
+      if (d == 64) R = draws(64);
+      return __umulhi(x, nchoices);
+    };
+    // neighbourhood bracket of the node just visited (visit index nvis-1): LADJ [edge ref] position ... RADJ
+    auto bracket = [&](int v, uint64_t A) {
+      const bool member = (lane < nvis) && ((A >> ord) & 1ull);   // lane = visit index: ascending order for free
+      const uint64_t M = __ballot(member);
+      const int cnt = __popcll(M);
+      if (is0) { tok[pos] = GTOK_SENT_LADJ; tok[pos + 1 + per * cnt] = GTOK_SENT_RADJ; }
+      if (member) {
+        const int q = pos + 1 + per * mbcnt64(M);
+        if (LAB) { tok[q] = (uint16_t)(kEdgeRef | (v << 6) | ord); tok[q + 1] = (uint16_t)(idx_off + lane); }
+        else tok[q] = (uint16_t)(idx_off + lane);
+      }
+      pos += 2 + per * cnt;
+    };
+    // first visit of v after a trail step from `pred`: [edge ref] position [type] leave in ONE store
+    auto step_to = [&](int v, int pred) {
+      if (lane == nvis) ord = v;
+      vis |= 1ull << v;
+      if (LAB) {
+        int t = __builtin_amdgcn_readlane(nat, v);
+        t = is1 ? idx_off + nvis : t;
+        t = is0 ? (kEdgeRef | (pred << 6) | v) : t;
+        if (lane < 3) tokl[pos] = (uint16_t)t;
+        pos += 3;
+      } else {
+        if (is0) tokl[pos] = (uint16_t)(idx_off + nvis);
+        pos += 1;
+      }
+      ++nvis;
+      // uncovered edges back to visited nodes (v included: self loop), minus the trail edge just taken
+      const uint64_t A = readlane64(adj, v) & vis & ~(1ull << pred);
+      if (A) bracket(v, A);
+    };
+    // first visit of v as a start / restart node (no incoming trail edge)
+    auto start_at = [&](int v) {
+      if (lane == nvis) ord = v;
+      vis |= 1ull << v;
+      if (LAB) {
+        int t = __builtin_amdgcn_readlane(nat, v);
+        t = is0 ? idx_off + nvis : t;
+        if (lane < 2) tokl[pos] = (uint16_t)t;
+        pos += 2;
+      } else {
+        if (is0) tokl[pos] = (uint16_t)(idx_off + nvis);
+        pos += 1;
+      }
+      ++nvis;
+      const uint64_t A = readlane64(adj, v) & vis;
+      if (A) bracket(v, A);
+    };
+
+    if (is0) tok[0] = GTOK_SENT_SOS;
+    if (n > 0) {
+      int cur = (int)below((uint32_t)n);
+      start_at(cur);
+      while (NOLIM || pos < lim) {
+        const uint64_t row = readlane64(adj, cur) & ~vis;
+        if (row) {  // extend the trail over an uncovered edge (always towards an unvisited node)
+          const int nxt = kth_bit_reg(row, (int)below((uint32_t)__popcll(row)));
+          step_to(nxt, cur);
+          cur = nxt;
+          continue;
+        }
+        // dead end: visited nodes that still own uncovered edges
+        const uint64_t live = (uint64_t)__ballot((adj & ~vis) != 0) & vis;
+        if (live) {
+          cur = kth_bit_reg(live, (int)below((uint32_t)__popcll(live)));
+          const int k = __ffsll((unsigned long long)__ballot(lane < nvis && ord == cur)) - 1;   // its visit index
+          if (lane < 2) tokl[pos] = (uint16_t)(is0 ? GTOK_SENT_RESET : idx_off + k);
+          pos += 2;
+          continue;
+        }
+        if (nvis < n) {  // another component or an isolated node
+          const uint64_t un = ~vis & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+          cur = kth_bit_reg(un, (int)below((uint32_t)(n - nvis)));
+          if (is0) tok[pos] = GTOK_SENT_RESET;
+          pos += 1;
+          start_at(cur);
+          continue;
+        }
+        break;
+      }
+    }
+    if (is0) tok[pos] = GTOK_SENT_EOS;
+    pos += 1;
+
+    // ---- row out: resolve edge-type placeholders, remap, append the query, pad
+    const int ltrail = min(pos, lim);
+    int len = ltrail;
+    if (a.p.query) {  // trainer/train_agtt.py:257-267: [idx_off+N, idx_off+u, idx_off+v] after the trail, not remapped
+      if (lane < 3)
+        tok[ltrail + lane] = (uint16_t)(idx_off + (lane == 0 ? nfull : a.p.query[2 * (int64_t)g + lane - 1]));
+      len = ltrail + 3;
+    }
+    wave_sync();
+    write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, a.ld), a.p.pad_id, [=](int i) -> int {
+      int t = tok[i];
+      if (i >= ltrail) return t;
+      if (LAB && (t & kEdgeRef)) {  // first listed entry x->y, else first y->x
+        const int x = (t >> 6) & 63, y = t & 63;
+        int et = 0;
+        bool found = false;
+        for (int k = rp[x], ke = rp[x + 1]; k < ke && !found; ++k)
+          if (colL[k] == (uint16_t)y) { et = eatL[k]; found = true; }
+        for (int k = rp[y], ke = rp[y + 1]; k < ke && !found; ++k)
+          if (colL[k] == (uint16_t)x) { et = eatL[k]; found = true; }
+        t = edge_off + et;
+      }
+      return remap ? remap_zinc_token(t, idx_off, node_off, edge_off) : t;
+    });
+    if (is0) a.out_len[g] = len;
+    wave_sync();
+  }
+}
+
+}  // namespace gtok
