@@ -322,8 +322,9 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   // GTOK_SENT_GENERIC=1 forces the LDS bit-matrix kernel (A/B runs, tests of both paths)
   const char *force = std::getenv("GTOK_SENT_GENERIC");
   const bool reg_path = W == 1 && !(force && force[0] == '1') &&
-                        GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < kEdgeRef &&
-                        (!p->labeled || g->max_edges <= 65535);
+                        22 + GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < kEdgeRef &&
+                        (!p->labeled || g->max_edges <= 65535) &&
+                        (!p->remap_zinc || g->max_nodes <= p->max_num_nodes);   // remap folded into constants
 
   SentArgs a;
   a.g = *g; a.p = *p; a.cap = cap; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
@@ -337,7 +338,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.l.tok = off; off += align_up(tokcap * 2, 8);
     a.l.rp = a.l.col = a.l.eat = off;
     if (p->labeled) {
-      a.l.rp = off; off += align_up((64 + 1) * 4, 8);
+      a.l.rp = off; off += 64 * 64;                       // edge-type table et[a][b]
       a.l.col = off; off += align_up(maxe * 2, 8);
       a.l.eat = off; off += align_up(maxe, 8);
     }

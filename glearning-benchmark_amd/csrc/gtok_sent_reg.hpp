@@ -52,8 +52,13 @@ __device__ __forceinline__ int kth_bit_reg(uint64_t word, int k) {
 // walk needs a bounds check.
 constexpr int kSentSlack = 144;
 
-// LAB: labelled graphs.  NOLIM: the host proved min(max_len) >= the longest possible trail of this
-// batch, so the walk needs no per-iteration truncation test.
+// LAB: labelled graphs.  NOLIM: the host proved max_len >= the longest possible trail of this batch, so
+// the walk needs no per-iteration truncation test.
+//
+// The ZINC remap (trainer/train_agtt.py:171-244) is folded into the emission constants: SOS/RESET/LADJ/
+// RADJ/EOS and the position base are picked once per launch, node-type tokens are remapped once per node
+// at load time, edge-type tokens once per placeholder in the writer — no per-token remap pass.  (The host
+// only takes this kernel with remap when max_nodes <= max_num_nodes, where folding is exact.)
 template <bool LAB, bool NOLIM>
 __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -62,9 +67,9 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
   unsigned char *base = smem + (size_t)wave * a.l.stride;
   uint64_t *adjT = reinterpret_cast<uint64_t *>(base + a.l.adj);   // [64] transposed bits (symmetric closure)
   uint16_t *tok = reinterpret_cast<uint16_t *>(base + a.l.tok);
-  int32_t *rp = reinterpret_cast<int32_t *>(base + a.l.rp);
-  uint16_t *colL = reinterpret_cast<uint16_t *>(base + a.l.col);
-  uint8_t *eatL = base + a.l.eat;
+  uint16_t *colL = reinterpret_cast<uint16_t *>(base + a.l.col);   // staged neighbour ids   (labelled)
+  uint8_t *eatL = base + a.l.eat;                                  // staged edge types      (labelled)
+  uint8_t *et = base + a.l.rp;                                     // [64][64] edge type of (a,b), O(1) for the writer
 
   const int lim = a.p.max_len;
   const int idx_off = GTOK_SENT_IDX_OFFSET;
@@ -72,6 +77,9 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
   const int edge_off = node_off + a.p.num_node_types;
   const uint32_t k0 = (uint32_t)a.p.seed, k1 = (uint32_t)(a.p.seed >> 32), epoch = (uint32_t)a.p.epoch;
   const bool remap = a.p.remap_zinc != 0;
+  const int pos_base = remap ? 22 : idx_off;                       // 22 + (t - idx_off)
+  const int T_RESET = remap ? 2 : GTOK_SENT_RESET, T_LADJ = remap ? 2 : GTOK_SENT_LADJ;
+  const int T_RADJ = remap ? 2 : GTOK_SENT_RADJ, T_EOS = remap ? 1 : GTOK_SENT_EOS;
   constexpr int per = LAB ? 2 : 1;
   const bool is0 = lane == 0, is1 = lane == 1;
 
@@ -90,15 +98,17 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
     const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
 
-    // ---- load: this lane's row bounds, node-type TOKEN; (labelled) stage the neighbour lists for the writer
+    // ---- load: this lane's row bounds and its node-type TOKEN; (labelled) stage the entries, coalesced
     int rs = 0, re = 0, nat = 0;
     if (lane < n) {
       rs = rpg[lane]; re = rpg[lane + 1];
-      if (LAB) nat = node_off + a.g.nattr[nb0 + lane];
+      if (LAB) {
+        nat = node_off + a.g.nattr[nb0 + lane];
+        if (remap) nat = remap_zinc_token(nat, idx_off, node_off, edge_off);
+      }
     }
     adjT[lane] = 0;
     if (LAB) {
-      if (lane < n) { rp[lane] = rs; if (lane == n - 1) rp[n] = re; }
       for (int i = lane; i < e; i += kWave) {
         colL[i] = (uint16_t)colg[i];
         eatL[i] = a.g.eattr[e0 + i];
@@ -120,15 +130,24 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     wave_sync();
     // ---- undirected=True: own row in a register, transposed bits through LDS atomics.  The adjacency is
     // never modified afterwards: for a visited node c the uncovered edges are exactly adj[c] & ~vis.
+    // Edge types: et[a][b] = type of the first listed entry a->b, else of the first b->a — reverse cells
+    // first, forward cells on top, each lane walking its row backwards so the earliest entry wins.
     uint64_t adj = 0;
-    for (int k = rs; k < re; ++k) {
+    for (int k = re - 1; k >= rs; --k) {
       const int v = LAB ? (int)colL[k] : colg[k];
       if ((unsigned)v < (unsigned)n) {
         adj |= 1ull << v;
         atomicOr(reinterpret_cast<unsigned long long *>(&adjT[v]), 1ull << lane);
+        if (LAB) et[v * 64 + lane] = eatL[k];
       }
     }
     wave_sync();
+    if (LAB) {
+      for (int k = re - 1; k >= rs; --k) {
+        const int v = colL[k];
+        if ((unsigned)v < (unsigned)n) et[lane * 64 + v] = eatL[k];
+      }
+    }
     adj |= adjT[lane];
 
     // ---- walk (all control values wave-uniform, kept in SGPRs)
@@ -147,11 +166,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       const bool member = (lane < nvis) && ((A >> ord) & 1ull);   // lane = visit index: ascending order for free
       const uint64_t M = __ballot(member);
       const int cnt = __popcll(M);
-      if (is0) { tok[pos] = GTOK_SENT_LADJ; tok[pos + 1 + per * cnt] = GTOK_SENT_RADJ; }
+      if (is0) { tok[pos] = (uint16_t)T_LADJ; tok[pos + 1 + per * cnt] = (uint16_t)T_RADJ; }
       if (member) {
         const int q = pos + 1 + per * mbcnt64(M);
-        if (LAB) { tok[q] = (uint16_t)(kEdgeRef | (v << 6) | ord); tok[q + 1] = (uint16_t)(idx_off + lane); }
-        else tok[q] = (uint16_t)(idx_off + lane);
+        if (LAB) { tok[q] = (uint16_t)(kEdgeRef | (v << 6) | ord); tok[q + 1] = (uint16_t)(pos_base + lane); }
+        else tok[q] = (uint16_t)(pos_base + lane);
       }
       pos += 2 + per * cnt;
     };
@@ -161,12 +180,12 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       vis |= 1ull << v;
       if (LAB) {
         int t = __builtin_amdgcn_readlane(nat, v);
-        t = is1 ? idx_off + nvis : t;
+        t = is1 ? pos_base + nvis : t;
         t = is0 ? (kEdgeRef | (pred << 6) | v) : t;
         if (lane < 3) tokl[pos] = (uint16_t)t;
         pos += 3;
       } else {
-        if (is0) tokl[pos] = (uint16_t)(idx_off + nvis);
+        if (is0) tokl[pos] = (uint16_t)(pos_base + nvis);
         pos += 1;
       }
       ++nvis;
@@ -180,11 +199,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       vis |= 1ull << v;
       if (LAB) {
         int t = __builtin_amdgcn_readlane(nat, v);
-        t = is0 ? idx_off + nvis : t;
+        t = is0 ? pos_base + nvis : t;
         if (lane < 2) tokl[pos] = (uint16_t)t;
         pos += 2;
       } else {
-        if (is0) tokl[pos] = (uint16_t)(idx_off + nvis);
+        if (is0) tokl[pos] = (uint16_t)(pos_base + nvis);
         pos += 1;
       }
       ++nvis;
@@ -192,7 +211,7 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       if (A) bracket(v, A);
     };
 
-    if (is0) tok[0] = GTOK_SENT_SOS;
+    if (is0) tok[0] = GTOK_SENT_SOS;   // SOS -> <bos>: 0 either way
     if (n > 0) {
       int cur = (int)below((uint32_t)n);
       start_at(cur);
@@ -209,14 +228,14 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
         if (live) {
           cur = kth_bit_reg(live, (int)below((uint32_t)__popcll(live)));
           const int k = __ffsll((unsigned long long)__ballot(lane < nvis && ord == cur)) - 1;   // its visit index
-          if (lane < 2) tokl[pos] = (uint16_t)(is0 ? GTOK_SENT_RESET : idx_off + k);
+          if (lane < 2) tokl[pos] = (uint16_t)(is0 ? T_RESET : pos_base + k);
           pos += 2;
           continue;
         }
         if (nvis < n) {  // another component or an isolated node
           const uint64_t un = ~vis & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
           cur = kth_bit_reg(un, (int)below((uint32_t)(n - nvis)));
-          if (is0) tok[pos] = GTOK_SENT_RESET;
+          if (is0) tok[pos] = (uint16_t)T_RESET;
           pos += 1;
           start_at(cur);
           continue;
@@ -224,10 +243,10 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
         break;
       }
     }
-    if (is0) tok[pos] = GTOK_SENT_EOS;
+    if (is0) tok[pos] = (uint16_t)T_EOS;
     pos += 1;
 
-    // ---- row out: resolve edge-type placeholders, remap, append the query, pad
+    // ---- row out: resolve edge-type placeholders, append the query, pad
     const int ltrail = min(pos, lim);
     int len = ltrail;
     if (a.p.query) {  // trainer/train_agtt.py:257-267: [idx_off+N, idx_off+u, idx_off+v] after the trail, not remapped
@@ -238,18 +257,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     wave_sync();
     write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, a.ld), a.p.pad_id, [=](int i) -> int {
       int t = tok[i];
-      if (i >= ltrail) return t;
-      if (LAB && (t & kEdgeRef)) {  // first listed entry x->y, else first y->x
-        const int x = (t >> 6) & 63, y = t & 63;
-        int et = 0;
-        bool found = false;
-        for (int k = rp[x], ke = rp[x + 1]; k < ke && !found; ++k)
-          if (colL[k] == (uint16_t)y) { et = eatL[k]; found = true; }
-        for (int k = rp[y], ke = rp[y + 1]; k < ke && !found; ++k)
-          if (colL[k] == (uint16_t)x) { et = eatL[k]; found = true; }
-        t = edge_off + et;
+      if (LAB && (t & kEdgeRef) && i < ltrail) {
+        t = edge_off + et[t & 0xFFF];
+        if (remap) t = remap_zinc_token(t, idx_off, node_off, edge_off);
       }
-      return remap ? remap_zinc_token(t, idx_off, node_off, edge_off) : t;
+      return t;
     });
     if (is0) a.out_len[g] = len;
     wave_sync();
