@@ -44,8 +44,28 @@ __device__ __forceinline__ int mbcnt64(uint64_t m) {
 // ends at that bit, so one compare + scalar AND + s_ff1 finds it
 __device__ __forceinline__ int kth_bit_reg(uint64_t word, int k) {
   const uint64_t eq = (uint64_t)__ballot(mbcnt64(word) == k);
-  return __ffsll((unsigned long long)(eq & word)) - 1;
+  return __builtin_ctzll(eq & word);   // k < popcount(word): never empty
 }
+
+// Wave-uniform reads of the read-only graph pointers as SCALAR loads (constant address space): the
+// compiler will not prove invariance through the by-value argument struct on its own.
+typedef const int32_t __attribute__((address_space(4))) *kptr32;
+typedef const int64_t __attribute__((address_space(4))) *kptr64;
+__device__ __forceinline__ int sload(const int32_t *p, int64_t i) { return ((kptr32)(uintptr_t)p)[i]; }
+__device__ __forceinline__ int64_t sload(const int64_t *p, int64_t i) { return ((kptr64)(uintptr_t)p)[i]; }
+
+// remap_zinc_token restricted to node-type tokens (t = node_off + x >= node_off), branch-free:
+// train_agtt.py:209-230 — x < ntypes: atom 8+x if x < 9 else 22+t; otherwise the token sits in the edge
+// range: b = x - ntypes, bond 17+b if b < 4 else 22+t.
+__device__ __forceinline__ int remap_node_type(int x, int node_off, int ntypes) {
+  const int t = node_off + x, b = x - ntypes;
+  int r = 22 + t;
+  r = (x < ntypes && x < 9) ? 8 + x : r;
+  r = (b >= 0 && b < 4) ? 17 + b : r;
+  return r;
+}
+// ... and to edge-type tokens (t = edge_off + at >= edge_off): bond 17+at if at < 4 else 22+t
+__device__ __forceinline__ int remap_edge_type(int at, int edge_off) { return at < 4 ? 17 + at : 22 + edge_off + at; }
 
 // How much a single walk iteration can append past `lim`: edge + position + type + LADJ + 64 x 2 + RADJ,
 // plus RESET/position and EOS.  The token buffer is sized min(lim, bound) + kSentSlack, so no store in the
@@ -88,11 +108,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
   for (int unit = u0; unit < u1; ++unit) {
     const int g = unit * wpb + wave;
     if (g >= a.g.num_graphs) break;
-    const int nb0 = a.g.node_ptr[g];
-    const int nfull = a.g.node_ptr[g + 1] - nb0;
+    const int nb0 = sload(a.g.node_ptr, g);
+    const int nfull = sload(a.g.node_ptr, g + 1) - nb0;
     const int n = min(nfull, 64);
-    const int64_t e0 = a.g.edge_ptr[g];
-    const int e = LAB ? min((int)(a.g.edge_ptr[g + 1] - e0), a.g.max_edges) : (int)(a.g.edge_ptr[g + 1] - e0);
+    const int64_t e0 = sload(a.g.edge_ptr, g);
+    const int e = LAB ? min((int)(sload(a.g.edge_ptr, g + 1) - e0), a.g.max_edges) : (int)(sload(a.g.edge_ptr, g + 1) - e0);
     const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
     const int32_t *__restrict__ colg = a.g.col + e0;
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
@@ -103,8 +123,8 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     if (lane < n) {
       rs = rpg[lane]; re = rpg[lane + 1];
       if (LAB) {
-        nat = node_off + a.g.nattr[nb0 + lane];
-        if (remap) nat = remap_zinc_token(nat, idx_off, node_off, edge_off);
+        const int x = a.g.nattr[nb0 + lane];
+        nat = remap ? remap_node_type(x, node_off, a.p.num_node_types) : node_off + x;
       }
     }
     adjT[lane] = 0;
@@ -158,7 +178,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     auto below = [&](uint32_t nchoices) -> uint32_t {
       const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)R, d & 63);
       ++d;
-      if (d == 64) R = draws(64);
+      if (d == 64) {   // rare: keep the second Philox block out of the common path (opaque to hoisting)
+        int d0 = d;
+        asm volatile("" : "+s"(d0));
+        R = draws(d0);
+      }
       return __umulhi(x, nchoices);
     };
     // neighbourhood bracket of the node just visited (visit index nvis-1): LADJ [edge ref] position ... RADJ
@@ -258,8 +282,8 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, a.ld), a.p.pad_id, [=](int i) -> int {
       int t = tok[i];
       if (LAB && (t & kEdgeRef) && i < ltrail) {
-        t = edge_off + et[t & 0xFFF];
-        if (remap) t = remap_zinc_token(t, idx_off, node_off, edge_off);
+        const int at = et[t & 0xFFF];
+        t = remap ? remap_edge_type(at, edge_off) : edge_off + at;
       }
       return t;
     });
