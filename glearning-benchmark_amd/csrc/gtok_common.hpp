@@ -10,9 +10,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 namespace gtok {
 
 constexpr int kWave = 64;
+
+// Workgroups per CU to size a one-round grid for.  These kernels carry ~100 SGPRs, for which gfx950 admits
+// floor(800 / (ceil(sgpr/16)*16 + 16)) = 6 waves per SIMD while hipOccupancyMaxActiveBlocksPerMultiprocessor
+// answers 8 (MI355X_MICROARCH.md, "Residency and cooperative launch"); a grid sized by the API's answer runs
+// a straggler second round (measured: 0.72 ms at 8 vs 0.65 ms at 6).  GTOK_MAX_BLOCKS_PER_CU overrides.
+inline int resident_blocks(int api_answer) {
+  int cap = 6;
+  if (const char *s = std::getenv("GTOK_MAX_BLOCKS_PER_CU")) {
+    const int c = std::atoi(s);
+    if (c >= 1) cap = c;
+  }
+  return api_answer < cap ? api_answer : cap;
+}
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -339,6 +339,7 @@ static Launch plan(const void *kern, int num_items, int wpb, size_t lds) {
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, wpb * 64, lds) != hipSuccess || occ < 1) occ = 1;
+  occ = resident_blocks(occ);
   Launch L;
   L.units = (num_items + wpb - 1) / wpb;
   int nb = ncu * occ;

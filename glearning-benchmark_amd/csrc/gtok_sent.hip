@@ -338,7 +338,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.l.tok = off; off += align_up(tokcap * 2, 8);
     a.l.rp = a.l.col = a.l.eat = off;
     if (p->labeled) {
-      a.l.rp = off; off += 64 * 64;                       // edge-type table et[a][b]
+      a.l.rp = off; off += align_up(maxn * maxn, 8);      // edge-type table et[a][b]
       a.l.col = off; off += align_up(maxe * 2, 8);
       a.l.eat = off; off += align_up(maxe, 8);
     }
@@ -394,6 +394,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern),
                                                    wpb * 64, lds) != hipSuccess || occ < 1)
     occ = 1;
+  occ = gtok::resident_blocks(occ);
   a.units = (g->num_graphs + wpb - 1) / wpb;
   int nb = ncu * occ;
   if (nb > a.units) nb = a.units;

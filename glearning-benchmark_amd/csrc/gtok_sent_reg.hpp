@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
   uint16_t *tok = reinterpret_cast<uint16_t *>(base + a.l.tok);
   uint16_t *colL = reinterpret_cast<uint16_t *>(base + a.l.col);   // staged neighbour ids   (labelled)
   uint8_t *eatL = base + a.l.eat;                                  // staged edge types      (labelled)
-  uint8_t *et = base + a.l.rp;                                     // [64][64] edge type of (a,b), O(1) for the writer
+  uint8_t *et = base + a.l.rp;                                     // [maxn][maxn] edge type of (a,b), O(1) for the writer
+  const int S = a.maxn;
 
   const int lim = a.p.max_len;
   const int idx_off = GTOK_SENT_IDX_OFFSET;
@@ -158,14 +159,14 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       if ((unsigned)v < (unsigned)n) {
         adj |= 1ull << v;
         atomicOr(reinterpret_cast<unsigned long long *>(&adjT[v]), 1ull << lane);
-        if (LAB) et[v * 64 + lane] = eatL[k];
+        if (LAB) et[v * S + lane] = eatL[k];
       }
     }
     wave_sync();
     if (LAB) {
       for (int k = re - 1; k >= rs; --k) {
         const int v = colL[k];
-        if ((unsigned)v < (unsigned)n) et[lane * 64 + v] = eatL[k];
+        if ((unsigned)v < (unsigned)n) et[lane * S + v] = eatL[k];
       }
     }
     adj |= adjT[lane];
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, a.ld), a.p.pad_id, [=](int i) -> int {
       int t = tok[i];
       if (LAB && (t & kEdgeRef) && i < ltrail) {
-        const int at = et[t & 0xFFF];
+        const int at = et[((t >> 6) & 63) * S + (t & 63)];
         t = remap ? remap_edge_type(at, edge_off) : edge_off + at;
       }
       return t;
