@@ -323,7 +323,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   const char *force = std::getenv("GTOK_SENT_GENERIC");
   const bool reg_path = W == 1 && !(force && force[0] == '1') &&
                         22 + GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < kEdgeRef &&
-                        (!p->labeled || g->max_edges <= 65535) &&
+                        g->max_edges <= 32768 &&
                         (!p->remap_zinc || g->max_nodes <= p->max_num_nodes);   // remap folded into constants
 
   SentArgs a;
@@ -336,10 +336,10 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     const int64_t bound = p->labeled ? 2 + 7 * (int64_t)maxn + 2 * (int64_t)maxe : 2 + 5 * (int64_t)maxn + (int64_t)maxe;
     const int tokcap = (int)(bound < p->max_len ? bound : p->max_len) + kSentSlack;
     a.l.tok = off; off += align_up(tokcap * 2, 8);
-    a.l.rp = a.l.col = a.l.eat = off;
+    a.l.rp = a.l.eat = off;
+    a.l.col = off; off += align_up(maxe * 2, 8);          // staged neighbour ids
     if (p->labeled) {
       a.l.rp = off; off += align_up(maxn * maxn, 8);      // edge-type table et[a][b]
-      a.l.col = off; off += align_up(maxe * 2, 8);
       a.l.eat = off; off += align_up(maxe, 8);
     }
   } else {

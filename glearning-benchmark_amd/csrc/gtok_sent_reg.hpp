@@ -104,36 +104,66 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
   constexpr int per = LAB ? 2 : 1;
   const bool is0 = lane == 0, is1 = lane == 1;
 
+  // Software pipeline over the wave's graphs: the scalar pointers of graph i+2 and the per-lane data of
+  // graph i+1 (row bounds, node type, first 128 CSR entries) are requested before graph i is walked, so
+  // the ~4 dependent memory round trips at the head of every graph overlap with the previous walk.
+  struct Ptrs { int n0, n1; int64_t e0, e1; };   // raw values: differences are taken at the use, not at the load
+  struct Data { int rs, re, x, c0, c1, a0, a1; };
+  auto load_ptrs = [&](int g) -> Ptrs {
+    Ptrs p;
+    p.n0 = sload(a.g.node_ptr, g); p.n1 = sload(a.g.node_ptr, g + 1);
+    p.e0 = sload(a.g.edge_ptr, g); p.e1 = sload(a.g.edge_ptr, g + 1);
+    return p;
+  };
+  auto load_data = [&](int g, const Ptrs &p) -> Data {
+    Data q = {0, 0, 0, 0, 0, 0, 0};
+    const int32_t *__restrict__ rpg = a.g.rowptr + p.n0 + g;
+    const int32_t *__restrict__ colg = a.g.col + p.e0;
+    const int pe = (int)(p.e1 - p.e0);
+    if (lane < min(p.n1 - p.n0, 64)) {
+      q.rs = rpg[lane]; q.re = rpg[lane + 1];
+      if (LAB) q.x = a.g.nattr[p.n0 + lane];
+    }
+    if (lane < pe) { q.c0 = colg[lane]; if (LAB) q.a0 = a.g.eattr[p.e0 + lane]; }
+    if (lane + 64 < pe) { q.c1 = colg[lane + 64]; if (LAB) q.a1 = a.g.eattr[p.e0 + lane + 64]; }
+    return q;
+  };
+
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
-  for (int unit = u0; unit < u1; ++unit) {
-    const int g = unit * wpb + wave;
-    if (g >= a.g.num_graphs) break;
-    const int nb0 = sload(a.g.node_ptr, g);
-    const int nfull = sload(a.g.node_ptr, g + 1) - nb0;
+  const int G = a.g.num_graphs;
+  int g = u0 * wpb + wave;
+  if (u0 >= u1 || g >= G) return;
+  Ptrs pc = load_ptrs(g);
+  Data dc = load_data(g, pc);
+  bool has_next = (u0 + 1 < u1) && (g + wpb < G);
+  Ptrs pn = pc;
+  if (has_next) pn = load_ptrs(g + wpb);
+  for (int unit = u0;; ++unit) {
+    Data dn = dc;
+    if (has_next) dn = load_data(g + wpb, pn);
+    const bool has_next2 = (unit + 2 < u1) && (g + 2 * wpb < G);
+    Ptrs pnn = pn;
+    if (has_next2) pnn = load_ptrs(g + 2 * wpb);
+
+    const int nfull = pc.n1 - pc.n0;
     const int n = min(nfull, 64);
-    const int64_t e0 = sload(a.g.edge_ptr, g);
-    const int e = LAB ? min((int)(sload(a.g.edge_ptr, g + 1) - e0), a.g.max_edges) : (int)(sload(a.g.edge_ptr, g + 1) - e0);
-    const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
+    const int64_t e0 = pc.e0;
+    const int e = min((int)(pc.e1 - pc.e0), a.g.max_edges);
     const int32_t *__restrict__ colg = a.g.col + e0;
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
     const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
 
-    // ---- load: this lane's row bounds and its node-type TOKEN; (labelled) stage the entries, coalesced
-    int rs = 0, re = 0, nat = 0;
-    if (lane < n) {
-      rs = rpg[lane]; re = rpg[lane + 1];
-      if (LAB) {
-        const int x = a.g.nattr[nb0 + lane];
-        nat = remap ? remap_node_type(x, node_off, a.p.num_node_types) : node_off + x;
-      }
-    }
+    // ---- this lane's row bounds and node-type TOKEN; stage the entries in LDS (coalesced)
+    const int rs = dc.rs, re = dc.re;
+    int nat = 0;
+    if (LAB && lane < n) nat = remap ? remap_node_type(dc.x, node_off, a.p.num_node_types) : node_off + dc.x;
     adjT[lane] = 0;
-    if (LAB) {
-      for (int i = lane; i < e; i += kWave) {
-        colL[i] = (uint16_t)colg[i];
-        eatL[i] = a.g.eattr[e0 + i];
-      }
+    if (lane < e) { colL[lane] = (uint16_t)dc.c0; if (LAB) eatL[lane] = (uint8_t)dc.a0; }
+    if (lane + 64 < e) { colL[lane + 64] = (uint16_t)dc.c1; if (LAB) eatL[lane + 64] = (uint8_t)dc.a1; }
+    for (int i = lane + 128; i < e; i += kWave) {   // long edge lists: the rest, not prefetched
+      colL[i] = (uint16_t)colg[i];
+      if (LAB) eatL[i] = a.g.eattr[e0 + i];
     }
     // decision-major Philox: lane j holds the word of decision d0 + j (block (d0+j)>>2, word (d0+j)&3).
     // A graph of n <= 64 nodes takes at most 2n <= 128 decisions: two registers cover every walk.
@@ -154,19 +184,36 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     // Edge types: et[a][b] = type of the first listed entry a->b, else of the first b->a — reverse cells
     // first, forward cells on top, each lane walking its row backwards so the earliest entry wins.
     uint64_t adj = 0;
-    for (int k = re - 1; k >= rs; --k) {
-      const int v = LAB ? (int)colL[k] : colg[k];
-      if ((unsigned)v < (unsigned)n) {
-        adj |= 1ull << v;
-        atomicOr(reinterpret_cast<unsigned long long *>(&adjT[v]), 1ull << lane);
-        if (LAB) et[v * S + lane] = eatL[k];
+    for (int k0 = rs + ((re - rs - 1) & ~3); k0 >= rs; k0 -= 4) {   // chunks of 4, last chunk first
+      int v[4], at[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                                  // all reads first: one round trip
+        const int k = min(k0 + j, re - 1);
+        v[j] = colL[k];
+        if (LAB) at[j] = eatL[k];
+      }
+#pragma unroll
+      for (int j = 3; j >= 0; --j) {
+        if (k0 + j < re && (unsigned)v[j] < (unsigned)n) {
+          adj |= 1ull << v[j];
+          atomicOr(reinterpret_cast<unsigned long long *>(&adjT[v[j]]), 1ull << lane);
+          if (LAB) et[v[j] * S + lane] = (uint8_t)at[j];            // reverse cell
+        }
       }
     }
     wave_sync();
     if (LAB) {
-      for (int k = re - 1; k >= rs; --k) {
-        const int v = colL[k];
-        if ((unsigned)v < (unsigned)n) et[lane * S + v] = eatL[k];
+      for (int k0 = rs + ((re - rs - 1) & ~3); k0 >= rs; k0 -= 4) {
+        int v[4], at[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = min(k0 + j, re - 1);
+          v[j] = colL[k];
+          at[j] = eatL[k];
+        }
+#pragma unroll
+        for (int j = 3; j >= 0; --j)
+          if (k0 + j < re && (unsigned)v[j] < (unsigned)n) et[lane * S + v[j]] = (uint8_t)at[j];   // forward cell on top
       }
     }
     adj |= adjT[lane];
@@ -280,16 +327,54 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       len = ltrail + 3;
     }
     wave_sync();
-    write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, a.ld), a.p.pad_id, [=](int i) -> int {
-      int t = tok[i];
-      if (LAB && (t & kEdgeRef) && i < ltrail) {
-        const int at = et[((t >> 6) & 63) * S + (t & 63)];
-        t = remap ? remap_edge_type(at, edge_off) : edge_off + at;
+    {
+      int32_t *__restrict__ orow = a.out + (int64_t)g * a.ld;
+      const int ld = a.ld, pad = a.p.pad_id, lw = min(len, ld);
+      if (((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(orow) & 15u) == 0)) {
+        for (int i = lane * 4; i < ld; i += kWave * 4) {
+          int4 o = make_int4(pad, pad, pad, pad);
+          if (i < lw) {
+            const uint2 w = *reinterpret_cast<const uint2 *>(tok + i);   // 4 tokens, one ds_read_b64
+            int t[4] = {(int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16)};
+            if (LAB) {
+              bool ph[4];
+              int at[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {                              // 4 edge-type reads in flight together
+                ph[j] = (t[j] & kEdgeRef) && (i + j < ltrail);
+                at[j] = et[ph[j] ? ((t[j] >> 6) & 63) * S + (t[j] & 63) : 0];
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (ph[j]) t[j] = remap ? remap_edge_type(at[j], edge_off) : edge_off + at[j];
+            }
+            o.x = t[0];
+            o.y = i + 1 < lw ? t[1] : pad;
+            o.z = i + 2 < lw ? t[2] : pad;
+            o.w = i + 3 < lw ? t[3] : pad;
+          }
+          *reinterpret_cast<int4 *>(orow + i) = o;
+        }
+      } else {
+        for (int i = lane; i < ld; i += kWave) {
+          int t = pad;
+          if (i < lw) {
+            t = tok[i];
+            if (LAB && (t & kEdgeRef) && i < ltrail) {
+              const int at = et[((t >> 6) & 63) * S + (t & 63)];
+              t = remap ? remap_edge_type(at, edge_off) : edge_off + at;
+            }
+          }
+          orow[i] = t;
+        }
       }
-      return t;
-    });
+    }
     if (is0) a.out_len[g] = len;
     wave_sync();
+    if (!has_next) break;
+    g += wpb;
+    pc = pn; dc = dn; pn = pnn;
+    has_next = has_next2;
   }
 }
 
