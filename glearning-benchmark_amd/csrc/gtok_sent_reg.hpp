@@ -68,9 +68,9 @@ __device__ __forceinline__ int remap_node_type(int x, int node_off, int ntypes) 
 __device__ __forceinline__ int remap_edge_type(int at, int edge_off) { return at < 4 ? 17 + at : 22 + edge_off + at; }
 
 // How much a single walk iteration can append past `lim`: edge + position + type + LADJ + 64 x 2 + RADJ,
-// plus RESET/position and EOS.  The token buffer is sized min(lim, bound) + kSentSlack, so no store in the
+// plus RESET/position and EOS, plus the 63 junk slots an unpredicated store touches.  The token buffer is sized min(lim, bound) + kSentSlack, so no store in the
 // walk needs a bounds check.
-constexpr int kSentSlack = 144;
+constexpr int kSentSlack = 224;   // + 64 slots for the unpredicated stores
 
 // LAB: labelled graphs.  NOLIM: the host proved max_len >= the longest possible trail of this batch, so
 // the walk needs no per-iteration truncation test.
@@ -218,10 +218,23 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     }
     adj |= adjT[lane];
 
-    // ---- walk (all control values wave-uniform, kept in SGPRs)
-    uint64_t vis = 0;
-    int pos = 1, d = 0, nvis = 0, ord = 0;
-    uint16_t *tokl = tok + lane;   // this lane's slot relative to the running position
+    // ---- walk.  The kernel is bound by SCALAR issue (measured: ~1000 SALU vs ~900 VALU per molecule, scalar
+    // pipe ~70 % busy), so only what steers control flow lives in SGPRs (vis, cur, its bit, the decision
+    // counter); the write cursor, the next position token, the visit counter and the edge-ref prefix are
+    // kept as lane-uniform VGPR values (seeded from an opaque zero so the compiler leaves them on the VALU).
+    // Token stores are unpredicated: lane j writes slot pos+j, the lanes past the step's 1..3 tokens drop
+    // junk into slots that later steps overwrite or that lie beyond the final length.
+    // consecutive all-lane stores overlap ACROSS lanes (slot pos+j of one store is slot pos'+j' of the next)
+    // although never within a lane, so the compiler must not reorder them: a zero-instruction barrier
+#define GTOK_TOK_ORDER() asm volatile("" ::: "memory")
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    uint64_t vis = 0, bcur = 0;
+    int d = 0, cur = 0, ord = 0;
+    uint16_t *tokp = tok + 1 + lane;          // slot of this lane at the running position (pos = 1 after SOS)
+    int vptok = vz + pos_base;                // position token of the next new node
+    int vnv = vz;                             // nodes visited so far
+    int vcur6 = vz;                           // kEdgeRef | cur << 6
 
     auto below = [&](uint32_t nchoices) -> uint32_t {
       const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)R, d & 63);
@@ -233,9 +246,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       }
       return __umulhi(x, nchoices);
     };
-    // neighbourhood bracket of the node just visited (visit index nvis-1): LADJ [edge ref] position ... RADJ
+    // neighbourhood bracket of the node just visited: LADJ [edge ref] position ... RADJ   (uncommon path)
     auto bracket = [&](int v, uint64_t A) {
-      const bool member = (lane < nvis) && ((A >> ord) & 1ull);   // lane = visit index: ascending order for free
+      const int nv = __popcll(vis);
+      const int pos = (int)(__builtin_amdgcn_readfirstlane((int)(uintptr_t)tokp) - (int)(uintptr_t)tok) >> 1;
+      const bool member = (lane < nv) && ((A >> ord) & 1ull);     // lane = visit index: ascending order for free
       const uint64_t M = __ballot(member);
       const int cnt = __popcll(M);
       if (is0) { tok[pos] = (uint16_t)T_LADJ; tok[pos + 1 + per * cnt] = (uint16_t)T_RADJ; }
@@ -244,79 +259,92 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
         if (LAB) { tok[q] = (uint16_t)(kEdgeRef | (v << 6) | ord); tok[q + 1] = (uint16_t)(pos_base + lane); }
         else tok[q] = (uint16_t)(pos_base + lane);
       }
-      pos += 2 + per * cnt;
+      GTOK_TOK_ORDER();
+      tokp += 2 + per * cnt;
     };
-    // first visit of v after a trail step from `pred`: [edge ref] position [type] leave in ONE store
-    auto step_to = [&](int v, int pred) {
-      if (lane == nvis) ord = v;
-      vis |= 1ull << v;
-      if (LAB) {
-        int t = __builtin_amdgcn_readlane(nat, v);
-        t = is1 ? pos_base + nvis : t;
-        t = is0 ? (kEdgeRef | (pred << 6) | v) : t;
-        if (lane < 3) tokl[pos] = (uint16_t)t;
-        pos += 3;
-      } else {
-        if (is0) tokl[pos] = (uint16_t)(pos_base + nvis);
-        pos += 1;
-      }
-      ++nvis;
-      // uncovered edges back to visited nodes (v included: self loop), minus the trail edge just taken
-      const uint64_t A = readlane64(adj, v) & vis & ~(1ull << pred);
-      if (A) bracket(v, A);
-    };
-    // first visit of v as a start / restart node (no incoming trail edge)
+    // first visit of v as a start / restart node (no incoming trail edge): position [type]
     auto start_at = [&](int v) {
-      if (lane == nvis) ord = v;
-      vis |= 1ull << v;
-      if (LAB) {
-        int t = __builtin_amdgcn_readlane(nat, v);
-        t = is0 ? pos_base + nvis : t;
-        if (lane < 2) tokl[pos] = (uint16_t)t;
-        pos += 2;
-      } else {
-        if (is0) tokl[pos] = (uint16_t)(pos_base + nvis);
-        pos += 1;
-      }
-      ++nvis;
-      const uint64_t A = readlane64(adj, v) & vis;
+      ord = (lane == vnv) ? v : ord;
+      const uint64_t bv = 1ull << v;
+      vis |= bv;
+      int t = LAB ? __builtin_amdgcn_readlane(nat, v) : vptok;
+      t = is0 ? vptok : t;
+      *tokp = (uint16_t)t;
+      GTOK_TOK_ORDER();
+      tokp += per;
+      vptok += 1; vnv += 1;
+      const uint64_t A = readlane64(adj, v) & vis;   // only a self loop can be in there
       if (A) bracket(v, A);
+      cur = v; bcur = bv; vcur6 = ((vz + v) << 6) | kEdgeRef;
     };
 
     if (is0) tok[0] = GTOK_SENT_SOS;   // SOS -> <bos>: 0 either way
     if (n > 0) {
-      int cur = (int)below((uint32_t)n);
-      start_at(cur);
-      while (NOLIM || pos < lim) {
-        const uint64_t row = readlane64(adj, cur) & ~vis;
-        if (row) {  // extend the trail over an uncovered edge (always towards an unvisited node)
+      start_at((int)below((uint32_t)n));
+      for (;;) {
+        // extend the trail while the current node has an uncovered edge (it always leads to an unvisited node)
+        uint64_t row = readlane64(adj, cur) & ~vis;
+        while (row) {
+          if (!NOLIM) {
+            const int pos = (int)(__builtin_amdgcn_readfirstlane((int)(uintptr_t)tokp) - (int)(uintptr_t)tok) >> 1;
+            if (pos >= lim) break;
+          }
           const int nxt = kth_bit_reg(row, (int)below((uint32_t)__popcll(row)));
-          step_to(nxt, cur);
-          cur = nxt;
-          continue;
+          ord = (lane == vnv) ? nxt : ord;
+          const uint64_t bn = 1ull << nxt;
+          vis |= bn;
+          if (LAB) {   // [edge ref] position type in ONE store from lanes 0..2
+            int t = __builtin_amdgcn_readlane(nat, nxt);
+            t = is1 ? vptok : t;
+            t = is0 ? (vcur6 | nxt) : t;
+            *tokp = (uint16_t)t;
+            GTOK_TOK_ORDER();
+            tokp += 3;
+          } else {
+            *tokp = (uint16_t)vptok;
+            GTOK_TOK_ORDER();
+            tokp += 1;
+          }
+          vptok += 1; vnv += 1;
+          // uncovered edges back to visited nodes (nxt included: self loop), minus the trail edge just taken
+          const uint64_t adjn = readlane64(adj, nxt);
+          const uint64_t A = adjn & vis & ~bcur;
+          if (A) bracket(nxt, A);
+          cur = nxt; bcur = bn; vcur6 = ((vz + nxt) << 6) | kEdgeRef;
+          row = adjn & ~vis;
+        }
+        if (!NOLIM) {
+          const int pos = (int)(__builtin_amdgcn_readfirstlane((int)(uintptr_t)tokp) - (int)(uintptr_t)tok) >> 1;
+          if (pos >= lim) break;
         }
         // dead end: visited nodes that still own uncovered edges
         const uint64_t live = (uint64_t)__ballot((adj & ~vis) != 0) & vis;
+        const int nv = __popcll(vis);
         if (live) {
-          cur = kth_bit_reg(live, (int)below((uint32_t)__popcll(live)));
-          const int k = __ffsll((unsigned long long)__ballot(lane < nvis && ord == cur)) - 1;   // its visit index
-          if (lane < 2) tokl[pos] = (uint16_t)(is0 ? T_RESET : pos_base + k);
-          pos += 2;
+          const int c = kth_bit_reg(live, (int)below((uint32_t)__popcll(live)));
+          const int k = __builtin_ctzll((uint64_t)__ballot(lane < nv && ord == c));   // its visit index
+          *tokp = (uint16_t)(is0 ? T_RESET : pos_base + k);
+          GTOK_TOK_ORDER();
+          tokp += 2;
+          cur = c; bcur = 1ull << c; vcur6 = ((vz + c) << 6) | kEdgeRef;
           continue;
         }
-        if (nvis < n) {  // another component or an isolated node
+        if (nv < n) {  // another component or an isolated node
           const uint64_t un = ~vis & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
-          cur = kth_bit_reg(un, (int)below((uint32_t)(n - nvis)));
-          if (is0) tok[pos] = (uint16_t)T_RESET;
-          pos += 1;
-          start_at(cur);
+          const int c = kth_bit_reg(un, (int)below((uint32_t)(n - nv)));
+          *tokp = (uint16_t)T_RESET;
+          GTOK_TOK_ORDER();
+          tokp += 1;
+          start_at(c);
           continue;
         }
         break;
       }
     }
-    if (is0) tok[pos] = (uint16_t)T_EOS;
-    pos += 1;
+    *tokp = (uint16_t)T_EOS;
+    GTOK_TOK_ORDER();
+    const int pos = ((int)(__builtin_amdgcn_readfirstlane((int)(uintptr_t)tokp) - (int)(uintptr_t)tok) >> 1) + 1;
+#undef GTOK_TOK_ORDER
 
     // ---- row out: resolve edge-type placeholders, append the query, pad
     const int ltrail = min(pos, lim);
