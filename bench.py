@@ -30,6 +30,9 @@ ZINC_FULL_GRAPHS = 249456      # 220,011 / 24,445 / 5,000 (SURVEY.md §8d config
 WORKLOADS = {
     "zinc_full": dict(graphs=ZINC_FULL_GRAPHS, desc="AGTT labelled SENT + fused ZINC remap, ZINC-full-shaped synthetic molecules"),
     "zinc_subset": dict(graphs=12000, desc="AGTT labelled SENT + fused ZINC remap, ZINC-subset-shaped synthetic molecules"),
+    # BASELINE config 5 shape (graph_generator.sh families, 10..256 nodes, sparsity 0.1-0.2, max_len 600); the
+    # default per-GPU count is 1/16 of the 125k a rank would hold of the 1M corpus, to keep generation short
+    "synth_er": dict(graphs=8192, desc="AGTT unlabelled SENT, Erdos-Renyi graph-token-shaped graphs, 10-256 nodes, max_len 600"),
 }
 
 
@@ -70,7 +73,7 @@ def main():
     ap.add_argument("--graphs", type=int, default=None, help="graphs per rank (default: the workload's size)")
     ap.add_argument("--ld", default="tight", choices=["tight", "safe"],
                     help="slab width: measured max length + margin (verified after the run) or the a-priori bound")
-    ap.add_argument("--cpu-sample", type=int, default=100000, help="graphs in the cpu_baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="graphs in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ibtt", action="store_true")
     args = ap.parse_args()
@@ -89,20 +92,25 @@ def main():
 
     wl = WORKLOADS[args.workload]
     G = args.graphs or wl["graphs"]
-    max_len, ntypes, etypes = 1024, 9, 4
+    zinc = args.workload.startswith("zinc")
+    max_len, ntypes, etypes = (1024, 9, 4) if zinc else (600, 0, 0)
     t_gen = time.perf_counter()
-    d = gtok.synth.zinc_like(G, seed=1000 + rank)
-    host = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+    if zinc:
+        d = gtok.synth.zinc_like(G, seed=1000 + rank)
+        host = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+    else:
+        d = gtok.synth.er_batch_device(G, dev, seed=1000 + rank)
+        host = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"])
     batch = host.to(dev)
     torch.cuda.synchronize()
     log(f"[bench] rank corpus: {G} graphs, {host.num_nodes_total} nodes, {host.num_edges_total} CSR entries "
         f"({time.perf_counter() - t_gen:.1f}s to generate + upload)")
     max_nodes = gtok.dist.all_reduce_max_int(host.max_nodes, dev)   # tokenizer.set_num_nodes (train_agtt.py:534)
     graph_base = rank * G
-    kw = dict(labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True, graph_base=graph_base)
+    kw = dict(labeled=zinc, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=zinc, graph_base=graph_base)
 
     # slab width
-    safe_ld = gtok.ops.sent_safe_ld(batch, True, max_len)
+    safe_ld = gtok.ops.sent_safe_ld(batch, zinc, max_len)
     if args.ld == "tight":
         _, ln0 = gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=0, ld=safe_ld, **kw)
         ld = min(safe_ld, (int(ln0.max().item()) * 5 // 4 + 8 + 3) // 4 * 4)
@@ -135,7 +143,7 @@ def main():
     tokens_per_sec = float(tok_total.item()) / wall
 
     # roofline of the dominant kernel (sent_kernel<1,true>): algorithmic bytes / launch duration
-    read_b = host.algorithmic_read_bytes(ibtt=False, labeled=True)
+    read_b = host.algorithmic_read_bytes(ibtt=False, labeled=zinc)
     write_b = 4.0 * tokens_per_step_rank + 4.0 * G
     kern_s = float(np.mean(kern_ms)) * 1e-3
     achieved = (read_b + write_b) / kern_s / 1e9
@@ -145,7 +153,8 @@ def main():
         rec = json.load(open(tpath)).get(f"sent:{args.workload}:{G}:{args.ld}")
         if rec:
             traffic = rec["hbm_bytes_per_launch"]
-    roofline = dict(bound="hbm", kernel="sent_kernel<W=1,labelled>", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+    kname = "sent_reg_kernel<labelled>" if zinc else f"sent_kernel<W={-(-host.max_nodes // 64)},unlabelled>"
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     algorithmic_bytes_per_launch=int(read_b + write_b), kernel_ms=round(kern_s * 1e3, 4),
                     padded_slab_bytes_per_launch=int(4 * G * ld))
@@ -159,27 +168,45 @@ def main():
                            parallelism=f"graph-sharded x{world}, no data-path collective"),
                roofline=roofline)
 
-    # IBTT molecular serialiser on the same corpus (second half of the metric; outside the timed region)
+    # IBTT serialiser on the same corpus (second half of the metric; outside the timed region)
     if not args.no_ibtt:
-        vocab = {t: i for i, t in enumerate(
-            ["<bos>", "<eos>", "<pad>", "<unk>", "<q>", "<p>", "<atom>", "<bond>", "C", "N", "O", "F", "P", "S", "Cl",
-             "Br", "I", "single", "double", "triple", "aromatic", "regression"]
-            + [str(i) for i in range(max_nodes)] + ["X", "unknown"])}
-        lut = gtok.ops.zinc_lut(vocab, max_nodes).to(dev)
-        ild = (min(max_len, 4 + 2 * host.max_nodes + 4 * host.max_edges) + 3) // 4 * 4
+        if zinc:
+            vocab = {t: i for i, t in enumerate(
+                ["<bos>", "<eos>", "<pad>", "<unk>", "<q>", "<p>", "<atom>", "<bond>", "C", "N", "O", "F", "P", "S", "Cl",
+                 "Br", "I", "single", "double", "triple", "aromatic", "regression"]
+                + [str(i) for i in range(max_nodes)] + ["X", "unknown"])}
+            lut = gtok.ops.zinc_lut(vocab, max_nodes).to(dev)
+            _, l0 = gtok.ops.ibtt_zinc(batch, lut, max_len, vocab["<pad>"])
+            ild = (int(l0.max().item()) + 3) // 4 * 4                      # lengths are deterministic: exact width
+            run = lambda out: gtok.ops.ibtt_zinc(batch, lut, max_len, vocab["<pad>"], ld=ild, out=out)
+            ibtt_read = host.algorithmic_read_bytes(ibtt=True, labeled=True)
+        else:
+            vocab = {t: i for i, t in enumerate(["<pad>", "<bos>", "<e>", "<n>", "<q>", "<p>", "<eos>", "yes", "no", "has_cycle"]
+                                                + [str(i) for i in range(max_nodes)])}
+            lut = gtok.ops.synth_lut(vocab, max_nodes).to(dev)
+            q = torch.zeros((G, 4), dtype=torch.int32, device=dev); q[:, 0] = 1; q[:, 1] = vocab["has_cycle"]
+            _, l0 = gtok.ops.ibtt_synth(batch, lut, q, max_len, vocab["<pad>"])
+            ild = (int(l0.max().item()) + 3) // 4 * 4
+            run = lambda out: gtok.ops.ibtt_synth(batch, lut, q, max_len, vocab["<pad>"], ld=ild, out=out)
+            # the serialiser stops reading edges once max_len tokens are out: 4(N+1) rowptr + 4*min(E, max_len/3) col
+            ecap = torch.clamp(torch.from_numpy(d["edge_counts"]), max=(max_len + 2) // 3)
+            ibtt_read = 4 * (host.num_nodes_total + G) + 4 * int(ecap.sum())
         iids = torch.empty((G, ild), dtype=torch.int32, device=dev)
         iln = torch.empty((G,), dtype=torch.int32, device=dev)
-        f = lambda k: gtok.ops.ibtt_zinc(batch, lut, max_len, vocab["<pad>"], ld=ild, out=(iids, iln))
+        f = lambda k: run((iids, iln))
         for _ in range(args.warmup):
             f(0)
         iwall, ik_ms = timed_loop(f, args.steps, world)
         itok = float(iln.sum().item())
-        ib = host.algorithmic_read_bytes(ibtt=True, labeled=True) + 4.0 * itok + 4.0 * G
+        ib = ibtt_read + 4.0 * itok + 4.0 * G
         ik = float(np.mean(ik_ms)) * 1e-3
-        out["ibtt"] = dict(graphs_per_sec_per_gpu=round(G * args.steps / iwall, 1),
+        out["ibtt"] = dict(kernel="ibtt_zinc_kernel" if zinc else "ibtt_synth_kernel",
+                           graphs_per_sec_per_gpu=round(G * args.steps / iwall, 1),
                            tokens_per_sec_per_gpu=round(itok * args.steps / iwall, 1), kernel_ms=round(ik * 1e3, 4),
-                           slab_width=ild, roofline=dict(bound="hbm", achieved=round(ib / ik / 1e9, 2), peak=HBM_PEAK_GBS,
-                                                         unit="GB/s", frac=round(ib / ik / 1e9 / HBM_PEAK_GBS, 5)))
+                           slab_width=ild, avg_tokens_per_graph=round(itok / G, 2),
+                           roofline=dict(bound="hbm", achieved=round(ib / ik / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                         frac=round(ib / ik / 1e9 / HBM_PEAK_GBS, 5), algorithmic_bytes_per_launch=int(ib),
+                                         padded_slab_bytes_per_launch=int(4 * G * ild)))
 
     # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
     if world > 1:
@@ -201,12 +228,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as orc
-        S = min(G, args.cpu_sample)
+        S = min(G, args.cpu_sample or (100000 if zinc else 4096))
+        sl = lambda k, hi: None if k not in d else d[k][:hi]
         coo = orc.Coo(d["node_counts"][:S], d["edge_counts"][:S], d["src"][:int(host.edge_ptr[S])],
-                      d["dst"][:int(host.edge_ptr[S])], d["x"][:int(host.node_ptr[S])],
-                      d["edge_attr"][:int(host.edge_ptr[S])])
+                      d["dst"][:int(host.edge_ptr[S])], sl("x", int(host.node_ptr[S])) if zinc else None,
+                      sl("edge_attr", int(host.edge_ptr[S])) if zinc else None)
         cores = orc.num_threads()
-        okw = dict(labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True, ld=ld, nthreads=cores)
+        okw = dict(labeled=zinc, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=zinc, ld=ld, nthreads=cores)
         orc.sent(coo.slice(0, min(S, 2000)), max_nodes, max_len, 0, 0, **okw)
         reps, t0 = 0, time.perf_counter()
         while reps < 3 or time.perf_counter() - t0 < 10.0:

@@ -121,4 +121,28 @@ __device__ __forceinline__ void write_row(int32_t *__restrict__ row, int ld, int
   }
 }
 
+
+// Same, for a row staged as uint16 tokens in LDS (8-byte aligned): 4 tokens per ds_read_b64, f(token, i) maps
+// a staged token to its final id.  Reads stay below lw rounded up to 4 (the staging buffer has that slack).
+template <typename F>
+__device__ __forceinline__ void write_row_tok16(int32_t *__restrict__ row, int ld, int lw, int pad,
+                                                const uint16_t *tok, F f) {
+  const int lane = lane_id();
+  if (((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0)) {
+    for (int i = lane * 4; i < ld; i += kWave * 4) {
+      int4 o = make_int4(pad, pad, pad, pad);
+      if (i < lw) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(tok + i);
+        o.x = f((int)(w.x & 0xFFFFu), i);
+        o.y = i + 1 < lw ? f((int)(w.x >> 16), i + 1) : pad;
+        o.z = i + 2 < lw ? f((int)(w.y & 0xFFFFu), i + 2) : pad;
+        o.w = i + 3 < lw ? f((int)(w.y >> 16), i + 3) : pad;
+      }
+      *reinterpret_cast<int4 *>(row + i) = o;
+    }
+  } else {
+    for (int i = lane; i < ld; i += kWave) row[i] = (i < lw) ? f((int)tok[i], i) : pad;
+  }
+}
+
 }  // namespace gtok

@@ -1,0 +1,285 @@
+// gtok_sent_lds.hpp — SENT walk for graphs of up to 64*W nodes (W = 1, 2, 4, 8): the adjacency lives in LDS as
+// an IMMUTABLE bit matrix adj[n][W]; the only walk state is the visited set, W 64-bit words in SGPRs, because
+// for a visited node c the uncovered edges are exactly adj[c] & ~vis, and a new node's neighbourhood bracket is
+// adj[v] & vis minus the trail edge just taken.  Decisions come from a register-resident,
+// decision-major Philox block (64 decisions per refill); tokens go to an LDS row with unpredicated, ordered
+// all-lane stores (lane j -> slot pos+j, junk beyond the step's tokens is overwritten by later steps).
+// Same spec and token stream as sent_reg_kernel; bit-exact checker oracle/gtok_oracle.c:oracle_sent.
+#pragma once
+#include "gtok_sent_reg.hpp"
+
+namespace gtok {
+
+template <int W, bool LAB>
+__global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
+  unsigned char *base = smem + (size_t)wave * a.l.stride;
+  uint64_t *adj = reinterpret_cast<uint64_t *>(base + a.l.adj);
+  uint16_t *order = reinterpret_cast<uint16_t *>(base + a.l.order);
+  uint16_t *tok = reinterpret_cast<uint16_t *>(base + a.l.tok);
+  uint16_t *colL = reinterpret_cast<uint16_t *>(base + a.l.col);
+  int32_t *rp = reinterpret_cast<int32_t *>(base + a.l.rp);     // labelled only
+  uint8_t *eatL = base + a.l.eat;                                // labelled only
+  uint8_t *natL = base + a.l.nat;                                // labelled only
+
+  const int lim = a.p.max_len;
+  const int idx_off = GTOK_SENT_IDX_OFFSET;
+  const int node_off = idx_off + a.p.max_num_nodes;
+  const int edge_off = node_off + a.p.num_node_types;
+  const uint32_t k0 = (uint32_t)a.p.seed, k1 = (uint32_t)(a.p.seed >> 32), epoch = (uint32_t)a.p.epoch;
+  const bool remap = a.p.remap_zinc != 0;
+  constexpr int per = LAB ? 2 : 1;
+  const bool is0 = lane == 0, is1 = lane == 1;
+#define GTOK_TOK_ORDER() asm volatile("" ::: "memory")
+
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * wpb + wave;
+    if (g >= a.g.num_graphs) break;
+    const int nb0 = sload(a.g.node_ptr, g);
+    const int nfull = sload(a.g.node_ptr, g + 1) - nb0;
+    const int n = min(nfull, a.maxn);
+    const int64_t e0 = sload(a.g.edge_ptr, g);
+    const int e = min((int)(sload(a.g.edge_ptr, g + 1) - e0), a.g.max_edges);
+    const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
+    const int32_t *__restrict__ colg = a.g.col + e0;
+    const uint64_t gid = (uint64_t)(a.p.graph_base + g);
+    const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
+
+    // ---- stage (coalesced) and build the symmetric closure
+    for (int i = lane; i < n * W; i += kWave) adj[i] = 0;
+    if (LAB) {   // labelled walks look edge types up in the neighbour lists: stage them (coalesced)
+      for (int i = lane; i < e; i += kWave) {
+        colL[i] = (uint16_t)colg[i];
+        eatL[i] = a.g.eattr[e0 + i];
+      }
+      for (int i = lane; i <= n; i += kWave) rp[i] = rpg[i];
+      for (int i = lane; i < n; i += kWave) natL[i] = a.g.nattr[nb0 + i];
+    }
+    auto draws = [&](int d0) -> uint32_t {   // lane j: word of decision d0 + j
+      uint32_t o[4];
+      philox4x32_10((uint32_t)((d0 + lane) >> 2), epoch, gid_lo, gid_hi, k0, k1, o);
+      const int w = lane & 3;
+      uint32_t x = o[3];
+      x = w == 2 ? o[2] : x;
+      x = w == 1 ? o[1] : x;
+      x = w == 0 ? o[0] : x;
+      return x;
+    };
+    uint32_t R = draws(0);
+    wave_sync();
+    for (int u = lane; u < n; u += kWave) {
+      const int rs = rpg[u], re = rpg[u + 1];
+      for (int k0e = rs; k0e < re; k0e += 4) {   // 4 neighbour reads in flight per round trip
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = LAB ? (int)colL[min(k0e + j, re - 1)] : colg[min(k0e + j, re - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (k0e + j < re && (unsigned)v[j] < (unsigned)n) {
+            atomicOr(reinterpret_cast<unsigned long long *>(&adj[u * W + (v[j] >> 6)]), 1ull << (v[j] & 63));
+            atomicOr(reinterpret_cast<unsigned long long *>(&adj[v[j] * W + (u >> 6)]), 1ull << (u & 63));
+          }
+        }
+      }
+    }
+    wave_sync();
+
+    // ---- walk
+    uint64_t vis[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) vis[w] = 0;
+    int pos = 1, d = 0, nvis = 0, cur = 0;
+
+    auto below = [&](uint32_t nchoices) -> uint32_t {
+      const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)R, d & 63);
+      ++d;
+      if ((d & 63) == 0) {
+        int d0 = d;
+        asm volatile("" : "+s"(d0));
+        R = draws(d0);
+      }
+      return __umulhi(x, nchoices);
+    };
+    auto fetch_row = [&](int v, uint64_t (&r)[W]) {   // lanes 0..W-1 read one word each, then to SGPRs
+      const uint64_t mine = adj[v * W + (lane < W ? lane : 0)];
+#pragma unroll
+      for (int w = 0; w < W; ++w) r[w] = readlane64(mine, w);
+    };
+    auto pick = [&](const uint64_t (&m)[W], int k) -> int {   // k-th set bit across the W words
+      int res = 0;
+      bool done = false;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const int c = __popcll(m[w]);
+        if (!done) {
+          if (k < c) { res = w * 64 + kth_bit_reg(m[w], k); done = true; }
+          else k -= c;
+        }
+      }
+      return res;
+    };
+    // edge type of (x,y), both wave-uniform: first listed entry x->y, else first y->x
+    auto etype_uniform = [&](int x, int y) -> int {
+      for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass ? y : x, c = pass ? x : y;
+        const int rs = rp[r], re = rp[r + 1];
+        for (int b0 = rs; b0 < re; b0 += kWave) {
+          const int k = b0 + lane;
+          const uint64_t m = __ballot((k < re) && (colL[k] == (uint16_t)c));
+          if (m) return eatL[b0 + __builtin_ctzll(m)];
+        }
+      }
+      return 0;
+    };
+    auto etype_lane = [&](int x, int y) -> int {   // x uniform, y per lane
+      for (int k = rp[x], ke = rp[x + 1]; k < ke; ++k)
+        if (colL[k] == (uint16_t)y) return eatL[k];
+      for (int k = rp[y], ke = rp[y + 1]; k < ke; ++k)
+        if (colL[k] == (uint16_t)x) return eatL[k];
+      return 0;
+    };
+    // first visit of v; pred >= 0: reached over the trail edge (pred, v)
+    auto visit = [&](int v, int pred) {
+      if (is0) order[nvis] = (uint16_t)v;
+#pragma unroll
+      for (int w = 0; w < W; ++w) vis[w] |= (w == (v >> 6)) ? (1ull << (v & 63)) : 0ull;
+      if (LAB) {
+        const int ty = node_off + natL[v];
+        if (pred >= 0) {
+          const int et = edge_off + etype_uniform(pred, v);
+          int t = ty;
+          t = is1 ? idx_off + nvis : t;
+          t = is0 ? et : t;
+          tok[pos + lane] = (uint16_t)t;
+          GTOK_TOK_ORDER();
+          pos += 3;
+        } else {
+          tok[pos + lane] = (uint16_t)(is0 ? idx_off + nvis : ty);
+          GTOK_TOK_ORDER();
+          pos += 2;
+        }
+      } else {
+        tok[pos + lane] = (uint16_t)(idx_off + nvis);
+        GTOK_TOK_ORDER();
+        pos += 1;
+      }
+      ++nvis;
+      uint64_t r[W];
+      fetch_row(v, r);
+      bool any = false;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        uint64_t aw = r[w] & vis[w];
+        if (pred >= 0 && w == (pred >> 6)) aw &= ~(1ull << (pred & 63));
+        any |= aw != 0;
+      }
+      if (!any) return;
+      wave_sync();   // order[] written by lane 0 is read by every lane below
+      int cnt = 0;
+      for (int b0 = 0; b0 < nvis; b0 += kWave) {   // lane = visit index: members in ascending visit order
+        const int k = b0 + lane;
+        int nb = 0;
+        bool member = false;
+        if (k < nvis) {
+          nb = order[k];
+          member = ((adj[v * W + (nb >> 6)] >> (nb & 63)) & 1ull) && nb != pred;
+        }
+        const uint64_t M = __ballot(member);
+        if (member) {
+          const int q = pos + 1 + per * (cnt + mbcnt64(M));
+          if (LAB) { tok[q] = (uint16_t)(edge_off + etype_lane(v, nb)); tok[q + 1] = (uint16_t)(idx_off + k); }
+          else tok[q] = (uint16_t)(idx_off + k);
+        }
+        cnt += __popcll(M);
+      }
+      if (is0) { tok[pos] = GTOK_SENT_LADJ; tok[pos + 1 + per * cnt] = GTOK_SENT_RADJ; }
+      GTOK_TOK_ORDER();
+      pos += 2 + per * cnt;
+    };
+
+    if (is0) tok[0] = GTOK_SENT_SOS;
+    if (n > 0) {
+      cur = (int)below((uint32_t)n);
+      visit(cur, -1);
+      while (pos < lim) {
+        uint64_t m[W];
+        fetch_row(cur, m);
+        int cnt = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) { m[w] &= ~vis[w]; cnt += __popcll(m[w]); }
+        if (cnt) {   // extend the trail over an uncovered edge (always towards an unvisited node)
+          const int nxt = pick(m, (int)below((uint32_t)cnt));
+          visit(nxt, cur);
+          cur = nxt;
+          continue;
+        }
+        // dead end: visited nodes that still own uncovered edges
+        int total = 0;
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const int v = c * 64 + lane;
+          uint64_t anyw = 0;
+          if (v < n) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) anyw |= adj[v * W + w] & ~vis[w];
+          }
+          m[c] = (c * 64 < n) ? ((uint64_t)__ballot(anyw != 0) & vis[c]) : 0ull;
+          total += __popcll(m[c]);
+        }
+        if (total) {
+          cur = pick(m, (int)below((uint32_t)total));
+          wave_sync();
+          int kidx = 0;
+          for (int b0 = 0; b0 < nvis; b0 += kWave) {   // its visit index
+            const uint64_t hit = __ballot(b0 + lane < nvis && order[b0 + lane] == (uint16_t)cur);
+            if (hit) { kidx = b0 + __builtin_ctzll(hit); break; }
+          }
+          tok[pos + lane] = (uint16_t)(is0 ? GTOK_SENT_RESET : idx_off + kidx);
+          GTOK_TOK_ORDER();
+          pos += 2;
+          continue;
+        }
+        if (nvis < n) {  // another component or an isolated node
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            const int rem = n - w * 64;
+            const uint64_t valid = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
+            m[w] = ~vis[w] & valid;
+          }
+          cur = pick(m, (int)below((uint32_t)(n - nvis)));
+          tok[pos + lane] = (uint16_t)GTOK_SENT_RESET;
+          GTOK_TOK_ORDER();
+          pos += 1;
+          visit(cur, -1);
+          continue;
+        }
+        break;
+      }
+    }
+    tok[pos + lane] = (uint16_t)GTOK_SENT_EOS;
+    GTOK_TOK_ORDER();
+    pos += 1;
+
+    // ---- row out
+    const int ltrail = min(pos, lim);
+    int len = ltrail;
+    if (a.p.query) {  // trainer/train_agtt.py:257-267: after the trail, original node ids, not remapped
+      if (lane < 3)
+        tok[ltrail + lane] = (uint16_t)(idx_off + (lane == 0 ? nfull : a.p.query[2 * (int64_t)g + lane - 1]));
+      len = ltrail + 3;
+    }
+    wave_sync();
+    write_row_tok16(a.out + (int64_t)g * a.ld, a.ld, min(len, a.ld), a.p.pad_id, tok, [=](int t, int i) -> int {
+      return (remap && i < ltrail) ? remap_zinc_token(t, idx_off, node_off, edge_off) : t;
+    });
+    if (is0) a.out_len[g] = len;
+    wave_sync();
+  }
+#undef GTOK_TOK_ORDER
+}
+
+}  // namespace gtok

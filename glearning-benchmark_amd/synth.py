@@ -169,3 +169,27 @@ def er_batch(num_graphs: int, seed: int = 0, min_nodes: int = 10, max_nodes: int
             srcs.append(iu[sel][keep]); dsts.append(iv[sel][keep]); ecs[c0 + j] = int(keep.sum())
     cat = lambda l: np.concatenate(l).astype(np.int64) if l else np.zeros(0, np.int64)
     return dict(node_counts=n, edge_counts=ecs, src=cat(srcs), dst=cat(dsts))
+
+
+def er_batch_device(num_graphs: int, device, seed: int = 0, min_nodes: int = 10, max_nodes: int = 256,
+                    min_sparsity: float = 0.1, max_sparsity: float = 0.2, chunk: int = 512) -> Dict[str, np.ndarray]:
+    """Same corpus family as er_batch(), sampled on the GPU with torch (bench.py's large-graph workload:
+    the host loop would take minutes at 10^5 graphs).  Returns host numpy batched COO, u<v, row-sorted."""
+    import torch
+    gen = torch.Generator(device=device); gen.manual_seed(seed)
+    n = torch.randint(min_nodes, max_nodes + 1, (num_graphs,), generator=gen, device=device)
+    p = torch.rand((num_graphs,), generator=gen, device=device) * (max_sparsity - min_sparsity) + min_sparsity
+    M = max_nodes
+    iu = torch.arange(M, device=device)
+    upper = iu[None, :] > iu[:, None]
+    srcs, dsts, counts = [], [], []
+    for c0 in range(0, num_graphs, chunk):
+        nn, pp = n[c0:c0 + chunk], p[c0:c0 + chunk]
+        keep = torch.rand((nn.numel(), M, M), generator=gen, device=device) < pp[:, None, None]
+        keep &= upper[None] & (iu[None, None, :] < nn[:, None, None])
+        g, u, v = keep.nonzero(as_tuple=True)          # sorted by (g, u, v)
+        counts.append(torch.bincount(g, minlength=nn.numel()))
+        srcs.append(u.to(torch.int32)); dsts.append(v.to(torch.int32))
+    cat = lambda l: torch.cat(l).cpu().numpy()
+    return dict(node_counts=n.cpu().numpy().astype(np.int64), edge_counts=cat(counts).astype(np.int64),
+                src=cat(srcs).astype(np.int64), dst=cat(dsts).astype(np.int64))
