@@ -61,10 +61,11 @@ class GraphBatch:
         return self.node_ptr[1:] - self.node_ptr[:-1]
 
     def algorithmic_read_bytes(self, ibtt: bool, labeled: bool) -> int:
-        """4(N+1) rowptr + 4E col (+4E order ids, IBTT) + N + E attrs (labelled)."""
+        """4(N+1) rowptr + 4E col (+4E order ids: IBTT, only when the batch stores them —
+        a row-sorted edge_index needs none) + N + E attrs (labelled)."""
         n, e, g = self.num_nodes_total, self.num_edges_total, self.num_graphs
         b = 4 * (n + g) + 4 * e
-        if ibtt:
+        if ibtt and self.eorder is not None:
             b += 4 * e
         if labeled:
             b += n + e

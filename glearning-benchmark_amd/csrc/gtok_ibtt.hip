@@ -10,6 +10,7 @@
 // stores.  Bit-exact checkers: oracle/gtok_oracle.c.
 #include "gtok_common.hpp"
 #include "gtok.h"
+#include "gtok_sent_reg.hpp"   // sload(): scalar loads of the graph pointers
 
 namespace gtok {
 
@@ -52,32 +53,76 @@ __global__ void __launch_bounds__(256) ibtt_zinc_kernel(const ZincArgs a) {
   int32_t *tok = reinterpret_cast<int32_t *>(base + a.l.tok);
   const int32_t *__restrict__ lut = a.lut;
   const int pad = a.pad_id, tcap = a.tcap;
+  const bool has_order = a.g.eorder != nullptr, has_ea = a.g.eattr != nullptr, has_na = a.g.nattr != nullptr;
 
   auto put = [&](int q, int v) { if (q < tcap) tok[q] = v; };
   auto node_id = [&](int i) { return (GTOK_ZLUT_NODE0 + i < a.lut_len) ? lut[GTOK_ZLUT_NODE0 + i] : pad; };
 
+  // Software pipeline (the kernel is latency-bound: ~570 instructions per molecule behind four dependent
+  // memory round trips): scalar pointers of graph i+2 and the per-lane head of graph i+1 — first 64 row
+  // pointers / node types, first 128 entries — are requested before graph i is serialised.
+  struct Ptrs { int n0, n1; int64_t e0, e1; };
+  struct Data { int rp, x, c0, c1, p0, p1, a0, a1; };
+  auto load_ptrs = [&](int g) -> Ptrs {
+    Ptrs p;
+    p.n0 = sload(a.g.node_ptr, g); p.n1 = sload(a.g.node_ptr, g + 1);
+    p.e0 = sload(a.g.edge_ptr, g); p.e1 = sload(a.g.edge_ptr, g + 1);
+    return p;
+  };
+  auto load_data = [&](int g, const Ptrs &p) -> Data {
+    Data q = {0, 255, 0, 0, 0, 0, 0, 0};
+    const int pn = p.n1 - p.n0, pe = (int)(p.e1 - p.e0);
+    if (lane <= pn) q.rp = a.g.rowptr[p.n0 + g + lane];
+    if (has_na && lane < pn) q.x = a.g.nattr[p.n0 + lane];
+    if (lane < pe) {
+      q.c0 = a.g.col[p.e0 + lane];
+      q.p0 = has_order ? a.g.eorder[p.e0 + lane] : lane;
+      if (has_ea) q.a0 = a.g.eattr[p.e0 + lane];
+    }
+    if (lane + 64 < pe) {
+      q.c1 = a.g.col[p.e0 + lane + 64];
+      q.p1 = has_order ? a.g.eorder[p.e0 + lane + 64] : lane + 64;
+      if (has_ea) q.a1 = a.g.eattr[p.e0 + lane + 64];
+    }
+    return q;
+  };
+
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
-  for (int unit = u0; unit < u1; ++unit) {
-    const int g = unit * wpb + wave;
-    if (g >= a.g.num_graphs) break;
-    const int nb0 = a.g.node_ptr[g];
-    const int n = min(a.g.node_ptr[g + 1] - nb0, a.maxn);
-    const int64_t e0 = a.g.edge_ptr[g];
-    const int e = min((int)(a.g.edge_ptr[g + 1] - e0), a.maxe);
+  const int G = a.g.num_graphs;
+  int g = u0 * wpb + wave;
+  if (u0 >= u1 || g >= G) return;
+  Ptrs pc = load_ptrs(g);
+  Data dc = load_data(g, pc);
+  bool has_next = (u0 + 1 < u1) && (g + wpb < G);
+  Ptrs pn = pc;
+  if (has_next) pn = load_ptrs(g + wpb);
+  for (int unit = u0;; ++unit) {
+    Data dn = dc;
+    if (has_next) dn = load_data(g + wpb, pn);
+    const bool has_next2 = (unit + 2 < u1) && (g + 2 * wpb < G);
+    Ptrs pnn = pn;
+    if (has_next2) pnn = load_ptrs(g + 2 * wpb);
+
+    const int nb0 = pc.n0;
+    const int n = min(pc.n1 - pc.n0, a.maxn);
+    const int64_t e0 = pc.e0;
+    const int e = min((int)(pc.e1 - pc.e0), a.maxe);
     const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
 
-    for (int i = lane; i <= n; i += kWave) rp[i] = rpg[i];
+    if (lane <= n) rp[lane] = dc.rp;
+    for (int i = lane + kWave; i <= n; i += kWave) rp[i] = rpg[i];   // more than 63 nodes: the rest, not prefetched
     wave_sync();
     // CSR entry k = (u, v, attr) listed at original position p: scatter back to COO order
-    for (int k = lane; k < e; k += kWave) {
-      const int v = a.g.col[e0 + k];
-      const int p = a.g.eorder ? a.g.eorder[e0 + k] : k;
-      const int at = a.g.eattr ? a.g.eattr[e0 + k] : 0;
+    auto scatter = [&](int k, int v, int p, int at) {
       const int u = row_of(rp, n, k);
       cc[k] = (uint16_t)v; co[k] = (uint16_t)p;
       if ((unsigned)p < (unsigned)e) { ou[p] = (uint16_t)u; ov[p] = (uint16_t)v; oa[p] = (uint8_t)at; }
-    }
+    };
+    if (lane < e) scatter(lane, dc.c0, dc.p0, dc.a0);
+    if (lane + 64 < e) scatter(lane + 64, dc.c1, dc.p1, dc.a1);
+    for (int k = lane + 128; k < e; k += kWave)
+      scatter(k, a.g.col[e0 + k], has_order ? a.g.eorder[e0 + k] : k, has_ea ? a.g.eattr[e0 + k] : 0);
     wave_sync();
     // zinc_dataset_indexbase.py:176-184: keep entry p iff no earlier entry joins the same {u,v}
     int kept = 0;
@@ -103,11 +148,12 @@ __global__ void __launch_bounds__(256) ibtt_zinc_kernel(const ZincArgs a) {
       }
       kept += __popcll(m);
     }
-    for (int i = lane; i < n; i += kWave) {  // :168-169, 'X' for x outside 0..8 (:104)
-      const int x = a.g.nattr ? a.g.nattr[nb0 + i] : 255;
+    auto put_atom = [&](int i, int x) {   // :168-169, 'X' for x outside 0..8 (:104)
       put(1 + 2 * i, lut[GTOK_ZLUT_ATOM]);
       put(2 + 2 * i, lut[GTOK_ZLUT_ATOM0 + (x <= 8 ? x : 9)]);
-    }
+    };
+    if (lane < n) put_atom(lane, dc.x);
+    for (int i = lane + kWave; i < n; i += kWave) put_atom(i, has_na ? a.g.nattr[nb0 + i] : 255);
     const int64_t T = 6 + 2 * (int64_t)n + 4 * (int64_t)kept;  // text tokens incl. label and <eos>
     if (lane == 0) {
       put(0, lut[GTOK_ZLUT_BOS]);
@@ -126,6 +172,10 @@ __global__ void __launch_bounds__(256) ibtt_zinc_kernel(const ZincArgs a) {
     write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, min(a.ld, tcap)), pad, [=](int i) -> int { return tok[i]; });
     if (lane == 0) a.out_len[g] = len;
     wave_sync();
+    if (!has_next) break;
+    g += wpb;
+    pc = pn; dc = dn; pn = pnn;
+    has_next = has_next2;
   }
 }
 
