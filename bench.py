@@ -45,11 +45,11 @@ def event_ms(pairs):
     return [s.elapsed_time(e) for s, e in pairs]
 
 
-def timed_loop(fn, steps, world):
+def timed_loop(fn, steps, multi):
     """barrier + synchronize on both sides, K launches between, HIP events around every launch
     (recorded on the stream the kernels run on)."""
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -58,7 +58,7 @@ def timed_loop(fn, steps, world):
         fn(k)
         pairs[k][1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     return time.perf_counter() - t0, event_ms(pairs)
@@ -87,7 +87,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the tokenizer has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # GTOK_BENCH_FORCE_DIST=1 runs the collective legs even with one rank (rehearsal of the N>1 path on a 1-GPU box)
+    multi = world > 1 or os.environ.get("GTOK_BENCH_FORCE_DIST") == "1"
+    if multi:
         dist.init_process_group("nccl", device_id=dev)
 
     wl = WORKLOADS[args.workload]
@@ -126,9 +128,9 @@ def main():
 
     for w in range(args.warmup):
         step(w, scratch_len)
-    wall, kern_ms = timed_loop(lambda k: step(args.warmup + k, lens[k]), args.steps, world)
+    wall, kern_ms = timed_loop(lambda k: step(args.warmup + k, lens[k]), args.steps, multi)
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
 
@@ -136,7 +138,7 @@ def main():
     if int(all_len.max().item()) > ld:
         raise SystemExit(f"slab width {ld} too narrow for a timed step (max len {int(all_len.max())}): rerun with --ld safe")
     tok_total = torch.tensor([float(all_len.sum().item())], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tok_total)
     tokens_per_step_rank = float(all_len.sum().item()) / args.steps
     value = world * G * args.steps / wall
@@ -196,7 +198,7 @@ def main():
         f = lambda k: run((iids, iln))
         for _ in range(args.warmup):
             f(0)
-        iwall, ik_ms = timed_loop(f, args.steps, world)
+        iwall, ik_ms = timed_loop(f, args.steps, multi)
         itok = float(iln.sum().item())
         ib = ibtt_read + 4.0 * itok + 4.0 * G
         ik = float(np.mean(ik_ms)) * 1e-3
@@ -209,7 +211,7 @@ def main():
                                          padded_slab_bytes_per_launch=int(4 * G * ild)))
 
     # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
-    if world > 1:
+    if multi:
         gtok.dist.gather_tokens(ids, lens[-1], world * G, 5)
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
@@ -252,7 +254,7 @@ def main():
                                    tokens_per_sec=round(float(rln.sum()) / cpu_s, 1), parity_with_gpu=bool(same))
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
