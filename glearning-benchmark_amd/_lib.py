@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "csrc", "libgtok.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("gtok_sent.hip", "gtok_ibtt.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "gtok_common.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_reg.hpp"),
+HEADERS = [os.path.join(_HERE, "csrc", "gtok_common.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_reg.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_lds.hpp"),
+           os.path.join(_HERE, "csrc", "gtok_sent_lane.hpp"),
            os.path.join(_ROOT, "include", "gtok.h")]
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)

@@ -7,9 +7,11 @@
 // DESIGN.md §SENT (upstream AutoGraph parity is unpinned); the
 // bit-exact checker is oracle/gtok_oracle.c:oracle_sent.
 //
-// One wavefront per graph; two kernels, one spec:
-//   sent_reg_kernel (gtok_sent_reg.hpp)  graphs of <= 64 nodes, adjacency rows in registers (lane = node)
-//   sent_lds_kernel (gtok_sent_lds.hpp)  up to 512 nodes, immutable adjacency bit matrix in LDS
+// Three kernels, one spec:
+//   sent_lane_kernel (gtok_sent_lane.hpp) LANE per graph (64 graphs per wave): big batches of graphs with
+//                                         <= 64 nodes and <= 255 entries (every ZINC molecule)
+//   sent_reg_kernel  (gtok_sent_reg.hpp)  WAVE per graph, <= 64 nodes, adjacency rows in registers (lane = node)
+//   sent_lds_kernel  (gtok_sent_lds.hpp)  WAVE per graph, up to 512 nodes, immutable adjacency bit matrix in LDS
 // This file is the launcher: LDS layout, kernel choice, grid sizing.
 #include <cstdlib>
 
@@ -17,6 +19,7 @@
 #include "gtok.h"
 #include "gtok_sent_reg.hpp"
 #include "gtok_sent_lds.hpp"
+#include "gtok_sent_lane.hpp"
 
 namespace gtok {
 
@@ -46,7 +49,56 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   // register-resident walk for graphs of at most 64 nodes (placeholders need bit 15 of a token free);
   // GTOK_SENT_GENERIC=1 forces the LDS bit-matrix kernel (A/B runs, tests of both paths)
   const char *force = std::getenv("GTOK_SENT_GENERIC");
-  const bool reg_path = W == 1 && !(force && force[0] == '1') &&
+  // GTOK_SENT_KERNEL=lane|reg|lds pins the kernel (tests run every path).  Default: wave-per-graph; the
+  // lane-per-graph kernel is opt-in until its labelled variant beats sent_reg_kernel (see its header)
+  const char *pin = std::getenv("GTOK_SENT_KERNEL");
+  const bool lane_ok = maxn <= 64 && g->max_edges <= 255 &&
+                       22 + GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < (1 << 30) &&
+                       (!p->remap_zinc || g->max_nodes <= p->max_num_nodes);
+  bool lane_path = false;
+  if (pin && lane_ok && pin[0] == 'l' && pin[1] == 'a') lane_path = true;
+  if (pin && (pin[0] == 'r' || (pin[0] == 'l' && pin[1] == 'd'))) lane_path = false;
+  if (force && force[0] == '1') lane_path = false;
+  if (lane_path) {
+    SentArgs a;
+    a.g = *g; a.p = *p; a.cap = cap; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
+    int off = 0;
+    a.l.adj = off; off += maxn * 64 * 8;
+    a.l.rng = a.l.tok = 0;
+    // contiguous staging of the wave's CSR chunk; walk arrays (order/vidx/rem) alias it for unlabelled graphs
+    const int stage0 = off;
+    a.l.rp = off; off += align_up((maxn + 1) * 64, 16);
+    a.l.col = off; off += align_up(maxe * 64, 16);
+    a.l.eat = a.l.nat = off;
+    if (p->labeled) {
+      a.l.eat = off; off += align_up(maxe * 64, 16);
+      a.l.nat = off; off += align_up(maxn * 64, 16);
+    }
+    int walk0 = p->labeled ? off : stage0;
+    a.l.order = walk0; walk0 += maxn * 64;
+    a.l.vidx = walk0; walk0 += maxn * 64;
+    a.l.vis = walk0; walk0 += maxn * 64;                   // rem[]
+    if (walk0 > off) off = walk0;
+    a.l.stride = align_up(off, 16);
+    if (a.l.stride <= 64 * 1024) {
+      typedef void (*K)(const SentArgs);
+      K kern = p->labeled ? (K)sent_lane_kernel<true> : (K)sent_lane_kernel<false>;
+      int dev = 0, ncu = 256, occ = 1;
+      if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64,
+                                                       (size_t)a.l.stride) != hipSuccess || occ < 1)
+        occ = 1;
+      a.units = (g->num_graphs + 63) / 64;
+      int nb = ncu * occ;
+      if (nb > a.units) nb = a.units;
+      a.upb = (a.units + nb - 1) / nb;
+      nb = (a.units + a.upb - 1) / a.upb;
+      hipLaunchKernelGGL(kern, dim3(nb), dim3(64), (size_t)a.l.stride, (hipStream_t)stream, a);
+      return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+    }
+  }
+  const bool reg_path = W == 1 && !(force && force[0] == '1') && !(pin && pin[0] == 'l' && pin[1] == 'd') &&
                         22 + GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < kEdgeRef &&
                         g->max_edges <= 32768 &&
                         (!p->remap_zinc || g->max_nodes <= p->max_num_nodes);   // remap folded into constants

@@ -165,3 +165,29 @@ def test_collate():
         rX, rA, m = orc.collate(ids.cpu().numpy(), ln.cpu().numpy(), index, 2, out_ld)
         assert m == lmax and X.dtype == torch.int64 and A.dtype == torch.bool
         assert np.array_equal(X.cpu().numpy(), rX) and np.array_equal(A.cpu().numpy(), rA)
+
+
+@pytest.mark.parametrize("pin", ["lane", "reg", "lds"])
+def test_sent_every_kernel_same_tokens(pin, monkeypatch):
+    """Three kernels implement the one SENT spec (lane-per-graph, register-resident wave-per-graph, LDS bit
+    matrix); GTOK_SENT_KERNEL pins one per call.  Each must reproduce the oracle on graphs they all accept."""
+    monkeypatch.setenv("GTOK_SENT_KERNEL", pin)
+    cases = [(gtok.synth.zinc_like(3000, seed=61), True, 37, dict(remap_zinc=True, num_node_types=9, num_edge_types=4)),
+             (gtok.synth.zinc_like(800, seed=62, coalesced=False), True, 37, dict(num_node_types=28, num_edge_types=5)),
+             (gtok.synth.zinc_like(1500, seed=63), False, 40, {}),
+             (gtok.synth.graph_token_like(400, seed=64, with_text=False, algorithms=("er", "ba", "sbm", "path", "star")), False, 49, {}),
+             (edge_case_graphs(), True, 8, dict(num_node_types=28, num_edge_types=6)),
+             (edge_case_graphs(), False, 8, {})]
+    for d, labeled, nn, kw in cases:
+        batch, coo = both(d, labeled)
+        for max_len in (1024, 40):
+            ids, ln = gtok.ops.sent(batch.to(DEV), nn, max_len, 17, 5, labeled=labeled, graph_base=123, **kw)
+            ref, rln = orc.sent(coo, nn, max_len, 17, 5, labeled=labeled, graph_base=123, ld=ids.shape[1], **kw)
+            _cmp(ids, ln, ref, rln, f"sent[{pin}] labeled={labeled} max_len={max_len}")
+    # with a query tail
+    g = gtok.synth.graph_token_like(300, seed=65, task="shortest_path", with_text=False, algorithms=("er", "ba", "path"))
+    b2, c2 = both(g, False)
+    q = np.array([qq if qq is not None else (0, 0) for qq in g["queries"]], np.int32)
+    ids, ln = gtok.ops.sent(b2.to(DEV), 49, 600, 5, 2, query=torch.from_numpy(q))
+    ref, rln = orc.sent(c2, 49, 600, 5, 2, query=q, ld=ids.shape[1])
+    _cmp(ids, ln, ref, rln, f"sent[{pin}]+query")
