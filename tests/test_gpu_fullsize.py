@@ -1,0 +1,96 @@
+"""GPU, at BASELINE.json's full single-GPU sizes: the ZINC-full-shaped corpus (249,456 molecules) and a batch of
+large graph-token-shaped graphs (10-256 nodes).  The multi-threaded C oracle is fast enough to check every row
+bit for bit; on top of that the size-independent properties of the domain (determinism, new trails per epoch,
+shard invariance through the global graph index, losslessness of a sample, closed-form IBTT lengths)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import both, gtok, orc, zinc_vocab
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ZINC_FULL = 249456
+THREADS = max(1, min(16, orc.num_threads()))
+
+
+@pytest.fixture(scope="module")
+def zinc_full():
+    d = gtok.synth.zinc_like(ZINC_FULL, seed=1000)
+    batch, coo = both(d)
+    return d, batch, batch.to(DEV), coo
+
+
+def test_sent_zinc_full_bit_exact_and_properties(zinc_full):
+    d, host, dev, coo = zinc_full
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ld = 192
+    ids, ln = gtok.ops.sent(dev, 37, 1024, 7, 3, ld=ld, **kw)
+    ref, rln = orc.sent(coo, 37, 1024, 7, 3, ld=ld, nthreads=THREADS, **kw)
+    assert int(ln.max()) <= ld, "slab too narrow for this epoch: the comparison below would be vacuous"
+    assert np.array_equal(ln.cpu().numpy(), rln)
+    assert np.array_equal(ids.cpu().numpy(), ref)
+    # properties on the device tensors
+    rows = torch.arange(ZINC_FULL, device=DEV)
+    assert bool((ids[:, 0] == 0).all())                                   # <bos>
+    assert bool((ids[rows, (ln - 1).long()] == 1).all())                  # <eos> after the remap
+    pad_mask = torch.arange(ld, device=DEV)[None, :] >= ln[:, None]
+    assert bool((ids[pad_mask] == 5).all())                               # Graph2TrailTokenizer.pad beyond the length
+    assert int(ids.max()) < 22 + 37 + 100                                 # vocab_size of train_agtt.py:561 (x <= 27)
+    # determinism, a fresh trail per epoch, shard invariance through graph_base
+    again, aln = gtok.ops.sent(dev, 37, 1024, 7, 3, ld=ld, **kw)
+    assert torch.equal(again, ids) and torch.equal(aln, ln)
+    nxt, _ = gtok.ops.sent(dev, 37, 1024, 7, 4, ld=ld, **kw)
+    assert float((nxt != ids).any(1).float().mean()) > 0.99
+    lo, hi = 100000, 180000
+    part, pln = gtok.ops.sent(host.shard(lo, hi).to(DEV), 37, 1024, 7, 3, graph_base=lo, ld=ld, **kw)
+    assert torch.equal(part, ids[lo:hi]) and torch.equal(pln, ln[lo:hi])
+
+
+def test_sent_zinc_full_lossless_sample(zinc_full):
+    d, host, dev, coo = zinc_full
+    ids, ln = gtok.ops.sent(dev, 37, 1024, 11, 0, labeled=True, num_node_types=28, num_edge_types=6, ld=192)
+    pick = np.random.default_rng(0).choice(ZINC_FULL, 1500, replace=False)
+    h, hl = ids[torch.from_numpy(pick).to(DEV)].cpu().numpy(), ln.cpu().numpy()[pick]
+    for r, g in enumerate(pick):
+        n, edges, ntypes, etypes, used = orc.sent_decode(h[r, :hl[r]].tolist(), 37, True, 28)
+        e0, e1, n0 = coo.edge_ptr[g], coo.edge_ptr[g + 1], coo.node_ptr[g]
+        assert used == hl[r] and n == coo.node_counts[g] and len(edges) == (e1 - e0) // 2
+        assert sorted(ntypes.values()) == sorted(int(v) for v in coo.x[n0:n0 + n])
+        assert sorted(etypes.values()) == sorted(int(v) for v in coo.edge_attr[e0:e1][coo.src[e0:e1] < coo.dst[e0:e1]])
+
+
+def test_ibtt_zinc_full_bit_exact_and_lengths(zinc_full):
+    d, host, dev, coo = zinc_full
+    vocab = zinc_vocab(40)
+    lut = gtok.ops.zinc_lut(vocab, 40)
+    ids, ln = gtok.ops.ibtt_zinc(dev, lut, 1024, vocab["<pad>"], ld=240)
+    ref, rln = orc.ibtt_zinc(coo, lut.numpy(), 1024, vocab["<pad>"], 240, nthreads=THREADS)
+    assert int(ln.max()) <= 240
+    assert np.array_equal(ln.cpu().numpy(), rln) and np.array_equal(ids.cpu().numpy(), ref)
+    # closed form: 4 + 2N + 4B ids (B undirected bonds; the synthetic molecules list both directions once)
+    want = 4 + 2 * d["node_counts"] + 4 * (d["edge_counts"] // 2)
+    assert np.array_equal(ln.cpu().numpy(), want)
+    # idempotence / determinism
+    again, aln = gtok.ops.ibtt_zinc(dev, lut, 1024, vocab["<pad>"], ld=240)
+    assert torch.equal(again, ids) and torch.equal(aln, ln)
+
+
+def test_large_graphs_bit_exact():
+    """BASELINE config 5 shape: 10..256 nodes, sparsity 0.1-0.2, max_len 600 (most trails are cut there)."""
+    d = gtok.synth.er_batch_device(4096, torch.device(DEV), seed=1000)
+    batch, coo = both(d, False)
+    dev = batch.to(DEV)
+    ids, ln = gtok.ops.sent(dev, 256, 600, 3, 1, ld=600)
+    ref, rln = orc.sent(coo, 256, 600, 3, 1, ld=600, nthreads=THREADS)
+    assert np.array_equal(ln.cpu().numpy(), rln) and np.array_equal(ids.cpu().numpy(), ref)
+    assert float((ln == 600).float().mean()) > 0.5, "the truncation path must be hot in this configuration"
+    vocab = {t: i for i, t in enumerate(["<pad>", "<bos>", "<e>", "<n>", "<q>", "<p>", "<eos>", "yes", "no", "has_cycle"]
+                                        + [str(i) for i in range(256)])}
+    lut = gtok.ops.synth_lut(vocab, 256)
+    q = np.zeros((4096, 4), np.int32); q[:, 0] = 1; q[:, 1] = vocab["has_cycle"]
+    ids2, ln2 = gtok.ops.ibtt_synth(dev, lut, torch.from_numpy(q), 600, 0, ld=600)
+    ref2, rln2 = orc.ibtt_synth(coo, lut.numpy(), q, 600, 0, 600, nthreads=THREADS)
+    assert np.array_equal(ln2.cpu().numpy(), rln2) and np.array_equal(ids2.cpu().numpy(), ref2)
+    want = np.minimum(600, 1 + 3 * d["edge_counts"] + 1 + d["node_counts"] + 1 + 1 + 1)
+    assert np.array_equal(ln2.cpu().numpy(), want)
