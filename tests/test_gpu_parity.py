@@ -191,3 +191,24 @@ def test_sent_every_kernel_same_tokens(pin, monkeypatch):
     ids, ln = gtok.ops.sent(b2.to(DEV), 49, 600, 5, 2, query=torch.from_numpy(q))
     ref, rln = orc.sent(c2, 49, 600, 5, 2, query=q, ld=ids.shape[1])
     _cmp(ids, ln, ref, rln, f"sent[{pin}]+query")
+
+
+def test_torch_custom_ops():
+    """torch.ops.gtok.* are the same kernels; CUDA only (a CPU tensor must be refused, not tokenized on the host)."""
+    d = gtok.synth.zinc_like(500, seed=70)
+    batch, coo = both(d)
+    b = batch.to(DEV)
+    ids, ln = torch.ops.gtok.sent(b.node_ptr, b.edge_ptr, b.rowptr, b.col, b.nattr, b.eattr, None, b.max_nodes,
+                                  b.max_edges, 37, 1024, 192, 3, 1, True, 9, 4, True, 5, 0)
+    ref, rln = orc.sent(coo, 37, 1024, 3, 1, labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True, ld=192)
+    _cmp(ids, ln, ref, rln, "torch.ops.gtok.sent")
+    vocab = zinc_vocab(40)
+    lut = gtok.ops.zinc_lut(vocab, 40).to(DEV)
+    ids2, ln2 = torch.ops.gtok.ibtt_zinc(b.node_ptr, b.edge_ptr, b.rowptr, b.col, b.eorder, b.nattr, b.eattr, lut,
+                                         b.max_nodes, b.max_edges, 1024, 2, 240)
+    ref2, rln2 = orc.ibtt_zinc(coo, lut.cpu().numpy(), 1024, 2, 240)
+    _cmp(ids2, ln2, ref2, rln2, "torch.ops.gtok.ibtt_zinc")
+    X, A = torch.ops.gtok.collate(ids2, ln2, torch.arange(8, device=DEV), 2, int(ln2[:8].max()))
+    assert X.dtype == torch.int64 and A.dtype == torch.bool and X.shape == A.shape
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.gtok.remap_zinc(ids.cpu(), ln.cpu(), 6, 43, 52)

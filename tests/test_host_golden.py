@@ -202,3 +202,13 @@ def test_product_has_no_cpu_path():
                 src = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "libgtok_oracle", "oracle.py", "#include \"../../oracle"):
                     assert needle not in src, (f, needle)
+
+
+def test_custom_ops_are_registered_cuda_only_and_have_meta_kernels():
+    for name in ("sent", "ibtt_zinc", "ibtt_synth", "remap_zinc", "collate"):
+        assert hasattr(torch.ops.gtok, name), name
+    ids = torch.zeros((4, 8), dtype=torch.int32); ln = torch.full((4,), 8, dtype=torch.int32)
+    with pytest.raises((NotImplementedError, RuntimeError)):       # no CPU kernel exists
+        torch.ops.gtok.remap_zinc(ids, ln, 6, 43, 52)
+    out = torch.ops.gtok.remap_zinc(ids.to("meta"), ln.to("meta"), 6, 43, 52)   # shape inference without a GPU
+    assert out.shape == (4, 8) and out.device.type == "meta"
