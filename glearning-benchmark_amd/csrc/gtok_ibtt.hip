@@ -410,9 +410,9 @@ using namespace gtok;
 extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut_len, int32_t max_len,
                               int32_t pad_id, int32_t *out_ids, int32_t ld, int32_t *out_len,
                               void *stream) {
-  if (!csr_ok(g) || !lut || lut_len < GTOK_ZLUT_NODE0 || max_len < 0 || !out_ids || !out_len || ld <= 0)
-    return GTOK_E_INVAL;
-  if (g->num_graphs == 0) return GTOK_OK;
+  if (!g || g->num_graphs < 0 || max_len < 0 || ld <= 0) return GTOK_E_INVAL;
+  if (g->num_graphs == 0) return GTOK_OK;   // an empty batch is a no-op
+  if (!csr_ok(g) || !lut || lut_len < GTOK_ZLUT_NODE0 || !out_ids || !out_len) return GTOK_E_INVAL;
   if (g->max_nodes > 65535 || g->max_edges > 65535) return GTOK_E_TOO_LARGE;
   ZincArgs a;
   a.g = *g; a.lut = lut; a.lut_len = lut_len; a.max_len = max_len; a.pad_id = pad_id;
@@ -450,9 +450,9 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
 extern "C" int gtok_ibtt_synth(const gtok_csr *g, const int32_t *lut, int32_t lut_len,
                                const int32_t *query, int32_t max_len, int32_t pad_id,
                                int32_t *out_ids, int32_t ld, int32_t *out_len, void *stream) {
-  if (!csr_ok(g) || !lut || lut_len < GTOK_SLUT_NODE0 || max_len < 0 || !out_ids || !out_len || ld <= 0)
-    return GTOK_E_INVAL;
+  if (!g || g->num_graphs < 0 || max_len < 0 || ld <= 0) return GTOK_E_INVAL;
   if (g->num_graphs == 0) return GTOK_OK;
+  if (!csr_ok(g) || !lut || lut_len < GTOK_SLUT_NODE0 || !out_ids || !out_len) return GTOK_E_INVAL;
   SynthArgs a;
   a.g = *g; a.lut = lut; a.query = query; a.lut_len = lut_len; a.max_len = max_len; a.pad_id = pad_id;
   a.maxn = g->max_nodes > 0 ? g->max_nodes : 1;
@@ -482,13 +482,12 @@ extern "C" int gtok_ibtt_synth(const gtok_csr *g, const int32_t *lut, int32_t lu
 extern "C" int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts,
                                 const gtok_vocab_table *vocab, int32_t strip_label, int32_t max_len,
                                 int32_t *out_ids, int32_t ld, int32_t *out_len, void *stream) {
-  if (!text_ptr || !vocab || num_texts < 0 || max_len < 0 || !out_ids || !out_len || ld <= 0)
-    return GTOK_E_INVAL;
+  if (!vocab || num_texts < 0 || max_len < 0 || ld <= 0) return GTOK_E_INVAL;
   if (vocab->capacity <= 0 || (vocab->capacity & (vocab->capacity - 1)) || !vocab->key_off ||
       !vocab->key_len || !vocab->id || !vocab->key_bytes)
     return GTOK_E_INVAL;
   if (num_texts == 0) return GTOK_OK;
-  if (!bytes) return GTOK_E_INVAL;
+  if (!bytes || !text_ptr || !out_ids || !out_len) return GTOK_E_INVAL;
   TextArgs a;
   a.bytes = bytes; a.text_ptr = text_ptr; a.num_texts = num_texts; a.v = *vocab;
   a.strip_label = strip_label; a.pad_id = vocab->pad_id; a.max_len = max_len;

@@ -31,8 +31,9 @@ using namespace gtok;
 
 extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids,
                          int32_t ld, int32_t *out_len, void *stream) {
-  if (!g || !p || !out_ids || !out_len || ld <= 0 || g->num_graphs < 0) return GTOK_E_INVAL;
-  if (g->num_graphs == 0) return GTOK_OK;
+  if (!g || !p || ld <= 0 || g->num_graphs < 0) return GTOK_E_INVAL;
+  if (g->num_graphs == 0) return GTOK_OK;   // an empty batch is a no-op
+  if (!out_ids || !out_len) return GTOK_E_INVAL;
   if (!g->node_ptr || !g->edge_ptr || !g->rowptr || (g->max_edges > 0 && !g->col)) return GTOK_E_INVAL;
   if (p->max_len < 0 || p->max_num_nodes < 0) return GTOK_E_INVAL;
   if (p->labeled && (!g->nattr || !g->eattr)) return GTOK_E_INVAL;

@@ -212,3 +212,37 @@ def test_torch_custom_ops():
     assert X.dtype == torch.int64 and A.dtype == torch.bool and X.shape == A.shape
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.gtok.remap_zinc(ids.cpu(), ln.cpu(), 6, 43, 52)
+
+
+def test_c_abi_error_codes():
+    """Bad arguments come back as negative GTOK_E_* codes (nothing throws across the ABI, nothing is launched)."""
+    import ctypes
+    from importlib import import_module
+    L = gtok.lib()
+    lib_mod = gtok._lib
+    d = gtok.synth.zinc_like(8, seed=80)
+    b, _ = both(d)
+    b = b.to(DEV)
+    cs = b.c_struct()
+    ids = torch.empty((8, 64), dtype=torch.int32, device=DEV); ln = torch.empty(8, dtype=torch.int32, device=DEV)
+    p = lib_mod.GtokSentParams(37, 0, 0, 0, 64, 0, 5, 0, 1, 0, 0, None)
+    assert L.gtok_sent(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), 64, ln.data_ptr(), None) == 0
+    assert L.gtok_sent(ctypes.byref(cs), ctypes.byref(p), None, 64, ln.data_ptr(), None) == -1          # GTOK_E_INVAL
+    assert L.gtok_sent(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), 0, ln.data_ptr(), None) == -1
+    lab = lib_mod.GtokSentParams(37, 1, 9, 4, 64, 0, 5, 0, 1, 0, 0, None)
+    nolab = gtok.GraphBatch(b.num_graphs, b.max_nodes, b.max_edges, b.node_ptr, b.edge_ptr, b.rowptr, b.col, None, None, None)
+    cs2 = nolab.c_struct()
+    assert L.gtok_sent(ctypes.byref(cs2), ctypes.byref(lab), ids.data_ptr(), 64, ln.data_ptr(), None) == -1   # labelled, no attrs
+    big = gtok.GraphBatch(b.num_graphs, 600, b.max_edges, b.node_ptr, b.edge_ptr, b.rowptr, b.col, None, b.nattr, b.eattr)
+    cs3 = big.c_struct()
+    assert L.gtok_sent(ctypes.byref(cs3), ctypes.byref(p), ids.data_ptr(), 64, ln.data_ptr(), None) == -2    # GTOK_E_TOO_LARGE
+    assert L.gtok_ibtt_zinc(ctypes.byref(cs), None, 64, 64, 2, ids.data_ptr(), 64, ln.data_ptr(), None) == -1
+    vt = lib_mod.GtokVocabTable(12, 0, None, None, None, None)                                               # not a power of two
+    assert L.gtok_text_to_ids(None, ln.data_ptr(), 0, ctypes.byref(vt), 1, 8, ids.data_ptr(), 64, ln.data_ptr(), None) == -1
+    torch.cuda.synchronize()
+    with pytest.raises(gtok.GtokError):
+        gtok.ops.sent(big, 37, 64, 0)
+    # an empty batch is a no-op, not an error
+    empty = gtok.GraphBatch.from_coo([], [], [], []).to(DEV)
+    e_ids, e_ln = gtok.ops.sent(empty, 37, 64, 0, ld=8)
+    assert e_ids.shape == (0, 8) and e_ln.numel() == 0
