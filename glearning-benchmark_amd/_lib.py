@@ -23,12 +23,16 @@ c_u8p = ctypes.POINTER(ctypes.c_uint8)
 class GtokCsr(ctypes.Structure):
     _fields_ = [
         ("num_graphs", ctypes.c_int32), ("max_nodes", ctypes.c_int32),
-        ("max_edges", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("max_edges", ctypes.c_int32), ("flags", ctypes.c_int32),
         ("node_ptr", ctypes.c_void_p), ("edge_ptr", ctypes.c_void_p),
         ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p),
         ("eorder", ctypes.c_void_p), ("nattr", ctypes.c_void_p),
         ("eattr", ctypes.c_void_p),
+        ("chunk_nodes", ctypes.c_int32), ("chunk_edges", ctypes.c_int32),
     ]
+
+
+CSR_SIMPLE_SYMMETRIC = 1
 
 
 class GtokVocabTable(ctypes.Structure):

@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
-from ._lib import GtokCsr
+from ._lib import CSR_SIMPLE_SYMMETRIC, GtokCsr
 
 
 def _to_u8(a: Optional[np.ndarray]) -> Optional[np.ndarray]:
@@ -20,6 +20,25 @@ def _to_u8(a: Optional[np.ndarray]) -> Optional[np.ndarray]:
         return None
     a = np.asarray(a).reshape(-1).astype(np.int64, copy=False)
     return np.where((a >= 0) & (a < 255), a, 255).astype(np.uint8)
+
+
+def _chunk_max(counts: np.ndarray, group: int = 64) -> int:
+    """max over aligned groups of `group` graphs of the summed counts."""
+    counts = np.asarray(counts, dtype=np.int64)
+    if counts.size == 0:
+        return 0
+    pad = (-counts.size) % group
+    return int(np.pad(counts, (0, pad)).reshape(-1, group).sum(1).max())
+
+
+def _simple_symmetric(gid_e: np.ndarray, src: np.ndarray, dst: np.ndarray, max_nodes: int) -> bool:
+    """True iff no (graph, u, v) entry is listed twice and every (u, v) has its (v, u)."""
+    m = np.int64(max_nodes + 1)
+    fwd = np.sort((gid_e * m + src) * m + dst)
+    if fwd.size and (fwd[1:] == fwd[:-1]).any():
+        return False
+    rev = np.sort((gid_e * m + dst) * m + src)
+    return bool(np.array_equal(fwd, rev))
 
 
 @dataclass
@@ -34,6 +53,9 @@ class GraphBatch:
     eorder: Optional[torch.Tensor]    # int32 [sum E] or None (identity)
     nattr: Optional[torch.Tensor]     # uint8 [sum N]
     eattr: Optional[torch.Tensor]     # uint8 [sum E]
+    flags: int = 0                    # GTOK_CSR_*: properties verified on the host for the whole batch
+    chunk_nodes: int = 0              # max over 64-graph groups of sum N_g / sum E_g (LDS sizing of the
+    chunk_edges: int = 0              # lane-per-graph kernel); 0 = unknown
 
     @property
     def device(self) -> torch.device:
@@ -50,12 +72,14 @@ class GraphBatch:
     def to(self, device) -> "GraphBatch":
         mv = lambda t: None if t is None else t.to(device, non_blocking=True)
         return GraphBatch(self.num_graphs, self.max_nodes, self.max_edges, mv(self.node_ptr), mv(self.edge_ptr),
-                          mv(self.rowptr), mv(self.col), mv(self.eorder), mv(self.nattr), mv(self.eattr))
+                          mv(self.rowptr), mv(self.col), mv(self.eorder), mv(self.nattr), mv(self.eattr),
+                          self.flags, self.chunk_nodes, self.chunk_edges)
 
     def c_struct(self) -> GtokCsr:
         p = lambda t: None if t is None else t.data_ptr()
-        return GtokCsr(self.num_graphs, self.max_nodes, self.max_edges, 0, p(self.node_ptr), p(self.edge_ptr),
-                       p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr))
+        return GtokCsr(self.num_graphs, self.max_nodes, self.max_edges, self.flags, p(self.node_ptr), p(self.edge_ptr),
+                       p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr),
+                       self.chunk_nodes, self.chunk_edges)
 
     def node_counts(self) -> torch.Tensor:
         return self.node_ptr[1:] - self.node_ptr[:-1]
@@ -79,16 +103,18 @@ class GraphBatch:
         sl = lambda t, a, b: None if t is None else t[a:b].clone()
         nc = (self.node_ptr[lo + 1:hi + 1] - self.node_ptr[lo:hi])
         ec = (self.edge_ptr[lo + 1:hi + 1] - self.edge_ptr[lo:hi])
+        cn, ce = _chunk_max(nc.numpy()), _chunk_max(ec.numpy())
         return GraphBatch(hi - lo, int(nc.max()) if hi > lo else 0, int(ec.max()) if hi > lo else 0,
                           (self.node_ptr[lo:hi + 1] - n0).clone(), (self.edge_ptr[lo:hi + 1] - e0).clone(),
                           sl(self.rowptr, n0 + lo, n1 + hi), sl(self.col, e0, e1), sl(self.eorder, e0, e1),
-                          sl(self.nattr, n0, n1), sl(self.eattr, e0, e1))
+                          sl(self.nattr, n0, n1), sl(self.eattr, e0, e1), self.flags, cn, ce)
 
     # ------------------------------------------------------------------ builders
     @staticmethod
-    def from_coo(node_counts, edge_counts, src, dst, x=None, edge_attr=None) -> "GraphBatch":
+    def from_coo(node_counts, edge_counts, src, dst, x=None, edge_attr=None, check_symmetric: bool = True) -> "GraphBatch":
         """Batched COO -> CSR.  src/dst are LOCAL node ids, edges of graph g are contiguous, in the
-        order the source edge_index lists them (that order is kept in `eorder`)."""
+        order the source edge_index lists them (that order is kept in `eorder`).  check_symmetric: verify once
+        whether the rows are complete duplicate-free adjacency lists (sets GTOK_CSR_SIMPLE_SYMMETRIC)."""
         node_counts = np.asarray(node_counts, dtype=np.int64).reshape(-1)
         edge_counts = np.asarray(edge_counts, dtype=np.int64).reshape(-1)
         src = np.asarray(src, dtype=np.int64).reshape(-1)
@@ -130,8 +156,11 @@ class GraphBatch:
                 raise ValueError("edge_attr length does not match edge_counts")
             eattr = take(eattr)
         t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
-        return GraphBatch(G, int(node_counts.max()) if G else 0, int(edge_counts.max()) if G else 0,
-                          t(node_ptr.astype(np.int32)), t(edge_ptr), t(rowptr), t(col), t(eorder), t(nattr), t(eattr))
+        max_nodes = int(node_counts.max()) if G else 0
+        flags = CSR_SIMPLE_SYMMETRIC if (check_symmetric and E and _simple_symmetric(gid_e, src, dst, max_nodes)) else 0
+        return GraphBatch(G, max_nodes, int(edge_counts.max()) if G else 0,
+                          t(node_ptr.astype(np.int32)), t(edge_ptr), t(rowptr), t(col), t(eorder), t(nattr), t(eattr),
+                          flags, _chunk_max(node_counts), _chunk_max(edge_counts))
 
     @staticmethod
     def from_data_list(data_list: Sequence, labeled: Optional[bool] = None) -> "GraphBatch":

@@ -23,6 +23,9 @@
 
 namespace gtok {
 
+// below this many graphs a launch cannot fill the chip with 64-graph waves: wave-per-graph is used instead
+constexpr int GTOK_LANE_MIN_GRAPHS = 1 << 30;   // lane kernel is opt-in for now (GTOK_SENT_KERNEL=lane)
+
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 }  // namespace gtok
@@ -53,33 +56,31 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   // GTOK_SENT_KERNEL=lane|reg|lds pins the kernel (tests run every path).  Default: wave-per-graph; the
   // lane-per-graph kernel is opt-in until its labelled variant beats sent_reg_kernel (see its header)
   const char *pin = std::getenv("GTOK_SENT_KERNEL");
-  const bool lane_ok = maxn <= 64 && g->max_edges <= 255 &&
-                       22 + GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < (1 << 30) &&
+  const bool lane_ok = maxn <= 64 && g->max_edges <= 255 && (g->flags & GTOK_CSR_SIMPLE_SYMMETRIC) &&
                        (!p->remap_zinc || g->max_nodes <= p->max_num_nodes);
-  bool lane_path = false;
+  bool lane_path = lane_ok && g->num_graphs >= GTOK_LANE_MIN_GRAPHS;
   if (pin && lane_ok && pin[0] == 'l' && pin[1] == 'a') lane_path = true;
   if (pin && (pin[0] == 'r' || (pin[0] == 'l' && pin[1] == 'd'))) lane_path = false;
   if (force && force[0] == '1') lane_path = false;
   if (lane_path) {
     SentArgs a;
     a.g = *g; a.p = *p; a.cap = cap; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
+    // staging sized by the largest 64-graph chunk when the host told us, else by the per-graph maxima
+    a.chunk_nodes = g->chunk_nodes > 0 ? g->chunk_nodes : 64 * maxn;
+    a.chunk_edges = g->chunk_edges > 0 ? g->chunk_edges : 64 * maxe;
+    a.chunk_rows = a.chunk_nodes + 64;
     int off = 0;
-    a.l.adj = off; off += maxn * 64 * 8;
-    a.l.rng = a.l.tok = 0;
-    // contiguous staging of the wave's CSR chunk; walk arrays (order/vidx/rem) alias it for unlabelled graphs
-    const int stage0 = off;
-    a.l.rp = off; off += align_up((maxn + 1) * 64, 16);
-    a.l.col = off; off += align_up(maxe * 64, 16);
+    a.l.adj = a.l.rng = a.l.tok = 0;
+    a.l.rp = off; off += align_up(a.chunk_rows + 4, 16);
+    a.l.col = off; off += align_up(a.chunk_edges + 4, 16);   // +4: clamped look-ahead reads of an empty last row
     a.l.eat = a.l.nat = off;
     if (p->labeled) {
-      a.l.eat = off; off += align_up(maxe * 64, 16);
-      a.l.nat = off; off += align_up(maxn * 64, 16);
+      a.l.eat = off; off += align_up(a.chunk_edges + 4, 16);
+      a.l.nat = off; off += align_up(a.chunk_nodes, 16);
     }
-    int walk0 = p->labeled ? off : stage0;
-    a.l.order = walk0; walk0 += maxn * 64;
-    a.l.vidx = walk0; walk0 += maxn * 64;
-    a.l.vis = walk0; walk0 += maxn * 64;                   // rem[]
-    if (walk0 > off) off = walk0;
+    a.l.order = 0;
+    a.l.vidx = off; off += maxn * 64;
+    a.l.vis = off; off += maxn * 64;                       // rem[]
     a.l.stride = align_up(off, 16);
     if (a.l.stride <= 64 * 1024) {
       typedef void (*K)(const SentArgs);
@@ -90,6 +91,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64,
                                                        (size_t)a.l.stride) != hipSuccess || occ < 1)
         occ = 1;
+      if (const char *cs = std::getenv("GTOK_LANE_BLOCKS_PER_CU")) { const int c = std::atoi(cs); if (c >= 1 && c < occ) occ = c; }
       a.units = (g->num_graphs + 63) / 64;
       int nb = ncu * occ;
       if (nb > a.units) nb = a.units;

@@ -4,20 +4,20 @@
 // the scalar-issue floor (profiles/r01/sq_counters_progress.md); a molecule has ~25 nodes, so 63 of 64 lanes
 // idle in every vector instruction.  Here every lane runs the whole walk of its own graph — the same spec and
 // token stream, bit-exact against oracle/gtok_oracle.c — so one vector instruction advances 64
-// graphs.  Per-graph state lives in LDS as arrays laid out [index][lane]: element (i, lane) sits in bank group
-// `lane` whatever i is, so 64 lanes indexing with 64 different i never conflict.
-//   adj   u64[maxn][64]  immutable symmetric adjacency rows        order/vidx u8[maxn][64]  visit order and inverse
-//   rem   u8 [maxn][64]  unvisited neighbours left per node: keeps the set of visited nodes that still own an
-//                        uncovered edge (`live`, a register) incremental, so a dead end costs O(1)
-//   rp/col/eat/nat u8    (labelled) the graph's own CSR, for edge-type lookups
-// Tokens are stored straight to the row in HBM (lane-private, sequential); the pad tail of the 64 rows is
-// filled cooperatively (coalesced) at the end.  Limits: maxn <= 64, maxe <= 255 (u8 indices).
+// graphs.
 //
-// STATUS (round 1): opt-in with GTOK_SENT_KERNEL=lane.  It needs 450 instruction slots per molecule against
-// 2075 for sent_reg_kernel, but 26 KB (unlabelled) / 41 KB (labelled) of LDS per 64-graph wave leave 6 / 3
-// waves per CU, and it is latency-bound there: ZINC-full unlabelled 0.375 ms (reg kernel 0.405), labelled
-// 0.93 ms (reg kernel 0.52).  Getting the labelled variant under the register kernel needs an LDS diet (edge
-// types in a rank-indexed table instead of the staged CSR) — next round.
+// Requires GTOK_CSR_SIMPLE_SYMMETRIC (host-verified: no duplicate entry, every (u,v) has its (v,u) — any
+// PyG-coalesced undirected graph): then the staged CSR rows ARE the adjacency lists, no bit matrix is built,
+// and the edge type of a neighbour sits next to its id.  LDS per wave:
+//   staged CSR chunk of the wave's 64 consecutive graphs (coalesced loads; u8 row pointers / neighbour ids /
+//   types), indexed per lane by its own offsets;
+//   vidx, rem  u8[maxn][64] laid out [index][lane] (lane l always hits bank group l: conflict-free for 64
+//   different indices).  vidx = node -> visit index; rem[u] = unvisited neighbours left, which keeps `live` —
+//   the visited nodes that still own an uncovered edge — incremental, so a dead end costs O(1).  Bracket
+//   members are recovered from the row itself (the entry whose neighbour carries visit index k), so no
+//   visit-order array is kept and the member's edge type comes with the entry.
+// Tokens are stored straight to the row in HBM (lane-private, sequential); the pad tails of the 64 rows are
+// filled cooperatively (coalesced) at the end.  Limits: maxn <= 64, maxe <= 255 (u8 indices).
 #pragma once
 #include "gtok_sent_reg.hpp"
 
@@ -32,10 +32,7 @@ template <bool LAB>
 __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  uint64_t *adj = reinterpret_cast<uint64_t *>(smem + a.l.adj);
-  uint8_t *order = smem + a.l.order, *vidx = smem + a.l.vidx, *rem = smem + a.l.vis;
-  // the wave's 64 graphs are one contiguous CSR chunk: staged here with coalesced loads, indexed per lane by
-  // its own offsets.  Unlabelled walks only need it for the build, so order/vidx/rem alias it (host layout).
+  uint8_t *vidx = smem + a.l.vidx, *rem = smem + a.l.vis;
   uint8_t *srp = smem + a.l.rp, *scol = smem + a.l.col, *seat = smem + a.l.eat, *snat = smem + a.l.nat;
 #define AT(arr, i) (arr)[(i) * 64 + lane]
 
@@ -49,6 +46,7 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
   const int T_RESET = remap ? 2 : GTOK_SENT_RESET, T_LADJ = remap ? 2 : GTOK_SENT_LADJ;
   const int T_RADJ = remap ? 2 : GTOK_SENT_RADJ, T_EOS = remap ? 1 : GTOK_SENT_EOS;
   const int G = a.g.num_graphs;
+  const int cap_r = a.chunk_rows, cap_e = a.chunk_edges, cap_n = a.chunk_nodes;   // staging capacities
 
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
@@ -68,10 +66,10 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
       e0 = a.g.edge_ptr[g];
       e = min((int)(a.g.edge_ptr[g + 1] - e0), a.g.max_edges);
     }
-    // ---- stage the chunk (coalesced, independent loads), then each lane builds its adjacency from LDS
-    wave_sync();   // the previous unit's order/vidx/rem may alias the staging area
+    // ---- stage the wave's CSR chunk: coalesced, independent loads (4 in flight per lane)
+    wave_sync();
     {
-      const int cr = min((N1 - N0) + (gl - g0), (a.maxn + 1) * 64);   // row pointers: graph g's slice starts at node_ptr[g]+g
+      const int cr = min((N1 - N0) + (gl - g0), cap_r);   // graph g's row pointers start at node_ptr[g] + g
       const int32_t *__restrict__ rpc = a.g.rowptr + N0 + g0;
       for (int i = lane; i < cr; i += 4 * kWave) {
         int v[4];
@@ -80,7 +78,7 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (i + j * kWave < cr) srp[i + j * kWave] = (uint8_t)v[j];
       }
-      const int ce = (int)min(E1 - E0, (int64_t)a.g.max_edges * 64);
+      const int ce = (int)min(E1 - E0, (int64_t)cap_e);
       const int32_t *__restrict__ cc = a.g.col + E0;
       for (int i = lane; i < ce; i += 4 * kWave) {
         int v[4], t[4];
@@ -94,23 +92,45 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
         for (int j = 0; j < 4; ++j) if (i + j * kWave < ce) { scol[i + j * kWave] = (uint8_t)v[j]; if (LAB) seat[i + j * kWave] = (uint8_t)t[j]; }
       }
       if (LAB) {
-        const int cn = min(N1 - N0, a.maxn * 64);
+        const int cn = min(N1 - N0, cap_n);
         for (int i = lane; i < cn; i += kWave) snat[i] = a.g.nattr[N0 + i];
       }
     }
-    for (int u = 0; u < n; ++u) AT(adj, u) = 0;
     wave_sync();
     const uint8_t *rpl = srp + (nb0 - N0) + lane;          // this lane's row pointers, neighbour ids, types
     const uint8_t *cl = scol + (int)(e0 - E0), *el = seat + (int)(e0 - E0), *nl = snat + (nb0 - N0);
-    for (int u = 0; u < n; ++u) {
-      const int rs = rpl[u], re = rpl[u + 1];
-      for (int k = rs; k < re && k < e; ++k) {
-        const int v = cl[k];
-        if ((unsigned)v < (unsigned)n) { AT(adj, u) |= 1ull << v; AT(adj, v) |= 1ull << u; }
-      }
-    }
-    if (!LAB) wave_sync();   // staging is dead from here on: order/vidx/rem reuse it
-    for (int u = 0; u < n; ++u) AT(rem, u) = (uint8_t)__popcll(AT(adj, u) & ~(1ull << u));
+    // A node's row: bounds + its first four neighbour ids in registers (one LDS round trip each); molecules
+    // never have more, longer rows continue in a scalar tail loop.
+    struct Row { int rs, re, u0, u1, u2, u3; };
+    auto load_row = [&](int v) __attribute__((always_inline)) -> Row {
+      Row r;
+      r.rs = rpl[v];
+      r.re = min((int)rpl[v + 1], e);
+      const int last = max(r.re - 1, r.rs);
+      r.u0 = cl[min(r.rs + 0, last)]; r.u1 = cl[min(r.rs + 1, last)];
+      r.u2 = cl[min(r.rs + 2, last)]; r.u3 = cl[min(r.rs + 3, last)];
+      return r;
+    };
+    auto row_mask = [&](const Row &r) __attribute__((always_inline)) -> uint64_t {
+      const int deg = r.re - r.rs;
+      uint64_t m = 0;
+      m |= deg > 0 ? 1ull << r.u0 : 0ull; m |= deg > 1 ? 1ull << r.u1 : 0ull;
+      m |= deg > 2 ? 1ull << r.u2 : 0ull; m |= deg > 3 ? 1ull << r.u3 : 0ull;
+      for (int k = r.rs + 4; k < r.re; ++k) m |= 1ull << cl[k];
+      return m;
+    };
+    // position of neighbour y inside the row (it is listed: symmetric adjacency)
+    auto entry_of = [&](const Row &r, int y) __attribute__((always_inline)) -> int {
+      const int deg = r.re - r.rs;
+      int k = r.rs;
+      k = (deg > 3 && r.u3 == y) ? r.rs + 3 : k;
+      k = (deg > 2 && r.u2 == y) ? r.rs + 2 : k;
+      k = (deg > 1 && r.u1 == y) ? r.rs + 1 : k;
+      k = (deg > 0 && r.u0 == y) ? r.rs + 0 : k;
+      for (int t = r.rs + 4; t < r.re; ++t) if (cl[t] == (uint8_t)y) k = t;
+      return k;
+    };
+    for (int u = 0; u < n; ++u) AT(rem, u) = (uint8_t)__popcll(row_mask(load_row(u)) & ~(1ull << u));
 
     // ---- walk (per lane; mirrors oracle_sent step for step)
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
@@ -138,36 +158,45 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
       ++d;
       return __umulhi(x, nchoices);
     };
-    // edge-type TOKEN of (x,y): first listed entry x->y, else first y->x
-    auto edge_token = [&](int x, int y) __attribute__((always_inline)) -> int {
-      int at = 0;
-      bool found = false;
-      for (int k = rpl[x], ke = rpl[x + 1]; k < ke && !found; ++k)
-        if (cl[k] == (uint8_t)y) { at = el[k]; found = true; }
-      for (int k = rpl[y], ke = rpl[y + 1]; k < ke && !found; ++k)
-        if (cl[k] == (uint8_t)x) { at = el[k]; found = true; }
+    auto edge_tok = [&](int at) __attribute__((always_inline)) -> int {
       return remap ? remap_edge_type(at, edge_off) : edge_off + at;
     };
-    // first visit of v; pred >= 0: reached over the trail edge (pred, v)
-    auto visit = [&](int v, int pred) __attribute__((always_inline)) {
+    // first visit of v; pred >= 0: reached over the trail edge (pred, v) whose edge-type token is `et`
+    auto visit = [&](int v, int pred, int et) __attribute__((always_inline)) {
       const int my = nvis;
-      const uint64_t row = AT(adj, v);
-      uint64_t nbm = row & ~(1ull << v), M = 0;
-      while (nbm) {   // neighbours of v: one unvisited neighbour fewer each; visited ones (bar pred) join the bracket
-        const int u = __builtin_ctzll(nbm);
-        nbm &= nbm - 1;
-        const int r = (int)AT(rem, u) - 1;
-        AT(rem, u) = (uint8_t)r;
-        if (r == 0) live &= ~(1ull << u);
-        if (((vis >> u) & 1ull) && u != pred) M |= 1ull << AT(vidx, u);
+      const Row r = load_row(v);
+      const int deg = r.re - r.rs;
+      // the four leading neighbours: their rem / vidx reads go out together
+      const int u[4] = {r.u0, r.u1, r.u2, r.u3};
+      int rm[4], vx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { rm[j] = AT(rem, u[j]); vx[j] = AT(vidx, u[j]); }
+      uint64_t M = 0;   // bracket members, as bits in VISIT-INDEX space (ascending order for free)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < deg) {
+          if (u[j] == v) { M |= 1ull << my; }            // self loop: v lists itself, last (largest visit index)
+          else {
+            AT(rem, u[j]) = (uint8_t)(rm[j] - 1);         // one unvisited neighbour fewer for u
+            if (rm[j] == 1) live &= ~(1ull << u[j]);
+            if (((vis >> u[j]) & 1ull) && u[j] != pred) M |= 1ull << vx[j];
+          }
+        }
       }
-      if ((row >> v) & 1ull) M |= 1ull << my;   // self loop: v lists itself, last (largest visit index)
+      for (int k = r.rs + 4; k < r.re; ++k) {             // long rows: scalar tail
+        const int w = cl[k];
+        if (w == v) { M |= 1ull << my; continue; }
+        const int q = (int)AT(rem, w) - 1;
+        AT(rem, w) = (uint8_t)q;
+        if (q == 0) live &= ~(1ull << w);
+        if (((vis >> w) & 1ull) && w != pred) M |= 1ull << AT(vidx, w);
+      }
+      const uint64_t vis_before = vis;
       vis |= 1ull << v;
-      AT(order, my) = (uint8_t)v;
       AT(vidx, v) = (uint8_t)my;
       if (AT(rem, v) > 0) live |= 1ull << v;
       ++nvis;
-      if (LAB && pred >= 0) emit(edge_token(pred, v));
+      if (LAB && pred >= 0) emit(et);
       emit(pos_base + my);
       if (LAB) {
         const int x = nl[v];
@@ -175,10 +204,20 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
       }
       if (M) {
         emit(T_LADJ);
-        while (M) {   // ascending visit index
+        while (M) {   // ascending visit index; the member with index k is the row entry whose neighbour carries it
           const int k = __builtin_ctzll(M);
           M &= M - 1;
-          if (LAB) emit(edge_token(v, AT(order, k)));
+          int kk = r.rs;
+#pragma unroll
+          for (int j = 3; j >= 0; --j) {
+            const bool hit = j < deg && (u[j] == v ? k == my : (((vis_before >> u[j]) & 1ull) && vx[j] == k && u[j] != pred));
+            kk = hit ? r.rs + j : kk;
+          }
+          for (int t = r.rs + 4; t < r.re; ++t) {
+            const int w = cl[t];
+            if (w == v ? k == my : (((vis_before >> w) & 1ull) && AT(vidx, w) == k && w != pred)) kk = t;
+          }
+          if (LAB) emit(edge_tok(el[kk]));
           emit(pos_base + k);
         }
         emit(T_RADJ);
@@ -189,12 +228,14 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
       emit(GTOK_SENT_SOS);
       if (n > 0) {
         cur = (int)below((uint32_t)n);
-        visit(cur, -1);
+        visit(cur, -1, 0);
         while (pos < lim) {
-          const uint64_t row = AT(adj, cur) & ~vis;
+          const Row rc = load_row(cur);
+          const uint64_t row = row_mask(rc) & ~vis;
           if (row) {   // extend the trail over an uncovered edge (always towards an unvisited node)
             const int nxt = kth_bit_serial(row, (int)below((uint32_t)__popcll(row)));
-            visit(nxt, cur);
+            const int et = LAB ? edge_tok(el[entry_of(rc, nxt)]) : 0;   // type of the listed entry cur->nxt
+            visit(nxt, cur, et);
             cur = nxt;
           } else if (live) {   // dead end: restart from a visited node that still owns uncovered edges
             cur = kth_bit_serial(live, (int)below((uint32_t)__popcll(live)));
@@ -204,7 +245,7 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
             const uint64_t un = ~vis & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
             cur = kth_bit_serial(un, (int)below((uint32_t)(n - nvis)));
             emit(T_RESET);
-            visit(cur, -1);
+            visit(cur, -1, 0);
           } else {
             break;
           }

@@ -27,6 +27,7 @@ struct SentArgs {
   int32_t *out_len;
   int units;      // ceil(G / waves_per_block)
   int upb;        // units per block
+  int chunk_rows, chunk_nodes, chunk_edges;   // lane-per-graph kernel: staging capacities of a 64-graph chunk
 };
 
 constexpr int kEdgeRef = 0x8000;  // tok entry = kEdgeRef | a << 6 | b : "edge type of (a,b)", resolved by the writer

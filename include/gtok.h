@@ -65,11 +65,15 @@ extern "C" {
 
 #define GTOK_MAX_NODES 512 /* SENT adjacency bit-matrix rows per wave (LDS)  */
 
+/* flags: properties the HOST has verified for the whole batch */
+#define GTOK_CSR_SIMPLE_SYMMETRIC 1 /* no entry listed twice, and (v,u) is listed whenever (u,v) is: the rows
+                                       are complete adjacency lists (PyG-coalesced undirected graphs)          */
+
 typedef struct gtok_csr {
   int32_t num_graphs;
   int32_t max_nodes; /* max N_g over the batch (host-known)                 */
   int32_t max_edges; /* max E_g over the batch (host-known)                 */
-  int32_t reserved;
+  int32_t flags;     /* GTOK_CSR_* (0 = nothing known)                      */
   const int32_t *node_ptr;
   const int64_t *edge_ptr;
   const int32_t *rowptr;
@@ -77,6 +81,8 @@ typedef struct gtok_csr {
   const int32_t *eorder;
   const uint8_t *nattr;
   const uint8_t *eattr;
+  int32_t chunk_nodes; /* max over 64-graph groups [64i, 64i+64) of sum N_g; 0 = unknown (64*max_nodes assumed) */
+  int32_t chunk_edges; /* same for sum E_g                                                                      */
 } gtok_csr;
 
 /* LUT layout for gtok_ibtt_zinc (int32 vocab ids; an absent token holds pad_id
