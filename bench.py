@@ -155,7 +155,8 @@ def main():
         rec = json.load(open(tpath)).get(f"sent:{args.workload}:{G}:{args.ld}")
         if rec:
             traffic = rec["hbm_bytes_per_launch"]
-    kname = "sent_reg_kernel<labelled>" if zinc else f"sent_kernel<W={-(-host.max_nodes // 64)},unlabelled>"
+    kname = gtok.ops.sent_kernel_name(batch, max_nodes, max_len, labeled=zinc, num_node_types=ntypes, num_edge_types=etypes,
+                                      remap_zinc=zinc) + ("<labelled>" if zinc else "<unlabelled>")
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                     algorithmic_bytes_per_launch=int(read_b + write_b), kernel_ms=round(kern_s * 1e3, 4),

@@ -24,9 +24,28 @@
 namespace gtok {
 
 // below this many graphs a launch cannot fill the chip with 64-graph waves: wave-per-graph is used instead
-constexpr int GTOK_LANE_MIN_GRAPHS = 1 << 30;   // lane kernel is opt-in for now (GTOK_SENT_KERNEL=lane)
+constexpr int GTOK_LANE_MIN_GRAPHS = 65536;     // measured crossover on ZINC-shaped molecules: ~64k graphs
 
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// 0 = lane-per-graph, 1 = register-resident wave-per-graph, 2 = LDS bit matrix.  GTOK_SENT_KERNEL=lane|reg|lds
+// pins a kernel where it is applicable (tests run every path); GTOK_SENT_GENERIC=1 is the old spelling of "lds".
+static int choose_sent_kernel(const gtok_csr *g, const gtok_sent_params *p) {
+  const int maxn = g->max_nodes > 0 ? g->max_nodes : 1;
+  const char *force = std::getenv("GTOK_SENT_GENERIC");
+  const char *pin = std::getenv("GTOK_SENT_KERNEL");
+  const bool pin_lane = pin && pin[0] == 'l' && pin[1] == 'a', pin_reg = pin && pin[0] == 'r';
+  const bool pin_lds = (pin && pin[0] == 'l' && pin[1] == 'd') || (force && force[0] == '1');
+  const bool fold_ok = !p->remap_zinc || g->max_nodes <= p->max_num_nodes;   // remap folded into constants
+  const bool lane_ok = maxn <= 64 && g->max_edges <= 255 && (g->flags & GTOK_CSR_SIMPLE_SYMMETRIC) && fold_ok;
+  const bool reg_ok = maxn <= 64 && g->max_edges <= 32768 && fold_ok &&
+                      22 + GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < kEdgeRef;
+  if (pin_lds) return 2;
+  if (pin_lane && lane_ok) return 0;
+  if (pin_reg && reg_ok) return 1;
+  if (lane_ok && !pin_reg && g->num_graphs >= GTOK_LANE_MIN_GRAPHS) return 0;
+  return reg_ok ? 1 : 2;
+}
 
 }  // namespace gtok
 
@@ -50,18 +69,8 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   const int W = maxn <= 64 ? 1 : maxn <= 128 ? 2 : maxn <= 256 ? 4 : 8;
   const int cap = p->max_len < ld ? p->max_len : ld;
   const int maxe = g->max_edges > 0 ? g->max_edges : 1;
-  // register-resident walk for graphs of at most 64 nodes (placeholders need bit 15 of a token free);
-  // GTOK_SENT_GENERIC=1 forces the LDS bit-matrix kernel (A/B runs, tests of both paths)
-  const char *force = std::getenv("GTOK_SENT_GENERIC");
-  // GTOK_SENT_KERNEL=lane|reg|lds pins the kernel (tests run every path).  Default: wave-per-graph; the
-  // lane-per-graph kernel is opt-in until its labelled variant beats sent_reg_kernel (see its header)
-  const char *pin = std::getenv("GTOK_SENT_KERNEL");
-  const bool lane_ok = maxn <= 64 && g->max_edges <= 255 && (g->flags & GTOK_CSR_SIMPLE_SYMMETRIC) &&
-                       (!p->remap_zinc || g->max_nodes <= p->max_num_nodes);
-  bool lane_path = lane_ok && g->num_graphs >= GTOK_LANE_MIN_GRAPHS;
-  if (pin && lane_ok && pin[0] == 'l' && pin[1] == 'a') lane_path = true;
-  if (pin && (pin[0] == 'r' || (pin[0] == 'l' && pin[1] == 'd'))) lane_path = false;
-  if (force && force[0] == '1') lane_path = false;
+  const int which = choose_sent_kernel(g, p);
+  const bool lane_path = which == 0, reg_path = which == 1;
   if (lane_path) {
     SentArgs a;
     a.g = *g; a.p = *p; a.cap = cap; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
@@ -82,7 +91,8 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.l.vidx = off; off += maxn * 64;
     a.l.vis = off; off += maxn * 64;                       // rem[]
     a.l.stride = align_up(off, 16);
-    if (a.l.stride <= 64 * 1024) {
+    if (a.l.stride > 64 * 1024) return GTOK_E_TOO_LARGE;
+    {
       typedef void (*K)(const SentArgs);
       K kern = p->labeled ? (K)sent_lane_kernel<true> : (K)sent_lane_kernel<false>;
       int dev = 0, ncu = 256, occ = 1;
@@ -101,11 +111,6 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
       return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
     }
   }
-  const bool reg_path = W == 1 && !(force && force[0] == '1') && !(pin && pin[0] == 'l' && pin[1] == 'd') &&
-                        22 + GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < kEdgeRef &&
-                        g->max_edges <= 32768 &&
-                        (!p->remap_zinc || g->max_nodes <= p->max_num_nodes);   // remap folded into constants
-
   SentArgs a;
   a.g = *g; a.p = *p; a.cap = cap; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
   int off = 0;
@@ -182,4 +187,15 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   nb = (a.units + a.upb - 1) / a.upb;
   hipLaunchKernelGGL(kern, dim3(nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_params *p) {
+  if (!g || !p) return "";
+  static const char *lds[] = {"sent_lds_kernel<W=1>", "sent_lds_kernel<W=2>", "sent_lds_kernel<W=4>", "sent_lds_kernel<W=8>"};
+  const int maxn = g->max_nodes > 0 ? g->max_nodes : 1;
+  switch (choose_sent_kernel(g, p)) {
+    case 0: return "sent_lane_kernel";
+    case 1: return "sent_reg_kernel";
+    default: return lds[maxn <= 64 ? 0 : maxn <= 128 ? 1 : maxn <= 256 ? 2 : 3];
+  }
 }

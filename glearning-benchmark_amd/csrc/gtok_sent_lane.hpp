@@ -138,23 +138,25 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
     int32_t *__restrict__ orow = a.out + (int64_t)g * ld;
     uint64_t vis = 0, live = 0;
     int nvis = 0, pos = 0, d = 0, cur = 0;
-    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+    uint64_t plo = 0, phi = 0;
 
     auto emit = [&](int t) __attribute__((always_inline)) {
       if (pos < cap) orow[pos] = t;
       ++pos;
     };
+    // decision d uses word d&3 of Philox block d>>2; the block is kept as two packed 64-bit values and the word
+    // is extracted with mask arithmetic (a select chain over the captured words makes the compiler select
+    // ADDRESSES and park them in scratch: two memory round trips per draw)
     auto below = [&](uint32_t nchoices) __attribute__((always_inline)) -> uint32_t {
       const int w = d & 3;
       if (w == 0) {
         uint32_t o[4];
         philox4x32_10((uint32_t)(d >> 2), epoch, gid_lo, gid_hi, k0, k1, o);
-        o0 = o[0]; o1 = o[1]; o2 = o[2]; o3 = o[3];
+        plo = ((uint64_t)o[1] << 32) | o[0];
+        phi = ((uint64_t)o[3] << 32) | o[2];
       }
-      uint32_t x = o3;
-      x = w == 2 ? o2 : x;
-      x = w == 1 ? o1 : x;
-      x = w == 0 ? o0 : x;
+      const uint64_t m = 0ull - (uint64_t)((w >> 1) & 1);
+      const uint32_t x = (uint32_t)(((plo & ~m) | (phi & m)) >> ((w & 1) << 5));
       ++d;
       return __umulhi(x, nchoices);
     };

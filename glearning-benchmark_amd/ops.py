@@ -131,6 +131,15 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
     return ids, ln
 
 
+def sent_kernel_name(batch: GraphBatch, max_num_nodes: int, max_len: int, labeled: bool = False, num_node_types: int = 0,
+                     num_edge_types: int = 0, remap_zinc: bool = False) -> str:
+    """Name of the kernel gtok_sent() picks for this batch (for profiles and bench labels)."""
+    p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc), SENT_PAD,
+                       0, 0, 0, 0, None)
+    cs = batch.c_struct()
+    return lib().gtok_sent_kernel_name(ctypes.byref(cs), ctypes.byref(p)).decode()
+
+
 def remap_zinc(ids: torch.Tensor, ln: torch.Tensor, idx_offset: int, node_idx_offset: int,
                edge_idx_offset: int) -> torch.Tensor:
     _need_gpu(ids, "remap_zinc")

@@ -190,6 +190,11 @@ int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len,
                  int64_t *out_x, uint8_t *out_attn, int32_t out_ld,
                  int32_t *batch_max, void *stream);
 
+/* Which SENT kernel gtok_sent() will run for this batch ("sent_lane_kernel": lane per graph, needs
+ * GTOK_CSR_SIMPLE_SYMMETRIC and a large batch; "sent_reg_kernel": wave per graph, <= 64 nodes;
+ * "sent_lds_kernel<W=..>": wave per graph, up to 512 nodes).  All three emit the same tokens.               */
+const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_params *p);
+
 /* Library/ABI version and build target string ("gfx950").                   */
 int gtok_version(void);
 const char *gtok_target(void);
