@@ -203,7 +203,13 @@ def main():
         itok = float(iln.sum().item())
         ib = ibtt_read + 4.0 * itok + 4.0 * G
         ik = float(np.mean(ik_ms)) * 1e-3
-        out["ibtt"] = dict(kernel="ibtt_zinc_kernel" if zinc else "ibtt_synth_kernel",
+        if zinc:
+            import ctypes
+            _cs = batch.c_struct()
+            iname = gtok.lib().gtok_ibtt_zinc_kernel_name(ctypes.byref(_cs)).decode()
+        else:
+            iname = "ibtt_synth_kernel"
+        out["ibtt"] = dict(kernel=iname,
                            graphs_per_sec_per_gpu=round(G * args.steps / iwall, 1),
                            tokens_per_sec_per_gpu=round(itok * args.steps / iwall, 1), kernel_ms=round(ik * 1e3, 4),
                            slab_width=ild, avg_tokens_per_graph=round(itok / G, 2),

@@ -246,3 +246,19 @@ def test_c_abi_error_codes():
     empty = gtok.GraphBatch.from_coo([], [], [], []).to(DEV)
     e_ids, e_ln = gtok.ops.sent(empty, 37, 64, 0, ld=8)
     assert e_ids.shape == (0, 8) and e_ln.numel() == 0
+
+
+@pytest.mark.parametrize("pin", ["lane", "wave"])
+@pytest.mark.parametrize("max_len,ld", [(1024, None), (64, 64), (10, 12), (1, 4), (0, 4), (1024, 40), (57, 60)])
+def test_ibtt_zinc_both_kernels(pin, max_len, ld, monkeypatch):
+    """The lane-per-graph IBTT kernel (simple symmetric batches in list order) and the wave-per-graph one give
+    the oracle's ids, including every truncation corner."""
+    monkeypatch.setenv("GTOK_IBTT_KERNEL", pin)
+    d = gtok.synth.zinc_like(3000, seed=91)
+    batch, coo = both(d)
+    assert batch.flags & 1 and batch.eorder is None
+    vocab = zinc_vocab(30, with_fallbacks=(max_len != 57))     # some node ids (and X/unknown) fall back to <pad>
+    lut = gtok.ops.zinc_lut(vocab, 40)
+    ids, ln = gtok.ops.ibtt_zinc(batch.to(DEV), lut, max_len, vocab["<pad>"], ld=ld)
+    ref, rln = orc.ibtt_zinc(coo, lut.numpy(), max_len, vocab["<pad>"], ids.shape[1])
+    _cmp(ids, ln, ref, rln, f"ibtt_zinc[{pin}]")
