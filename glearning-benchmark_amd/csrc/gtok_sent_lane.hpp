@@ -23,6 +23,9 @@
 
 namespace gtok {
 
+struct alignas(4) Tok3 { int a, b, c; };   // token groups stored with one dword-aligned 12- / 8-byte write
+struct alignas(4) Tok2 { int a, b; };
+
 __device__ __forceinline__ int kth_bit_serial(uint64_t w, int k) {   // per lane; k is small (degree-bounded)
   while (k-- > 0) w &= w - 1;
   return __builtin_ctzll(w);
@@ -198,11 +201,18 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
       AT(vidx, v) = (uint8_t)my;
       if (AT(rem, v) > 0) live |= 1ull << v;
       ++nvis;
-      if (LAB && pred >= 0) emit(et);
-      emit(pos_base + my);
-      if (LAB) {
+      if (LAB) {   // [edge type] position type: one 12- / 8-byte store (dword-aligned) instead of 3 / 2 scattered ones
         const int x = nl[v];
-        emit(remap ? remap_node_type(x, node_off, a.p.num_node_types) : node_off + x);
+        const int ty = remap ? remap_node_type(x, node_off, a.p.num_node_types) : node_off + x;
+        if (pred >= 0) {
+          if (pos + 2 < cap) { *reinterpret_cast<Tok3 *>(orow + pos) = Tok3{et, pos_base + my, ty}; pos += 3; }
+          else { emit(et); emit(pos_base + my); emit(ty); }
+        } else {
+          if (pos + 1 < cap) { *reinterpret_cast<Tok2 *>(orow + pos) = Tok2{pos_base + my, ty}; pos += 2; }
+          else { emit(pos_base + my); emit(ty); }
+        }
+      } else {
+        emit(pos_base + my);
       }
       if (M) {
         emit(T_LADJ);
