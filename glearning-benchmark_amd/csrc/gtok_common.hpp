@@ -29,6 +29,16 @@ inline int resident_blocks(int api_answer) {
   return api_answer < cap ? api_answer : cap;
 }
 
+// same limit for kernels launched as one-wave workgroups: 4 SIMDs x 6 waves
+inline int resident_waves(int api_answer) {
+  int cap = 24;
+  if (const char *s = std::getenv("GTOK_MAX_WAVES_PER_CU")) {
+    const int c = std::atoi(s);
+    if (c >= 1) cap = c;
+  }
+  return api_answer < cap ? api_answer : cap;
+}
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -13,7 +13,9 @@
 //   sent_reg_kernel  (gtok_sent_reg.hpp)  WAVE per graph, <= 64 nodes, adjacency rows in registers (lane = node)
 //   sent_lds_kernel  (gtok_sent_lds.hpp)  WAVE per graph, up to 512 nodes, immutable adjacency bit matrix in LDS
 // This file is the launcher: LDS layout, kernel choice, grid sizing.
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "gtok_common.hpp"
 #include "gtok.h"
@@ -28,14 +30,35 @@ constexpr int GTOK_LANE_MIN_GRAPHS = 65536;     // measured crossover on ZINC-sh
 
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
+// Ticket counters of the dynamically scheduled kernels: a per-device ring of slots (kQueues counters + one
+// retired-wave counter each), zeroed once when the device is first used.  A launch takes the next slot and its last wave re-arms it, so a
+// slot is clean again when its launch has drained; kSlots launches may be in flight at once (any streams).
+// The first call on a device allocates (not capturable in a hipGraph: warm up once before capturing).
+static int *take_queue_slot(int dev) {
+  constexpr int kSlots = 256, kMaxDev = 64, kSlotInts = (kQueues + 1) * kQueueStride;
+  static std::mutex mu;
+  static int *ring[kMaxDev] = {};
+  static std::atomic<unsigned> seq{0};
+  if (dev < 0 || dev >= kMaxDev) return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ring[dev]) {
+      int *p = nullptr;
+      if (hipMalloc(reinterpret_cast<void **>(&p), kSlots * kSlotInts * sizeof(int)) != hipSuccess) return nullptr;
+      if (hipMemset(p, 0, kSlots * kSlotInts * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+      ring[dev] = p;
+    }
+  }
+  return ring[dev] + (size_t)kSlotInts * (seq.fetch_add(1, std::memory_order_relaxed) % kSlots);
+}
+
 // 0 = lane-per-graph, 1 = register-resident wave-per-graph, 2 = LDS bit matrix.  GTOK_SENT_KERNEL=lane|reg|lds
-// pins a kernel where it is applicable (tests run every path); GTOK_SENT_GENERIC=1 is the old spelling of "lds".
+// pins a kernel where it is applicable (tests run every path).
 static int choose_sent_kernel(const gtok_csr *g, const gtok_sent_params *p) {
   const int maxn = g->max_nodes > 0 ? g->max_nodes : 1;
-  const char *force = std::getenv("GTOK_SENT_GENERIC");
   const char *pin = std::getenv("GTOK_SENT_KERNEL");
   const bool pin_lane = pin && pin[0] == 'l' && pin[1] == 'a', pin_reg = pin && pin[0] == 'r';
-  const bool pin_lds = (pin && pin[0] == 'l' && pin[1] == 'd') || (force && force[0] == '1');
+  const bool pin_lds = pin && pin[0] == 'l' && pin[1] == 'd';
   const bool fold_ok = !p->remap_zinc || g->max_nodes <= p->max_num_nodes;   // remap folded into constants
   const bool lane_ok = maxn <= 64 && g->max_edges <= 255 && (g->flags & GTOK_CSR_SIMPLE_SYMMETRIC) && fold_ok;
   const bool reg_ok = maxn <= 64 && g->max_edges <= 32768 && fold_ok &&
@@ -72,44 +95,43 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   const int which = choose_sent_kernel(g, p);
   const bool lane_path = which == 0, reg_path = which == 1;
   if (lane_path) {
-    SentArgs a;
-    a.g = *g; a.p = *p; a.cap = cap; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
+    SentLaneArgs a;
+    a.g = *g; a.p = *p; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
     // staging sized by the largest 64-graph chunk when the host told us, else by the per-graph maxima
-    a.chunk_nodes = g->chunk_nodes > 0 ? g->chunk_nodes : 64 * maxn;
-    a.chunk_edges = g->chunk_edges > 0 ? g->chunk_edges : 64 * maxe;
-    a.chunk_rows = a.chunk_nodes + 64;
+    a.cap_n = g->chunk_nodes > 0 ? g->chunk_nodes : 64 * maxn;
+    a.cap_e = g->chunk_edges > 0 ? g->chunk_edges : 64 * maxe;
+    a.cap_r = a.cap_n + 64;
     int off = 0;
-    a.l.adj = a.l.rng = a.l.tok = 0;
-    a.l.rp = off; off += align_up(a.chunk_rows + 4, 16);
-    a.l.col = off; off += align_up(a.chunk_edges + 4, 16);   // +4: clamped look-ahead reads of an empty last row
-    a.l.eat = a.l.nat = off;
+    a.off_rp = off; off += align_up(a.cap_r + 4, 16);
+    a.off_col = off; off += align_up(a.cap_e + 4, 16);   // +4: clamped look-ahead reads of an empty last row
+    a.off_eat = a.off_nat = off;
     if (p->labeled) {
-      a.l.eat = off; off += align_up(a.chunk_edges + 4, 16);
-      a.l.nat = off; off += align_up(a.chunk_nodes, 16);
+      a.off_eat = off; off += align_up(a.cap_e + 4, 16);
+      a.off_nat = off; off += align_up(a.cap_n, 16);
     }
-    a.l.order = 0;
-    a.l.vidx = off; off += maxn * 64;
-    a.l.vis = off; off += maxn * 64;                       // rem[]
-    a.l.stride = align_up(off, 16);
-    if (a.l.stride > 64 * 1024) return GTOK_E_TOO_LARGE;
-    {
-      typedef void (*K)(const SentArgs);
-      K kern = p->labeled ? (K)sent_lane_kernel<true> : (K)sent_lane_kernel<false>;
-      int dev = 0, ncu = 256, occ = 1;
-      if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
-      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64,
-                                                       (size_t)a.l.stride) != hipSuccess || occ < 1)
-        occ = 1;
-      if (const char *cs = std::getenv("GTOK_LANE_BLOCKS_PER_CU")) { const int c = std::atoi(cs); if (c >= 1 && c < occ) occ = c; }
-      a.units = (g->num_graphs + 63) / 64;
-      int nb = ncu * occ;
-      if (nb > a.units) nb = a.units;
-      a.upb = (a.units + nb - 1) / nb;
-      nb = (a.units + a.upb - 1) / a.upb;
-      hipLaunchKernelGGL(kern, dim3(nb), dim3(64), (size_t)a.l.stride, (hipStream_t)stream, a);
-      return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+    a.off_vidx = off; off += maxn * 64;
+    a.off_rem = off; off += maxn * 64;
+    a.lds = align_up(off, 16);
+    if (a.lds > 64 * 1024) return GTOK_E_TOO_LARGE;
+    typedef void (*K)(const SentLaneArgs);
+    K kern = p->labeled ? (K)sent_lane_kernel<true> : (K)sent_lane_kernel<false>;
+    int dev = 0, ncu = 256, occ = 1;
+    if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64,
+                                                     (size_t)a.lds) != hipSuccess || occ < 1)
+      occ = 1;
+    if (const char *cs = std::getenv("GTOK_LANE_BLOCKS_PER_CU")) {   // tuning knob
+      const int c = std::atoi(cs);
+      if (c >= 1 && c < occ) occ = c;
     }
+    a.units = (g->num_graphs + 63) / 64;
+    int nb = ncu * occ;
+    if (nb > a.units) nb = a.units;
+    a.upb = (a.units + nb - 1) / nb;
+    nb = (a.units + a.upb - 1) / a.upb;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(64), (size_t)a.lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
   }
   SentArgs a;
   a.g = *g; a.p = *p; a.cap = cap; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
@@ -144,7 +166,8 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   }
   a.l.stride = align_up(off, 16);
   if (a.l.stride > 160 * 1024) return GTOK_E_TOO_LARGE;
-  int wpb = 4;
+  // sent_lds_kernel waves never cooperate and draw graphs from a queue: one wave per workgroup packs LDS best
+  int wpb = reg_path ? 4 : 1;
   while (wpb > 1 && wpb * a.l.stride > 64 * 1024) wpb >>= 1;
   const size_t lds = (size_t)wpb * a.l.stride;
 
@@ -179,12 +202,23 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern),
                                                    wpb * 64, lds) != hipSuccess || occ < 1)
     occ = 1;
-  occ = gtok::resident_blocks(occ);
-  a.units = (g->num_graphs + wpb - 1) / wpb;
-  int nb = ncu * occ;
-  if (nb > a.units) nb = a.units;
-  a.upb = (a.units + nb - 1) / nb;
-  nb = (a.units + a.upb - 1) / a.upb;
+  a.queue = nullptr;
+  int nb;
+  if (reg_path) {
+    occ = gtok::resident_blocks(occ);
+    a.units = (g->num_graphs + wpb - 1) / wpb;
+    nb = ncu * occ;
+    if (nb > a.units) nb = a.units;
+    a.upb = (a.units + nb - 1) / nb;
+    nb = (a.units + a.upb - 1) / a.upb;
+  } else {
+    occ = gtok::resident_waves(occ);     // one-wave workgroups
+    a.units = g->num_graphs; a.upb = 0;
+    nb = ncu * occ;
+    if (nb > a.units) nb = a.units;
+    a.queue = take_queue_slot(dev);
+    if (!a.queue) return GTOK_E_LAUNCH;
+  }
   hipLaunchKernelGGL(kern, dim3(nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }

@@ -31,12 +31,26 @@ __device__ __forceinline__ int kth_bit_serial(uint64_t w, int k) {   // per lane
   return __builtin_ctzll(w);
 }
 
+struct SentLaneArgs {
+  gtok_csr g;
+  gtok_sent_params p;
+  int off_rp, off_col, off_eat, off_nat;   // staged CSR chunk of the wave (u8): row pointers, neighbour ids, edge / node types
+  int off_vidx, off_rem;                   // u8 [maxn][64]: node -> visit index, unvisited neighbours left
+  int lds;                                 // bytes of LDS per 64-graph wave
+  int maxn;                                // rows of vidx / rem
+  int cap_r, cap_n, cap_e;                 // staging capacities: row pointers, nodes, entries of one 64-graph chunk
+  int32_t *out;
+  int ld;
+  int32_t *out_len;
+  int units, upb;                          // 64-graph units in the batch / per workgroup
+};
+
 template <bool LAB>
-__global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
+__global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  uint8_t *vidx = smem + a.l.vidx, *rem = smem + a.l.vis;
-  uint8_t *srp = smem + a.l.rp, *scol = smem + a.l.col, *seat = smem + a.l.eat, *snat = smem + a.l.nat;
+  uint8_t *vidx = smem + a.off_vidx, *rem = smem + a.off_rem;
+  uint8_t *srp = smem + a.off_rp, *scol = smem + a.off_col, *seat = smem + a.off_eat, *snat = smem + a.off_nat;
 #define AT(arr, i) (arr)[(i) * 64 + lane]
 
   const int lim = a.p.max_len, ld = a.ld, cap = min(lim, ld);
@@ -49,7 +63,7 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentArgs a) {
   const int T_RESET = remap ? 2 : GTOK_SENT_RESET, T_LADJ = remap ? 2 : GTOK_SENT_LADJ;
   const int T_RADJ = remap ? 2 : GTOK_SENT_RADJ, T_EOS = remap ? 1 : GTOK_SENT_EOS;
   const int G = a.g.num_graphs;
-  const int cap_r = a.chunk_rows, cap_e = a.chunk_edges, cap_n = a.chunk_nodes;   // staging capacities
+  const int cap_r = a.cap_r, cap_e = a.cap_e, cap_n = a.cap_n;   // staging capacities
 
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);

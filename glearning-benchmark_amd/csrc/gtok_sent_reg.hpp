@@ -27,8 +27,11 @@ struct SentArgs {
   int32_t *out_len;
   int units;      // ceil(G / waves_per_block)
   int upb;        // units per block
-  int chunk_rows, chunk_nodes, chunk_edges;   // lane-per-graph kernel: staging capacities of a 64-graph chunk
+  int *queue;     // sent_lds_kernel: kQueues ticket counters + a retired-wave counter, kQueueStride ints apart,
+                  // all 0 between launches
 };
+
+constexpr int kQueues = 16, kQueueStride = 32;   // 128 B apart: one cache line / memory channel each
 
 constexpr int kEdgeRef = 0x8000;  // tok entry = kEdgeRef | a << 6 | b : "edge type of (a,b)", resolved by the writer
 
