@@ -1,7 +1,10 @@
 // gtok_sent_lds.hpp — SENT walk for graphs of up to 64*W nodes (W = 1, 2, 4, 8): the adjacency lives in LDS as
-// an IMMUTABLE bit matrix adj[n][W]; the only walk state is the visited set, W 64-bit words in SGPRs, because
-// for a visited node c the uncovered edges are exactly adj[c] & ~vis, and a new node's neighbourhood bracket is
-// adj[v] & vis minus the trail edge just taken.  Decisions come from a register-resident,
+// an IMMUTABLE bit matrix adj[n][W]; the only walk state is the visited set, because for a visited node c the
+// uncovered edges are exactly adj[c] & ~vis, and a new node's neighbourhood bracket is adj[v] & vis minus the
+// trail edge just taken.  W-word sets are LANE-DISTRIBUTED: lane l holds word l % W of the
+// visited set and of every row it fetches, so a set operation is one VALU op for all W words, a cardinality
+// is a popcount + a log2(W)-step DPP prefix, and only the one word a decision lands in moves to SGPRs
+// (an earlier version kept all W words in SGPR pairs: ~150 scalar instructions per visit at W = 4).  Decisions come from a register-resident,
 // decision-major Philox block (64 decisions per refill); tokens go to an LDS row with unpredicated, ordered
 // all-lane stores (lane j -> slot pos+j, junk beyond the step's tokens is overwritten by later steps).
 // Same spec and token stream as sent_reg_kernel; bit-exact checker oracle/gtok_oracle.c:oracle_sent.
@@ -109,9 +112,11 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
     wave_sync();
 
     // ---- walk
-    uint64_t vis[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) vis[w] = 0;
+    constexpr uint64_t kGroup = W >= 64 ? ~0ull : ((1ull << W) - 1ull);   // lanes 0..W-1: one copy of a set
+    const int wl = lane & (W - 1);               // the word of a W-word set this lane holds
+    uint64_t vis = 0;                            // visited set, word wl
+    const int rem_n = n - wl * 64;
+    const uint64_t validw = rem_n >= 64 ? ~0ull : (rem_n > 0 ? ((1ull << rem_n) - 1ull) : 0ull);
     int pos = 1, d = 0, nvis = 0, cur = 0;
 
     auto below = [&](uint32_t nchoices) -> uint32_t {
@@ -124,23 +129,22 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
       }
       return __umulhi(x, nchoices);
     };
-    auto fetch_row = [&](int v, uint64_t (&r)[W]) {   // lanes 0..W-1 read one word each, then to SGPRs
-      const uint64_t mine = adj[v * W + (lane < W ? lane : 0)];
-#pragma unroll
-      for (int w = 0; w < W; ++w) r[w] = readlane64(mine, w);
+    // lanes 0..W-1: c[0] + ... + c[lane]  (row_shr DPP steps; lanes past W-1 hold junk nobody reads)
+    auto prefix = [&](int c) -> int {
+      int x = c;
+      if (W > 1) x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+      if (W > 2) x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+      if (W > 4) x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+      return x;
     };
-    auto pick = [&](const uint64_t (&m)[W], int k) -> int {   // k-th set bit across the W words
-      int res = 0;
-      bool done = false;
-#pragma unroll
-      for (int w = 0; w < W; ++w) {
-        const int c = __popcll(m[w]);
-        if (!done) {
-          if (k < c) { res = w * 64 + kth_bit_reg(m[w], k); done = true; }
-          else k -= c;
-        }
-      }
-      return res;
+    auto total_of = [&](int incl) -> int { return __builtin_amdgcn_readlane(incl, W - 1); };
+    // k-th member (ascending node id; k wave-uniform, below the set's size) of a distributed set with per-word
+    // counts c and inclusive prefix incl
+    auto member = [&](uint64_t set, int c, int incl, int k) -> int {
+      if (W == 1) return kth_bit_reg(readlane64(set, 0), k);
+      const int ws = __popcll((uint64_t)__ballot(incl <= k) & kGroup);
+      const int kk = k - __builtin_amdgcn_readlane(incl - c, ws);
+      return ws * 64 + kth_bit_reg(readlane64(set, ws), kk);
     };
     // edge type of (x,y), both wave-uniform: first listed entry x->y, else first y->x
     auto etype_uniform = [&](int x, int y) -> int {
@@ -165,8 +169,7 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
     // first visit of v; pred >= 0: reached over the trail edge (pred, v)
     auto visit = [&](int v, int pred) {
       if (is0) order[nvis] = (uint16_t)v;
-#pragma unroll
-      for (int w = 0; w < W; ++w) vis[w] |= (w == (v >> 6)) ? (1ull << (v & 63)) : 0ull;
+      vis |= (wl == (v >> 6)) ? (1ull << (v & 63)) : 0ull;
       if (LAB) {
         const int ty = node_off + natL[v];
         if (pred >= 0) {
@@ -188,16 +191,9 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
         pos += 1;
       }
       ++nvis;
-      uint64_t r[W];
-      fetch_row(v, r);
-      bool any = false;
-#pragma unroll
-      for (int w = 0; w < W; ++w) {
-        uint64_t aw = r[w] & vis[w];
-        if (pred >= 0 && w == (pred >> 6)) aw &= ~(1ull << (pred & 63));
-        any |= aw != 0;
-      }
-      if (!any) return;
+      // visited neighbours of v; pred is always one of them, so a bracket exists iff there are more
+      const int nback = total_of(prefix(__popcll(adj[v * W + wl] & vis)));
+      if (nback <= (pred >= 0 ? 1 : 0)) return;
       wave_sync();   // order[] written by lane 0 is read by every lane below
       int cnt = 0;
       for (int b0 = 0; b0 < nvis; b0 += kWave) {   // lane = visit index: members in ascending visit order
@@ -226,32 +222,35 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
       cur = (int)below((uint32_t)n);
       visit(cur, -1);
       while (pos < lim) {
-        uint64_t m[W];
-        fetch_row(cur, m);
-        int cnt = 0;
-#pragma unroll
-        for (int w = 0; w < W; ++w) { m[w] &= ~vis[w]; cnt += __popcll(m[w]); }
-        if (cnt) {   // extend the trail over an uncovered edge (always towards an unvisited node)
-          const int nxt = pick(m, (int)below((uint32_t)cnt));
-          visit(nxt, cur);
-          cur = nxt;
-          continue;
+        {   // extend the trail over an uncovered edge (always towards an unvisited node)
+          const uint64_t cand = adj[cur * W + wl] & ~vis;
+          const int c = __popcll(cand), incl = prefix(c), cnt = total_of(incl);
+          if (cnt) {
+            const int nxt = member(cand, c, incl, (int)below((uint32_t)cnt));
+            visit(nxt, cur);
+            cur = nxt;
+            continue;
+          }
         }
-        // dead end: visited nodes that still own uncovered edges
-        int total = 0;
+        // dead end: visited nodes that still own uncovered edges (lane = node; needs every vis word)
+        uint64_t visS[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) visS[w] = readlane64(vis, w);
+        uint64_t live = 0;
 #pragma unroll
         for (int c = 0; c < W; ++c) {
           const int v = c * 64 + lane;
           uint64_t anyw = 0;
           if (v < n) {
 #pragma unroll
-            for (int w = 0; w < W; ++w) anyw |= adj[v * W + w] & ~vis[w];
+            for (int w = 0; w < W; ++w) anyw |= adj[v * W + w] & ~visS[w];
           }
-          m[c] = (c * 64 < n) ? ((uint64_t)__ballot(anyw != 0) & vis[c]) : 0ull;
-          total += __popcll(m[c]);
+          const uint64_t mc = (c * 64 < n) ? ((uint64_t)__ballot(anyw != 0) & visS[c]) : 0ull;
+          live = (wl == c) ? mc : live;
         }
+        const int lc = __popcll(live), lincl = prefix(lc), total = total_of(lincl);
         if (total) {
-          cur = pick(m, (int)below((uint32_t)total));
+          cur = member(live, lc, lincl, (int)below((uint32_t)total));
           wave_sync();
           int kidx = 0;
           for (int b0 = 0; b0 < nvis; b0 += kWave) {   // its visit index
@@ -264,13 +263,9 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
           continue;
         }
         if (nvis < n) {  // another component or an isolated node
-#pragma unroll
-          for (int w = 0; w < W; ++w) {
-            const int rem = n - w * 64;
-            const uint64_t valid = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
-            m[w] = ~vis[w] & valid;
-          }
-          cur = pick(m, (int)below((uint32_t)(n - nvis)));
+          const uint64_t fresh = ~vis & validw;
+          const int fc = __popcll(fresh);
+          cur = member(fresh, fc, prefix(fc), (int)below((uint32_t)(n - nvis)));
           tok[pos + lane] = (uint16_t)GTOK_SENT_RESET;
           GTOK_TOK_ORDER();
           pos += 1;
