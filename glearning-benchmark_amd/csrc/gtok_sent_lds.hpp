@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
   const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
   unsigned char *base = smem + (size_t)wave * a.l.stride;
   uint64_t *adj = reinterpret_cast<uint64_t *>(base + a.l.adj);
-  uint16_t *order = reinterpret_cast<uint16_t *>(base + a.l.order);
+  uint16_t *order = reinterpret_cast<uint16_t *>(base + a.l.order);   // completed 64-blocks of the visit order
   uint16_t *tok = reinterpret_cast<uint16_t *>(base + a.l.tok);
   uint16_t *colL = reinterpret_cast<uint16_t *>(base + a.l.col);
   int32_t *rp = reinterpret_cast<int32_t *>(base + a.l.rp);     // labelled only
@@ -62,6 +62,9 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
   int g = settle(draw());
   while (g < G) {
     const int ticket = draw();
+#ifdef GTOK_PHASE_TIMING   // profiling build only: cycle stamps per phase, left in the row's last columns
+    const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+#endif
     const int nb0 = sload(a.g.node_ptr, g);
     const int nfull = sload(a.g.node_ptr, g + 1) - nb0;
     const int n = min(nfull, a.maxn);
@@ -94,6 +97,9 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
     };
     uint32_t R = draws(0);
     wave_sync();
+#ifdef GTOK_PHASE_TIMING
+    const uint64_t ts1 = __builtin_amdgcn_s_memtime();
+#endif
     for (int u = lane; u < n; u += kWave) {
       const int rs = rpg[u], re = rpg[u + 1];
       for (int k0e = rs; k0e < re; k0e += 4) {   // 4 neighbour reads in flight per round trip
@@ -110,11 +116,17 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
       }
     }
     wave_sync();
+#ifdef GTOK_PHASE_TIMING
+    const uint64_t ts2 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- walk
     constexpr uint64_t kGroup = W >= 64 ? ~0ull : ((1ull << W) - 1ull);   // lanes 0..W-1: one copy of a set
     const int wl = lane & (W - 1);               // the word of a W-word set this lane holds
     uint64_t vis = 0;                            // visited set, word wl
+    int ord = 0;                                 // lane k: the node visited (64*(nvis >> 6) + k)-th; completed
+                                                 // 64-blocks of the visit order move to order[] in LDS
+    uint64_t curw = 0;                           // word wl of the set {cur}
     const int rem_n = n - wl * 64;
     const uint64_t validw = rem_n >= 64 ? ~0ull : (rem_n > 0 ? ((1ull << rem_n) - 1ull) : 0ull);
     int pos = 1, d = 0, nvis = 0, cur = 0;
@@ -166,10 +178,13 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
         if (colL[k] == (uint16_t)x) return eatL[k];
       return 0;
     };
-    // first visit of v; pred >= 0: reached over the trail edge (pred, v)
-    auto visit = [&](int v, int pred) {
-      if (is0) order[nvis] = (uint16_t)v;
-      vis |= (wl == (v >> 6)) ? (1ull << (v & 63)) : 0ull;
+    // first visit of v; pred >= 0: reached over the trail edge (pred, v).  Returns v's adjacency row (word wl):
+    // the next trail step needs exactly that row, so it is fetched once.
+    auto visit = [&](int v, int pred) -> uint64_t {
+      ord = (lane == (nvis & 63)) ? v : ord;
+      const uint64_t predw = pred >= 0 ? curw : 0ull;   // callers pass pred = cur (or none)
+      curw = (wl == (v >> 6)) ? (1ull << (v & 63)) : 0ull;   // v becomes cur
+      vis |= curw;
       if (LAB) {
         const int ty = node_off + natL[v];
         if (pred >= 0) {
@@ -191,19 +206,17 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
         pos += 1;
       }
       ++nvis;
-      // visited neighbours of v; pred is always one of them, so a bracket exists iff there are more
-      const int nback = total_of(prefix(__popcll(adj[v * W + wl] & vis)));
-      if (nback <= (pred >= 0 ? 1 : 0)) return;
-      wave_sync();   // order[] written by lane 0 is read by every lane below
+      const int top = (nvis - 1) >> 6;               // the 64-block of the visit order still in `ord`
+      if ((nvis & 63) == 0) order[top * 64 + lane] = (uint16_t)ord;   // block complete: park it
+      const uint64_t rowv = adj[v * W + wl];
+      // visited neighbours of v other than pred: none -> no bracket
+      if (((uint64_t)__ballot((rowv & vis & ~predw) != 0) & kGroup) == 0) return rowv;
       int cnt = 0;
-      for (int b0 = 0; b0 < nvis; b0 += kWave) {   // lane = visit index: members in ascending visit order
-        const int k = b0 + lane;
-        int nb = 0;
-        bool member = false;
-        if (k < nvis) {
-          nb = order[k];
-          member = ((adj[v * W + (nb >> 6)] >> (nb & 63)) & 1ull) && nb != pred;
-        }
+      for (int c = 0; c <= top; ++c) {   // lane = visit index: members in ascending visit order
+        const int k = c * 64 + lane;
+        const int nb = c == top ? ord : (int)order[k];   // (stale lanes of ord hold in-range node ids)
+        const uint64_t word = adj[v * W + (nb >> 6)];
+        const bool member = k < nvis && ((word >> (nb & 63)) & 1ull) && nb != pred;
         const uint64_t M = __ballot(member);
         if (member) {
           const int q = pos + 1 + per * (cnt + mbcnt64(M));
@@ -215,19 +228,20 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
       if (is0) { tok[pos] = GTOK_SENT_LADJ; tok[pos + 1 + per * cnt] = GTOK_SENT_RADJ; }
       GTOK_TOK_ORDER();
       pos += 2 + per * cnt;
+      return rowv;
     };
 
     if (is0) tok[0] = GTOK_SENT_SOS;
     if (n > 0) {
       cur = (int)below((uint32_t)n);
-      visit(cur, -1);
+      uint64_t rowc = visit(cur, -1);   // adjacency row of cur, word wl
       while (pos < lim) {
         {   // extend the trail over an uncovered edge (always towards an unvisited node)
-          const uint64_t cand = adj[cur * W + wl] & ~vis;
+          const uint64_t cand = rowc & ~vis;
           const int c = __popcll(cand), incl = prefix(c), cnt = total_of(incl);
           if (cnt) {
             const int nxt = member(cand, c, incl, (int)below((uint32_t)cnt));
-            visit(nxt, cur);
+            rowc = visit(nxt, cur);
             cur = nxt;
             continue;
           }
@@ -251,11 +265,13 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
         const int lc = __popcll(live), lincl = prefix(lc), total = total_of(lincl);
         if (total) {
           cur = member(live, lc, lincl, (int)below((uint32_t)total));
-          wave_sync();
+          rowc = adj[cur * W + wl];
+          curw = (wl == (cur >> 6)) ? (1ull << (cur & 63)) : 0ull;
           int kidx = 0;
-          for (int b0 = 0; b0 < nvis; b0 += kWave) {   // its visit index
-            const uint64_t hit = __ballot(b0 + lane < nvis && order[b0 + lane] == (uint16_t)cur);
-            if (hit) { kidx = b0 + __builtin_ctzll(hit); break; }
+          for (int c = 0, top = (nvis - 1) >> 6; c <= top; ++c) {   // its visit index
+            const int nb = c == top ? ord : (int)order[c * 64 + lane];
+            const uint64_t hit = __ballot(c * 64 + lane < nvis && nb == cur);
+            if (hit) { kidx = c * 64 + __builtin_ctzll(hit); break; }
           }
           tok[pos + lane] = (uint16_t)(is0 ? GTOK_SENT_RESET : idx_off + kidx);
           GTOK_TOK_ORDER();
@@ -269,7 +285,7 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
           tok[pos + lane] = (uint16_t)GTOK_SENT_RESET;
           GTOK_TOK_ORDER();
           pos += 1;
-          visit(cur, -1);
+          rowc = visit(cur, -1);
           continue;
         }
         break;
@@ -279,6 +295,9 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
     GTOK_TOK_ORDER();
     pos += 1;
 
+#ifdef GTOK_PHASE_TIMING
+    const uint64_t ts3 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- row out
     const int ltrail = min(pos, lim);
     int len = ltrail;
@@ -293,6 +312,13 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
     });
     if (is0) a.out_len[g] = len;
     wave_sync();
+#ifdef GTOK_PHASE_TIMING
+    if (is0 && a.ld >= 8) {
+      const uint64_t ts4 = __builtin_amdgcn_s_memtime();
+      int32_t *row = a.out + (int64_t)g * a.ld + a.ld - 4;
+      row[0] = (int32_t)(ts1 - ts0); row[1] = (int32_t)(ts2 - ts1); row[2] = (int32_t)(ts3 - ts2); row[3] = (int32_t)(ts4 - ts3);
+    }
+#endif
     g = settle(ticket);
   }
   // every wave retires after its last draw; the last one out re-arms the slot for the next launch that gets it
