@@ -30,9 +30,9 @@ ZINC_FULL_GRAPHS = 249456      # 220,011 / 24,445 / 5,000 (SURVEY.md §8d config
 WORKLOADS = {
     "zinc_full": dict(graphs=ZINC_FULL_GRAPHS, desc="AGTT labelled SENT + fused ZINC remap, ZINC-full-shaped synthetic molecules"),
     "zinc_subset": dict(graphs=12000, desc="AGTT labelled SENT + fused ZINC remap, ZINC-subset-shaped synthetic molecules"),
-    # BASELINE config 5 shape (graph_generator.sh families, 10..256 nodes, sparsity 0.1-0.2, max_len 600); the
-    # default per-GPU count is 1/4 of the 125k a rank would hold of the 1M corpus, to keep generation short
-    "synth_er": dict(graphs=32768, desc="AGTT unlabelled SENT, Erdos-Renyi graph-token-shaped graphs, 10-256 nodes, max_len 600"),
+    # BASELINE config 5 shape (graph_generator.sh families, 10..256 nodes, sparsity 0.1-0.2, max_len 600):
+    # 125k graphs = one rank's share of the 1M-graph corpus on 8 GPUs (sampled on the GPU in ~6 s)
+    "synth_er": dict(graphs=125000, desc="AGTT unlabelled SENT, Erdos-Renyi graph-token-shaped graphs, 10-256 nodes, max_len 600"),
 }
 
 
