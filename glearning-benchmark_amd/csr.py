@@ -32,7 +32,9 @@ def _chunk_max(counts: np.ndarray, group: int = 64) -> int:
 
 
 def _simple_symmetric(gid_e: np.ndarray, src: np.ndarray, dst: np.ndarray, max_nodes: int) -> bool:
-    """True iff no (graph, u, v) entry is listed twice and every (u, v) has its (v, u)."""
+    """True iff there is no self-loop, no (graph, u, v) entry is listed twice and every (u, v) has its (v, u)."""
+    if (src == dst).any():
+        return False
     m = np.int64(max_nodes + 1)
     fwd = np.sort((gid_e * m + src) * m + dst)
     if fwd.size and (fwd[1:] == fwd[:-1]).any():
@@ -114,7 +116,7 @@ class GraphBatch:
     def from_coo(node_counts, edge_counts, src, dst, x=None, edge_attr=None, check_symmetric: bool = True) -> "GraphBatch":
         """Batched COO -> CSR.  src/dst are LOCAL node ids, edges of graph g are contiguous, in the
         order the source edge_index lists them (that order is kept in `eorder`).  check_symmetric: verify once
-        whether the rows are complete duplicate-free adjacency lists (sets GTOK_CSR_SIMPLE_SYMMETRIC)."""
+        whether the graphs are simple and stored in both directions (sets GTOK_CSR_SIMPLE_SYMMETRIC)."""
         node_counts = np.asarray(node_counts, dtype=np.int64).reshape(-1)
         edge_counts = np.asarray(edge_counts, dtype=np.int64).reshape(-1)
         src = np.asarray(src, dtype=np.int64).reshape(-1)

@@ -53,6 +53,51 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// 16-byte vectors for staging and fills.  I32x4 / U8x16 carry only the element alignment of the array they are
+// read from (a CSR chunk starts at an arbitrary element; gfx950 global accesses may be unaligned), U8x16a is
+// for 16-byte aligned LDS.
+struct __attribute__((packed, aligned(4))) I32x4 { int32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U8x16 { uint32_t a, b, c, d; };
+struct __attribute__((aligned(16))) U8x16a { uint32_t a, b, c, d; };
+
+// ---- dynamic work distribution ------------------------------------------------------------------------
+// Work units (graphs, or 64-graph groups) are handed to waves in index order from device-wide ticket counters:
+// walk length varies several-fold inside a batch, and a static split leaves waves idle behind the slowest.
+// One counter serialises at ~15 ns per draw (measured: 0.48 ms for 32768 draws), so a launch uses kQueues of
+// them on separate cache lines.  Every wave's first unit is its own index (no draw); ticket t of queue q is
+// unit first_free + t * kQueues + q.  A wave draws from its home queue and moves round-robin to the next when
+// one runs dry; the next ticket is drawn before the current unit is processed, which hides the round trip.
+// Counter block (host: take_queue_slot): kQueues counters + one retired-wave counter, kQueueStride ints apart,
+// all zero between launches - the last wave to retire re-arms it.
+constexpr int kQueues = 16, kQueueStride = 32;   // 128 B apart
+struct Tickets {
+  int *ctr;
+  int q, hops, first_free, limit;
+  __device__ __forceinline__ void init(int *counters, int wave_index, int num_waves, int num_units) {
+    ctr = counters; q = wave_index & (kQueues - 1); hops = 0; first_free = num_waves; limit = num_units;
+  }
+  __device__ __forceinline__ int draw(bool lane0) const {   // the ticket lands in lane 0's register
+    int t = 0;
+    if (lane0) t = atomicAdd(ctr + q * kQueueStride, 1);
+    return t;
+  }
+  __device__ __forceinline__ int settle(int t, bool lane0) {   // ticket -> unit; `limit` when every queue is dry
+    int u = first_free + uni(t) * kQueues + q;
+    while (u >= limit) {
+      if (++hops == kQueues) return limit;
+      q = (q + 1) & (kQueues - 1);
+      u = first_free + uni(draw(lane0)) * kQueues + q;
+    }
+    return u;
+  }
+  __device__ __forceinline__ void retire(bool lane0, int lane, int num_waves) const {   // after the last draw
+    int last = 0;
+    if (lane0) last = atomicAdd(ctr + kQueues * kQueueStride, 1) == num_waves - 1;
+    if (uni(last) && lane <= kQueues)
+      __hip_atomic_store(ctr + lane * kQueueStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
 __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }

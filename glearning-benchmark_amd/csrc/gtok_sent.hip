@@ -128,8 +128,8 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.units = (g->num_graphs + 63) / 64;
     int nb = ncu * occ;
     if (nb > a.units) nb = a.units;
-    a.upb = (a.units + nb - 1) / nb;
-    nb = (a.units + a.upb - 1) / a.upb;
+    a.queue = take_queue_slot(dev);
+    if (!a.queue) return GTOK_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64), (size_t)a.lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
   }

@@ -42,7 +42,8 @@ struct SentLaneArgs {
   int32_t *out;
   int ld;
   int32_t *out_len;
-  int units, upb;                          // 64-graph units in the batch / per workgroup
+  int units;                               // 64-graph units in the batch
+  int *queue;                              // ticket counter block (gtok_common.hpp: Tickets)
 };
 
 template <bool LAB>
@@ -65,55 +66,103 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
   const int G = a.g.num_graphs;
   const int cap_r = a.cap_r, cap_e = a.cap_e, cap_n = a.cap_n;   // staging capacities
 
-  const int vb = virtual_block();
-  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
-  for (int unit = u0; unit < u1; ++unit) {
-    const int g0 = unit * 64;
+  // Units are drawn dynamically (a unit's time is set by its longest walk), and the loop is software-pipelined:
+  // the loads of the NEXT unit's CSR chunk are issued before the CURRENT unit's padding stores.  vmcnt retires in
+  // order on gfx9-family parts, so loads issued behind 40 KB of stores would wait for HBM to take them; issued
+  // ahead, they return while the stores drain, and the stores drain behind the next walk (which loads nothing).
+  // Staging moves 16 bytes per lane and load (4 column ids / 4 row pointers / 16 type bytes); the first passes of
+  // all four arrays are in flight together.
+  const bool lane0 = lane == 0;
+  Tickets tickets;
+  tickets.init(a.queue, (int)blockIdx.x, (int)gridDim.x, a.units);
+  constexpr int UR = 8, UC = 16, UE = 4, UN = 2;   // 16-byte vectors per lane in flight: row pointers, column ids, types
+  I32x4 rv[UR], cv[UC];
+  U8x16 ev[UE], nv[UN];
+  // the staged unit: group bounds (uniform) and this lane's graph
+  int g0 = 0, gl = 0, N0 = 0, N1 = 0, nb0 = 0, nfull = 0, n = 0, e = 0;
+  int64_t E0 = 0, E1 = 0, e0 = 0;
+  bool valid = false;
+#define GTOK_LANE_ISSUE(UNIT, MORE)                                                                               \
+  {                                                                                                               \
+    /* no next unit: every register is still (re)defined - a conditional issue would keep the old vectors live   \
+       through the whole walk - from unit 0's addresses, with all counts zero */                                  \
+    g0 = (MORE) ? (UNIT) * 64 : 0;                                                                                \
+    gl = (MORE) ? min(g0 + 64, G) : 0;                                                                            \
+    N0 = sload(a.g.node_ptr, g0); N1 = sload(a.g.node_ptr, gl);                                                   \
+    E0 = sload(a.g.edge_ptr, g0); E1 = sload(a.g.edge_ptr, gl);                                                   \
+    valid = g0 + lane < G;                                                                                        \
+    nb0 = N0; nfull = 0; e0 = E0; e = 0;                                                                          \
+    if (valid) {                                                                                                  \
+      nb0 = a.g.node_ptr[g0 + lane];                                                                              \
+      nfull = a.g.node_ptr[g0 + lane + 1] - nb0;                                                                  \
+      e0 = a.g.edge_ptr[g0 + lane];                                                                               \
+      e = min((int)(a.g.edge_ptr[g0 + lane + 1] - e0), a.g.max_edges);                                            \
+    }                                                                                                             \
+    n = min(nfull, a.maxn);                                                                                       \
+    const int nrv_ = min((N1 - N0) + (gl - g0), cap_r) >> 2, ncv_ = (int)min(E1 - E0, (int64_t)cap_e) >> 2;       \
+    const int nev_ = LAB ? ncv_ >> 2 : 0, nnv_ = LAB ? min(N1 - N0, cap_n) >> 4 : 0;                              \
+    const I32x4 *rpv_ = reinterpret_cast<const I32x4 *>(a.g.rowptr + N0 + g0);                                    \
+    const I32x4 *ccv_ = reinterpret_cast<const I32x4 *>(a.g.col + E0);                                            \
+    const U8x16 *ecv_ = reinterpret_cast<const U8x16 *>(LAB ? a.g.eattr + E0 : nullptr);                          \
+    const U8x16 *ncv2_ = reinterpret_cast<const U8x16 *>(LAB ? a.g.nattr + N0 : nullptr);                         \
+    _Pragma("unroll") for (int j = 0; j < UR; ++j) { const int t = lane + j * kWave; rv[j] = t < nrv_ ? rpv_[t] : I32x4{0, 0, 0, 0}; } \
+    if (LAB) {                                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < UE; ++j) { const int t = lane + j * kWave; ev[j] = t < nev_ ? ecv_[t] : U8x16{0, 0, 0, 0}; } \
+      _Pragma("unroll") for (int j = 0; j < UN; ++j) { const int t = lane + j * kWave; nv[j] = t < nnv_ ? ncv2_[t] : U8x16{0, 0, 0, 0}; } \
+    }                                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < UC; ++j) { const int t = lane + j * kWave; cv[j] = t < ncv_ ? ccv_[t] : I32x4{0, 0, 0, 0}; } \
+  }
+
+  int unit = (int)blockIdx.x;
+  GTOK_LANE_ISSUE(unit, unit < a.units);
+  while (unit < a.units) {
+    const int ticket = tickets.draw(lane0);
+#ifdef GTOK_PHASE_TIMING   // profiling build only: cycle stamps per phase, left in the last columns of the unit's first row
+    const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+#endif
     const int g = g0 + lane;
-    const bool valid = g < G;
-    const int gl = min(g0 + 64, G);                        // one past the wave's last graph
-    const int N0 = sload(a.g.node_ptr, g0), N1 = sload(a.g.node_ptr, gl);
-    const int64_t E0 = sload(a.g.edge_ptr, g0), E1 = sload(a.g.edge_ptr, gl);
-    int nb0 = N0, nfull = 0, n = 0, e = 0;
-    int64_t e0 = E0;
-    if (valid) {
-      nb0 = a.g.node_ptr[g];
-      nfull = a.g.node_ptr[g + 1] - nb0;
-      n = min(nfull, a.maxn);
-      e0 = a.g.edge_ptr[g];
-      e = min((int)(a.g.edge_ptr[g + 1] - e0), a.g.max_edges);
-    }
-    // ---- stage the wave's CSR chunk: coalesced, independent loads (4 in flight per lane)
-    wave_sync();
+    // ---- commit the staged chunk to LDS (the previous unit's walk has finished reading it)
+    __builtin_amdgcn_wave_barrier();
     {
       const int cr = min((N1 - N0) + (gl - g0), cap_r);   // graph g's row pointers start at node_ptr[g] + g
-      const int32_t *__restrict__ rpc = a.g.rowptr + N0 + g0;
-      for (int i = lane; i < cr; i += 4 * kWave) {
-        int v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (i + j * kWave < cr) ? rpc[i + j * kWave] : 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (i + j * kWave < cr) srp[i + j * kWave] = (uint8_t)v[j];
-      }
       const int ce = (int)min(E1 - E0, (int64_t)cap_e);
+      const int cn = min(N1 - N0, cap_n);
+      const int32_t *__restrict__ rpc = a.g.rowptr + N0 + g0;
       const int32_t *__restrict__ cc = a.g.col + E0;
-      for (int i = lane; i < ce; i += 4 * kWave) {
-        int v[4], t[4];
+      const uint8_t *__restrict__ ec = LAB ? a.g.eattr + E0 : nullptr;
+      const uint8_t *__restrict__ nc = LAB ? a.g.nattr + N0 : nullptr;
+      const I32x4 *rpv = reinterpret_cast<const I32x4 *>(rpc), *ccv = reinterpret_cast<const I32x4 *>(cc);
+      const U8x16 *ecv = reinterpret_cast<const U8x16 *>(ec), *ncv = reinterpret_cast<const U8x16 *>(nc);
+      uint32_t *srp4 = reinterpret_cast<uint32_t *>(srp), *scol4 = reinterpret_cast<uint32_t *>(scol);
+      U8x16a *seat16 = reinterpret_cast<U8x16a *>(seat), *snat16 = reinterpret_cast<U8x16a *>(snat);
+      const int nrv = cr >> 2, ncv4 = ce >> 2, nev = LAB ? ce >> 4 : 0, nnv = LAB ? cn >> 4 : 0;
+      auto pack4 = [](const I32x4 &v) -> uint32_t {
+        return ((uint32_t)v.x & 255u) | (((uint32_t)v.y & 255u) << 8) | (((uint32_t)v.z & 255u) << 16) | ((uint32_t)v.w << 24);
+      };
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool in = i + j * kWave < ce;
-          v[j] = in ? cc[i + j * kWave] : 0;
-          t[j] = (LAB && in) ? (int)a.g.eattr[E0 + i + j * kWave] : 0;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (i + j * kWave < ce) { scol[i + j * kWave] = (uint8_t)v[j]; if (LAB) seat[i + j * kWave] = (uint8_t)t[j]; }
-      }
+      for (int j = 0; j < UR; ++j) { const int t = lane + j * kWave; if (t < nrv) srp4[t] = pack4(rv[j]); }
       if (LAB) {
-        const int cn = min(N1 - N0, cap_n);
-        for (int i = lane; i < cn; i += kWave) snat[i] = a.g.nattr[N0 + i];
+#pragma unroll
+        for (int j = 0; j < UE; ++j) { const int t = lane + j * kWave; if (t < nev) seat16[t] = U8x16a{ev[j].a, ev[j].b, ev[j].c, ev[j].d}; }
+#pragma unroll
+        for (int j = 0; j < UN; ++j) { const int t = lane + j * kWave; if (t < nnv) snat16[t] = U8x16a{nv[j].a, nv[j].b, nv[j].c, nv[j].d}; }
       }
+#pragma unroll
+      for (int j = 0; j < UC; ++j) { const int t = lane + j * kWave; if (t < ncv4) scol4[t] = pack4(cv[j]); }
+      // chunks longer than the vectors in flight (not molecules), then the last < 4 / < 16 elements of each array
+      for (int t = lane + UR * kWave; t < nrv; t += kWave) srp4[t] = pack4(rpv[t]);
+      for (int t = lane + UC * kWave; t < ncv4; t += kWave) scol4[t] = pack4(ccv[t]);
+      for (int t = lane + UE * kWave; t < nev; t += kWave) { const U8x16 x = ecv[t]; seat16[t] = U8x16a{x.a, x.b, x.c, x.d}; }
+      for (int t = lane + UN * kWave; t < nnv; t += kWave) { const U8x16 x = ncv[t]; snat16[t] = U8x16a{x.a, x.b, x.c, x.d}; }
+      if (lane < (cr & 3)) srp[(nrv << 2) + lane] = (uint8_t)rpc[(nrv << 2) + lane];
+      if (lane < (ce & 3)) scol[(ncv4 << 2) + lane] = (uint8_t)cc[(ncv4 << 2) + lane];
+      if (LAB && lane < (ce & 15)) seat[(nev << 4) + lane] = ec[(nev << 4) + lane];
+      if (LAB && lane < (cn & 15)) snat[(nnv << 4) + lane] = nc[(nnv << 4) + lane];
     }
     wave_sync();
+#ifdef GTOK_PHASE_TIMING
+    const uint64_t ts1 = __builtin_amdgcn_s_memtime();
+#endif
     const uint8_t *rpl = srp + (nb0 - N0) + lane;          // this lane's row pointers, neighbour ids, types
     const uint8_t *cl = scol + (int)(e0 - E0), *el = seat + (int)(e0 - E0), *nl = snat + (nb0 - N0);
     // A node's row: bounds + its first four neighbour ids in registers (one LDS round trip each); molecules
@@ -147,8 +196,12 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
       for (int t = r.rs + 4; t < r.re; ++t) if (cl[t] == (uint8_t)y) k = t;
       return k;
     };
-    for (int u = 0; u < n; ++u) AT(rem, u) = (uint8_t)__popcll(row_mask(load_row(u)) & ~(1ull << u));
+    // GTOK_CSR_SIMPLE_SYMMETRIC: no self-loops, no duplicates -> a node's unvisited-neighbour count starts at its degree
+    for (int u = 0; u < n; ++u) AT(rem, u) = (uint8_t)max(min((int)rpl[u + 1], e) - (int)rpl[u], 0);
 
+#ifdef GTOK_PHASE_TIMING
+    const uint64_t ts2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- walk (per lane; mirrors oracle_sent step for step)
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
     const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
@@ -194,17 +247,13 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (j < deg) {
-          if (u[j] == v) { M |= 1ull << my; }            // self loop: v lists itself, last (largest visit index)
-          else {
-            AT(rem, u[j]) = (uint8_t)(rm[j] - 1);         // one unvisited neighbour fewer for u
-            if (rm[j] == 1) live &= ~(1ull << u[j]);
-            if (((vis >> u[j]) & 1ull) && u[j] != pred) M |= 1ull << vx[j];
-          }
+          AT(rem, u[j]) = (uint8_t)(rm[j] - 1);           // one unvisited neighbour fewer for u
+          if (rm[j] == 1) live &= ~(1ull << u[j]);
+          if (((vis >> u[j]) & 1ull) && u[j] != pred) M |= 1ull << vx[j];
         }
       }
       for (int k = r.rs + 4; k < r.re; ++k) {             // long rows: scalar tail
         const int w = cl[k];
-        if (w == v) { M |= 1ull << my; continue; }
         const int q = (int)AT(rem, w) - 1;
         AT(rem, w) = (uint8_t)q;
         if (q == 0) live &= ~(1ull << w);
@@ -236,12 +285,12 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
           int kk = r.rs;
 #pragma unroll
           for (int j = 3; j >= 0; --j) {
-            const bool hit = j < deg && (u[j] == v ? k == my : (((vis_before >> u[j]) & 1ull) && vx[j] == k && u[j] != pred));
+            const bool hit = j < deg && ((vis_before >> u[j]) & 1ull) && vx[j] == k && u[j] != pred;
             kk = hit ? r.rs + j : kk;
           }
           for (int t = r.rs + 4; t < r.re; ++t) {
             const int w = cl[t];
-            if (w == v ? k == my : (((vis_before >> w) & 1ull) && AT(vidx, w) == k && w != pred)) kk = t;
+            if (((vis_before >> w) & 1ull) && AT(vidx, w) == k && w != pred) kk = t;
           }
           if (LAB) emit(edge_tok(el[kk]));
           emit(pos_base + k);
@@ -288,15 +337,40 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
     }
     if (valid) a.out_len[g] = len;
 
-    // ---- pad tails of the wave's 64 rows, coalesced
-    const int lw = min(len, ld);
-    for (int j = 0; j < 64; ++j) {
-      if (g0 + j >= G) break;
-      const int lj = __builtin_amdgcn_readlane(lw, j);
-      int32_t *__restrict__ r = a.out + (int64_t)(g0 + j) * ld;
-      for (int i = lj + lane; i < ld; i += kWave) r[i] = a.p.pad_id;
+#ifdef GTOK_PHASE_TIMING
+    const uint64_t ts3 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- next unit: its loads go out ahead of this unit's padding stores
+    const int lw = min(len, ld), done_g0 = g0;
+    unit = tickets.settle(ticket, lane0);
+    GTOK_LANE_ISSUE(unit, unit < a.units);
+    // ---- pad the tails of the finished unit's 64 rows: four rows per pass, 16 lanes x 16-byte stores on each.
+    // (Filling the unit's whole slab region up front was tried: every wave of a round then writes 51 KB at the
+    // same moment and stalls ~30 us behind HBM; row-at-a-time 4-byte stores cost 27k cycles of loop overhead.)
+    {
+      const int q = lane & 15, pad = a.p.pad_id;
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 4 + (lane >> 4);
+        const int lr = __builtin_amdgcn_ds_bpermute(r << 2, lw);
+        if (done_g0 + it * 4 >= G) break;
+        if (done_g0 + r < G) {
+          int32_t *__restrict__ row = a.out + (int64_t)(done_g0 + r) * ld + lr;
+          const int nrem = ld - lr, nvec = nrem >> 2;
+          for (int t = q; t < nvec; t += 16) reinterpret_cast<I32x4 *>(row)[t] = I32x4{pad, pad, pad, pad};
+          if (q < (nrem & 3)) row[(nvec << 2) + q] = pad;
+        }
+      }
     }
+#ifdef GTOK_PHASE_TIMING
+    if (lane0 && ld >= 8) {
+      const uint64_t ts4 = __builtin_amdgcn_s_memtime();
+      int32_t *row = a.out + (int64_t)done_g0 * ld + ld - 4;
+      row[0] = (int32_t)(ts1 - ts0); row[1] = (int32_t)(ts2 - ts1); row[2] = (int32_t)(ts3 - ts2); row[3] = (int32_t)(ts4 - ts3);
+    }
+#endif
   }
+#undef GTOK_LANE_ISSUE
+  tickets.retire(lane0, lane, (int)gridDim.x);
 #undef AT
 }
 

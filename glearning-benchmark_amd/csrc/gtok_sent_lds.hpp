@@ -37,31 +37,13 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
   const bool is0 = lane == 0, is1 = lane == 1;
 #define GTOK_TOK_ORDER() asm volatile("" ::: "memory")
 
-  // Graphs are handed out one at a time from device-wide ticket counters: walk length varies by more than
-  // 10x inside a batch (10..256 nodes), and a static split left the average wave idle for a quarter of the
-  // launch.  One counter serialises at ~15 ns per draw (measured: 0.48 ms for 32768 draws), so there are
-  // kQueues of them on separate cache lines; queue q owns graphs q, q+kQueues, ...  A wave starts on its home
-  // queue and moves round-robin to the next one when it runs dry; the next ticket is drawn before the current
-  // graph is processed, so the round trip is hidden.
-  const int G = a.g.num_graphs;
-  int q = (int)(blockIdx.x * wpb + wave) & (kQueues - 1), hops = 0;
-  auto draw = [&]() -> int {
-    int t = 0;
-    if (is0) t = atomicAdd(a.queue + q * kQueueStride, 1);
-    return t;
-  };
-  auto settle = [&](int t) -> int {   // ticket -> graph, moving on from dry queues; G when all are dry
-    int g = uni(t) * kQueues + q;
-    while (g >= G) {
-      if (++hops == kQueues) return G;
-      q = (q + 1) & (kQueues - 1);
-      g = uni(draw()) * kQueues + q;
-    }
-    return g;
-  };
-  int g = settle(draw());
+  // graphs are drawn one at a time (gtok_common.hpp: Tickets): 10..256-node graphs differ >10x in walk length
+  const int G = a.g.num_graphs, nwaves = (int)(gridDim.x * wpb), wave_index = (int)(blockIdx.x * wpb + wave);
+  Tickets tickets;
+  tickets.init(a.queue, wave_index, nwaves, G);
+  int g = wave_index;
   while (g < G) {
-    const int ticket = draw();
+    const int ticket = tickets.draw(is0);
 #ifdef GTOK_PHASE_TIMING   // profiling build only: cycle stamps per phase, left in the row's last columns
     const uint64_t ts0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -319,13 +301,9 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
       row[0] = (int32_t)(ts1 - ts0); row[1] = (int32_t)(ts2 - ts1); row[2] = (int32_t)(ts3 - ts2); row[3] = (int32_t)(ts4 - ts3);
     }
 #endif
-    g = settle(ticket);
+    g = tickets.settle(ticket, is0);
   }
-  // every wave retires after its last draw; the last one out re-arms the slot for the next launch that gets it
-  int last = 0;
-  if (is0) last = atomicAdd(a.queue + kQueues * kQueueStride, 1) == (int)(gridDim.x * wpb) - 1;
-  if (uni(last) && lane <= kQueues)
-    __hip_atomic_store(a.queue + lane * kQueueStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tickets.retire(is0, lane, nwaves);
 #undef GTOK_TOK_ORDER
 }
 

@@ -27,11 +27,8 @@ struct SentArgs {
   int32_t *out_len;
   int units;      // ceil(G / waves_per_block)
   int upb;        // units per block
-  int *queue;     // sent_lds_kernel: kQueues ticket counters + a retired-wave counter, kQueueStride ints apart,
-                  // all 0 between launches
+  int *queue;     // sent_lds_kernel: ticket counter block (gtok_common.hpp: Tickets)
 };
-
-constexpr int kQueues = 16, kQueueStride = 32;   // 128 B apart: one cache line / memory channel each
 
 constexpr int kEdgeRef = 0x8000;  // tok entry = kEdgeRef | a << 6 | b : "edge type of (a,b)", resolved by the writer
 

@@ -66,8 +66,10 @@ extern "C" {
 #define GTOK_MAX_NODES 512 /* SENT adjacency bit-matrix rows per wave (LDS)  */
 
 /* flags: properties the HOST has verified for the whole batch */
-#define GTOK_CSR_SIMPLE_SYMMETRIC 1 /* no entry listed twice, and (v,u) is listed whenever (u,v) is: the rows
-                                       are complete adjacency lists (PyG-coalesced undirected graphs)          */
+#define GTOK_CSR_SIMPLE_SYMMETRIC 1 /* simple undirected graphs, both directions stored: no self-loop, no entry
+                                       listed twice, and (v,u) is listed whenever (u,v) is - every row is the
+                                       node's complete neighbour list (PyG-coalesced molecules).  A batch flagged
+                                       wrongly gets wrong tokens (never an out-of-bounds access).                */
 
 typedef struct gtok_csr {
   int32_t num_graphs;
