@@ -10,7 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 namespace gtok {
 
@@ -98,6 +100,28 @@ struct Tickets {
       __hip_atomic_store(ctr + lane * kQueueStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
+
+// Ticket counters of the dynamically scheduled kernels: a per-device ring of slots (kQueues counters + one
+// retired-wave counter each), zeroed once when the device is first used.  A launch takes the next slot and its last wave re-arms it, so a
+// slot is clean again when its launch has drained; kSlots launches may be in flight at once (any streams).
+// The first call on a device allocates (not capturable in a hipGraph: warm up once before capturing).
+inline int *take_queue_slot(int dev) {
+  constexpr int kSlots = 256, kMaxDev = 64, kSlotInts = (kQueues + 1) * kQueueStride;
+  static std::mutex mu;
+  static int *ring[kMaxDev] = {};
+  static std::atomic<unsigned> seq{0};
+  if (dev < 0 || dev >= kMaxDev) return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ring[dev]) {
+      int *p = nullptr;
+      if (hipMalloc(reinterpret_cast<void **>(&p), kSlots * kSlotInts * sizeof(int)) != hipSuccess) return nullptr;
+      if (hipMemset(p, 0, kSlots * kSlotInts * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+      ring[dev] = p;
+    }
+  }
+  return ring[dev] + (size_t)kSlotInts * (seq.fetch_add(1, std::memory_order_relaxed) % kSlots);
+}
 __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }

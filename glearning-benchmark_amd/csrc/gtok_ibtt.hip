@@ -189,8 +189,12 @@ __global__ void __launch_bounds__(256) ibtt_zinc_kernel(const ZincArgs a) {
 // v, and row order is list order, so "first occurrence wins" (zinc_dataset_indexbase.py:176-184) keeps exactly
 // the entries with u <= v.  Each lane then streams its own molecule: <bos>, 2 tokens per atom, one 16-byte
 // store per kept bond (<bond> TYPE u v), the 3-token tail — ~40 instructions per molecule instead of ~570.
-// The wave's 64 molecules are one contiguous CSR chunk, staged in LDS with coalesced loads (as in
-// gtok_sent_lane.hpp); the LUT sits in LDS too.  Same ids as ibtt_zinc_kernel, same oracle.
+// The wave's 64 molecules are one contiguous CSR chunk, staged in LDS with 16-byte loads (as in
+// gtok_sent_lane.hpp); the LUT sits in LDS too.  Bond types are staged as NIBBLES (min(type, 15): the grammar
+// only tells types 1..4 from "anything else"), which brings a ZINC wave to <= 10 KB of LDS = 16 waves per CU =
+// 4096 resident waves, more than ZINC-full's 3898 units: the whole corpus runs in ONE round (the kernel is
+// bound by per-unit latency, so a second, 2 %-full round used to double its time).  Units beyond the resident
+// waves are drawn from the ticket queues.  Same ids as ibtt_zinc_kernel, same oracle.
 struct ZincLaneArgs {
   gtok_csr g;
   const int32_t *lut;
@@ -198,21 +202,35 @@ struct ZincLaneArgs {
   int off_rp, off_col, off_eat, off_nat, off_lut, lds;   // byte offsets of the wave's staging areas
   int cap_r, cap_n, cap_e;
   int32_t *out; int ld; int32_t *out_len;
-  int units, upb;
+  int units;
+  int *queue;   // ticket counter block (gtok_common.hpp: Tickets)
 };
 
-__global__ void __launch_bounds__(64, 2) ibtt_zinc_lane_kernel(const ZincLaneArgs a) {
+// 4 type bytes -> 4 nibbles (16 bits), each min(byte, 15)
+__device__ __forceinline__ uint32_t nibbles4(uint32_t x) {
+  uint32_t hi = x & 0xF0F0F0F0u;
+  hi |= hi >> 1; hi |= hi >> 2;                       // any high bit set -> whole high nibble set
+  uint32_t y = (x | (hi >> 4)) & 0x0F0F0F0Fu;           // saturate
+  y = (y | (y >> 4)) & 0x00FF00FFu;
+  return (y | (y >> 8)) & 0xFFFFu;
+}
+
+// <= 128 VGPRs: 4 waves per SIMD, so that LDS (<= 10 KB) and not registers sets the 16 waves per CU
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) ibtt_zinc_lane_kernel(const ZincLaneArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
+  const bool lane0 = lane == 0;
   uint8_t *srp = smem + a.off_rp, *scol = smem + a.off_col, *seat = smem + a.off_eat, *snat = smem + a.off_nat;
   int32_t *slut = reinterpret_cast<int32_t *>(smem + a.off_lut);
   const int ld = a.ld, cap = min(a.max_len, ld), pad = a.pad_id, G = a.g.num_graphs;
   const bool has_ea = a.g.eattr != nullptr, has_na = a.g.nattr != nullptr;
 
   for (int i = lane; i < a.lut_len; i += kWave) slut[i] = a.lut[i];
-  const int vb = virtual_block();
-  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
-  for (int unit = u0; unit < u1; ++unit) {
+  Tickets tickets;
+  tickets.init(a.queue, (int)blockIdx.x, (int)gridDim.x, a.units);
+  int unit = (int)blockIdx.x;
+  while (unit < a.units) {
+    const int ticket = tickets.draw(lane0);
     const int g0 = unit * 64, g = g0 + lane, gl = min(g0 + 64, G);
     const bool valid = g < G;
     const int N0 = sload(a.g.node_ptr, g0), N1 = sload(a.g.node_ptr, gl);
@@ -223,35 +241,68 @@ __global__ void __launch_bounds__(64, 2) ibtt_zinc_lane_kernel(const ZincLaneArg
       nb0 = a.g.node_ptr[g]; n = a.g.node_ptr[g + 1] - nb0;
       e0 = a.g.edge_ptr[g]; e = (int)(a.g.edge_ptr[g + 1] - e0);
     }
-    wave_sync();
-    {  // stage the chunk: coalesced, independent loads
+    __builtin_amdgcn_wave_barrier();   // the previous unit's lanes are done reading the staging areas
+    {  // stage the chunk: 16 bytes per lane and load, every first-pass load issued before the first wait
       const int cr = min((N1 - N0) + (gl - g0), a.cap_r);
-      const int32_t *__restrict__ rpc = a.g.rowptr + N0 + g0;
-      for (int i = lane; i < cr; i += 4 * kWave) {
-        int v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (i + j * kWave < cr) ? rpc[i + j * kWave] : 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (i + j * kWave < cr) srp[i + j * kWave] = (uint8_t)v[j];
-      }
       const int ce = (int)min(E1 - E0, (int64_t)a.cap_e);
-      const int32_t *__restrict__ cc = a.g.col + E0;
-      for (int i = lane; i < ce; i += 4 * kWave) {
-        int v[4], t[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool in = i + j * kWave < ce;
-          v[j] = in ? cc[i + j * kWave] : 0;
-          t[j] = (has_ea && in) ? (int)a.g.eattr[E0 + i + j * kWave] : 0;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (i + j * kWave < ce) { scol[i + j * kWave] = (uint8_t)v[j]; seat[i + j * kWave] = (uint8_t)t[j]; }
-      }
       const int cn = min(N1 - N0, a.cap_n);
-      for (int i = lane; i < cn; i += kWave) snat[i] = has_na ? a.g.nattr[N0 + i] : (uint8_t)255;
+      const int32_t *__restrict__ rpc = a.g.rowptr + N0 + g0;
+      const int32_t *__restrict__ cc = a.g.col + E0;
+      const uint8_t *__restrict__ ec = has_ea ? a.g.eattr + E0 : nullptr;
+      const uint8_t *__restrict__ nc = has_na ? a.g.nattr + N0 : nullptr;
+      const I32x4 *rpv = reinterpret_cast<const I32x4 *>(rpc), *ccv = reinterpret_cast<const I32x4 *>(cc);
+      const U8x16 *ecv = reinterpret_cast<const U8x16 *>(ec), *ncv = reinterpret_cast<const U8x16 *>(nc);
+      uint32_t *srp4 = reinterpret_cast<uint32_t *>(srp), *scol4 = reinterpret_cast<uint32_t *>(scol);
+      uint2 *seat8 = reinterpret_cast<uint2 *>(seat);
+      U8x16a *snat16 = reinterpret_cast<U8x16a *>(snat);
+      const int nrv = cr >> 2, ncv4 = ce >> 2, nev = ce >> 4, nnv = cn >> 4;
+      auto pack4 = [](const I32x4 &v) -> uint32_t {
+        return ((uint32_t)v.x & 255u) | (((uint32_t)v.y & 255u) << 8) | (((uint32_t)v.z & 255u) << 16) | ((uint32_t)v.w << 24);
+      };
+      auto nib16 = [](const U8x16 &x) -> uint2 {
+        return make_uint2(nibbles4(x.a) | (nibbles4(x.b) << 16), nibbles4(x.c) | (nibbles4(x.d) << 16));
+      };
+      constexpr int UR = 4, UC = 8, UE = 4, UN = 2;   // vectors in flight per lane
+      I32x4 rv[UR], cv[UC];
+      U8x16 ev[UE], nv[UN];
+#pragma unroll
+      for (int j = 0; j < UR; ++j) { const int t = lane + j * kWave; rv[j] = t < nrv ? rpv[t] : I32x4{0, 0, 0, 0}; }
+#pragma unroll
+      for (int j = 0; j < UE; ++j) { const int t = lane + j * kWave; ev[j] = (has_ea && t < nev) ? ecv[t] : U8x16{0, 0, 0, 0}; }
+#pragma unroll
+      for (int j = 0; j < UN; ++j) { const int t = lane + j * kWave; nv[j] = (has_na && t < nnv) ? ncv[t] : U8x16{~0u, ~0u, ~0u, ~0u}; }
+#pragma unroll
+      for (int j = 0; j < UC; ++j) { const int t = lane + j * kWave; cv[j] = t < ncv4 ? ccv[t] : I32x4{0, 0, 0, 0}; }
+#pragma unroll
+      for (int j = 0; j < UR; ++j) { const int t = lane + j * kWave; if (t < nrv) srp4[t] = pack4(rv[j]); }
+#pragma unroll
+      for (int j = 0; j < UE; ++j) { const int t = lane + j * kWave; if (t < nev) seat8[t] = nib16(ev[j]); }
+#pragma unroll
+      for (int j = 0; j < UN; ++j) { const int t = lane + j * kWave; if (t < nnv) snat16[t] = U8x16a{nv[j].a, nv[j].b, nv[j].c, nv[j].d}; }
+#pragma unroll
+      for (int j = 0; j < UC; ++j) { const int t = lane + j * kWave; if (t < ncv4) scol4[t] = pack4(cv[j]); }
+      // chunks longer than the vectors in flight (not molecules), then the last < 4 / < 16 elements of each array
+      for (int t = lane + UR * kWave; t < nrv; t += kWave) srp4[t] = pack4(rpv[t]);
+      for (int t = lane + UC * kWave; t < ncv4; t += kWave) scol4[t] = pack4(ccv[t]);
+      for (int t = lane + UE * kWave; t < nev; t += kWave) seat8[t] = has_ea ? nib16(ecv[t]) : make_uint2(0u, 0u);
+      for (int t = lane + UN * kWave; t < nnv; t += kWave) {
+        const U8x16 x = has_na ? ncv[t] : U8x16{~0u, ~0u, ~0u, ~0u};
+        snat16[t] = U8x16a{x.a, x.b, x.c, x.d};
+      }
+      if (lane < (cr & 3)) srp[(nrv << 2) + lane] = (uint8_t)rpc[(nrv << 2) + lane];
+      if (lane < (ce & 3)) scol[(ncv4 << 2) + lane] = (uint8_t)cc[(ncv4 << 2) + lane];
+      if (lane < (cn & 15)) snat[(nnv << 4) + lane] = has_na ? nc[(nnv << 4) + lane] : (uint8_t)255;
+      {  // last < 16 bond types: one per lane, even lanes pair theirs with the right neighbour's
+        const int rest = ce & 15;
+        uint32_t x = (has_ea && lane < rest) ? (uint32_t)ec[(nev << 4) + lane] : 0u;
+        x = x > 15u ? 15u : x;
+        const uint32_t right = (uint32_t)__shfl_down((int)x, 1);
+        if (lane < rest && !(lane & 1)) seat[(nev << 3) + (lane >> 1)] = (uint8_t)(x | (right << 4));
+      }
     }
     wave_sync();
-    const uint8_t *rpl = srp + (nb0 - N0) + lane, *cl = scol + (int)(e0 - E0), *el = seat + (int)(e0 - E0), *nl = snat + (nb0 - N0);
+    const uint8_t *rpl = srp + (nb0 - N0) + lane, *cl = scol + (int)(e0 - E0), *nl = snat + (nb0 - N0);
+    const int eo = (int)(e0 - E0);   // this lane's first entry inside the chunk (nibble index)
     int32_t *__restrict__ orow = a.out + (int64_t)g * ld;
     auto node_id = [&](int i) { return (GTOK_ZLUT_NODE0 + i < a.lut_len) ? slut[GTOK_ZLUT_NODE0 + i] : pad; };
 
@@ -272,7 +323,7 @@ __global__ void __launch_bounds__(64, 2) ibtt_zinc_lane_kernel(const ZincLaneArg
         while (k >= row_end && u + 1 < n) { ++u; row_end = rpl[u + 1]; }
         const int v = cl[k];
         if (u <= v) {   // first occurrence of {u,v}: zinc_dataset_indexbase.py:176-184
-          const int at = el[k];
+          const int at = (seat[(eo + k) >> 1] >> (((eo + k) & 1) << 2)) & 15;
           const int t1 = slut[GTOK_ZLUT_BOND0 + ((at >= 1 && at <= 4) ? at : 0)], t2 = node_id(u), t3 = node_id(v);
           if (pos + 3 < cap) {
             *reinterpret_cast<int4 *>(orow + pos) = make_int4(t_bond, t1, t2, t3);   // dword-aligned 16-byte store
@@ -296,14 +347,23 @@ __global__ void __launch_bounds__(64, 2) ibtt_zinc_lane_kernel(const ZincLaneArg
       }
       a.out_len[g] = len;
     }
-    const int lw = min(len, ld);
-    for (int j = 0; j < 64; ++j) {   // pad tails of the wave's 64 rows, coalesced
-      if (g0 + j >= G) break;
-      const int lj = __builtin_amdgcn_readlane(lw, j);
-      int32_t *__restrict__ r = a.out + (int64_t)(g0 + j) * ld;
-      for (int i = lj + lane; i < ld; i += kWave) r[i] = pad;
+    {  // pad the tails of the unit's 64 rows: four rows per pass, 16 lanes x 16-byte stores on each
+      const int lw = min(len, ld), q = lane & 15;
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 4 + (lane >> 4);
+        const int lr = __builtin_amdgcn_ds_bpermute(r << 2, lw);
+        if (g0 + it * 4 >= G) break;
+        if (g0 + r < G) {
+          int32_t *__restrict__ row = a.out + (int64_t)(g0 + r) * ld + lr;
+          const int nrem = ld - lr, nvec = nrem >> 2;
+          for (int t = q; t < nvec; t += 16) reinterpret_cast<I32x4 *>(row)[t] = I32x4{pad, pad, pad, pad};
+          if (q < (nrem & 3)) row[(nvec << 2) + q] = pad;
+        }
+      }
     }
+    unit = tickets.settle(ticket, lane0);
   }
+  tickets.retire(lane0, lane, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -566,13 +626,13 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
       int off = 0;
       z.off_rp = off; off += align_up(z.cap_r + 4, 16);
       z.off_col = off; off += align_up(z.cap_e + 4, 16);
-      z.off_eat = off; off += align_up(z.cap_e + 4, 16);
+      z.off_eat = off; off += align_up((z.cap_e + 1) / 2 + 8, 16);   // nibbles
       z.off_nat = off; off += align_up(z.cap_n + 4, 16);
       z.off_lut = off; off += align_up(lut_len * 4, 16);
       z.lds = off;
       if (z.lds <= 64 * 1024) {
         int dev = 0, ncu = 256, occ = 1;
-        (void)hipGetDevice(&dev);
+        if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(ibtt_zinc_lane_kernel), 64,
                                                          (size_t)z.lds) != hipSuccess || occ < 1)
@@ -580,8 +640,8 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
         z.units = (g->num_graphs + 63) / 64;
         int nb = ncu * occ;
         if (nb > z.units) nb = z.units;
-        z.upb = (z.units + nb - 1) / nb;
-        nb = (z.units + z.upb - 1) / z.upb;
+        z.queue = gtok::take_queue_slot(dev);
+        if (!z.queue) return GTOK_E_LAUNCH;
         z.out = out_ids; z.ld = ld; z.out_len = out_len;
         hipLaunchKernelGGL(ibtt_zinc_lane_kernel, dim3(nb), dim3(64), (size_t)z.lds, (hipStream_t)stream, z);
         return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;

@@ -13,9 +13,7 @@
 //   sent_reg_kernel  (gtok_sent_reg.hpp)  WAVE per graph, <= 64 nodes, adjacency rows in registers (lane = node)
 //   sent_lds_kernel  (gtok_sent_lds.hpp)  WAVE per graph, up to 512 nodes, immutable adjacency bit matrix in LDS
 // This file is the launcher: LDS layout, kernel choice, grid sizing.
-#include <atomic>
 #include <cstdlib>
-#include <mutex>
 
 #include "gtok_common.hpp"
 #include "gtok.h"
@@ -30,27 +28,6 @@ constexpr int GTOK_LANE_MIN_GRAPHS = 65536;     // measured crossover on ZINC-sh
 
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
-// Ticket counters of the dynamically scheduled kernels: a per-device ring of slots (kQueues counters + one
-// retired-wave counter each), zeroed once when the device is first used.  A launch takes the next slot and its last wave re-arms it, so a
-// slot is clean again when its launch has drained; kSlots launches may be in flight at once (any streams).
-// The first call on a device allocates (not capturable in a hipGraph: warm up once before capturing).
-static int *take_queue_slot(int dev) {
-  constexpr int kSlots = 256, kMaxDev = 64, kSlotInts = (kQueues + 1) * kQueueStride;
-  static std::mutex mu;
-  static int *ring[kMaxDev] = {};
-  static std::atomic<unsigned> seq{0};
-  if (dev < 0 || dev >= kMaxDev) return nullptr;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!ring[dev]) {
-      int *p = nullptr;
-      if (hipMalloc(reinterpret_cast<void **>(&p), kSlots * kSlotInts * sizeof(int)) != hipSuccess) return nullptr;
-      if (hipMemset(p, 0, kSlots * kSlotInts * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
-      ring[dev] = p;
-    }
-  }
-  return ring[dev] + (size_t)kSlotInts * (seq.fetch_add(1, std::memory_order_relaxed) % kSlots);
-}
 
 // 0 = lane-per-graph, 1 = register-resident wave-per-graph, 2 = LDS bit matrix.  GTOK_SENT_KERNEL=lane|reg|lds
 // pins a kernel where it is applicable (tests run every path).
