@@ -60,6 +60,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // read from (a CSR chunk starts at an arbitrary element; gfx950 global accesses may be unaligned), U8x16a is
 // for 16-byte aligned LDS.
 struct __attribute__((packed, aligned(4))) I32x4 { int32_t x, y, z, w; };
+struct __attribute__((packed, aligned(4))) I32x2 { int32_t x, y; };
 struct __attribute__((packed, aligned(1))) U8x16 { uint32_t a, b, c, d; };
 struct __attribute__((aligned(16))) U8x16a { uint32_t a, b, c, d; };
 

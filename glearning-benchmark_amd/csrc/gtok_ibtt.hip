@@ -367,6 +367,117 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) ib
 }
 
 // ---------------------------------------------------------------------------------------------
+// IBTT molecular serialiser, SIXTEEN LANES per graph (4 molecules per wave)
+// ---------------------------------------------------------------------------------------------
+// Same precondition as the lane kernel (GTOK_CSR_SIMPLE_SYMMETRIC, list order: keep iff u <= v), but a DPP row of
+// 16 lanes shares one molecule, so every memory access is coalesced and no CSR data is staged at all:
+//   rows     lane = node: row pointers straight from global; each node writes its id over its entry range
+//            of a small LDS buffer (the entry -> row map; molecules have <= 4 entries per row)
+//   atoms    lane = node: one 8-byte store (<atom> TYPE); 16 lanes = 128 contiguous bytes
+//   bonds    lane = entry: neighbour id and bond type straight from global (64 / 16 contiguous bytes per
+//            group), row from the LDS map, kept entries ranked with one wave ballot, one 16-byte store each
+//   tail/pad the group's first lane writes the 3-token tail; all 16 pad the row with 16-byte stores
+// A unit (4 molecules) is ~300 instructions and a few microseconds, so the grid is thousands of units deep and
+// neither round quantisation nor per-unit latency matters (the lane kernel's unit is 64 molecules and ~100 us).
+struct ZincQuadArgs {
+  gtok_csr g;
+  const int32_t *lut;
+  int lut_len, max_len, pad_id;
+  int off_map, off_lut, lds;   // LDS: entry -> row map u16 [4][maxe], LUT
+  int maxe;
+  int32_t *out; int ld; int32_t *out_len;
+  int units, upb;
+};
+
+__global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id(), grp = lane >> 4, ql = lane & 15;
+  uint16_t *rmap = reinterpret_cast<uint16_t *>(smem + a.off_map) + grp * a.maxe;
+  int32_t *slut = reinterpret_cast<int32_t *>(smem + a.off_lut);
+  const int ld = a.ld, cap = min(a.max_len, ld), pad = a.pad_id, G = a.g.num_graphs;
+  const bool has_ea = a.g.eattr != nullptr, has_na = a.g.nattr != nullptr;
+  for (int i = lane; i < a.lut_len; i += kWave) slut[i] = a.lut[i];
+  wave_sync();
+  const int t_atom = slut[GTOK_ZLUT_ATOM], t_bond = slut[GTOK_ZLUT_BOND];
+  auto node_id = [&](int i) { return (GTOK_ZLUT_NODE0 + i < a.lut_len) ? slut[GTOK_ZLUT_NODE0 + i] : pad; };
+
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * 4 + grp;
+    const bool valid = g < G;
+    int nb0 = 0, n = 0, e = 0;
+    int64_t e0 = 0;
+    if (valid) {
+      nb0 = a.g.node_ptr[g]; n = a.g.node_ptr[g + 1] - nb0;
+      e0 = a.g.edge_ptr[g]; e = min((int)(a.g.edge_ptr[g + 1] - e0), a.maxe);
+    }
+    int32_t *__restrict__ orow = a.out + (int64_t)g * ld;
+    auto put = [&](int p, int t) { if (p < cap) orow[p] = t; };
+    const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
+    // ---- lane = node: entry -> row map, <atom> TYPE pairs
+    wave_sync();   // the previous unit's map is no longer read
+    if (valid && ql == 0) put(0, slut[GTOK_ZLUT_BOS]);
+    for (int i = ql; i < n; i += 16) {
+      const int rs = rpg[i], re = min(rpg[i + 1], e);
+      const int x = has_na ? (int)a.g.nattr[nb0 + i] : 255;   // :168-169, 'X' for x outside 0..8 (:104)
+      for (int k = rs; k < re; ++k) rmap[k] = (uint16_t)i;
+      const int p = 1 + 2 * i, id = slut[GTOK_ZLUT_ATOM0 + (x <= 8 ? x : 9)];
+      if (p + 1 < cap) *reinterpret_cast<I32x2 *>(orow + p) = I32x2{t_atom, id};   // dword-aligned 8-byte store
+      else put(p, t_atom);
+    }
+    wave_sync();
+    // ---- lane = entry: keep u <= v (first occurrence of {u,v}: zinc_dataset_indexbase.py:176-184)
+    int pos = 1 + 2 * n;
+    const int emax = max(max(__builtin_amdgcn_readlane(e, 0), __builtin_amdgcn_readlane(e, 16)),
+                         max(__builtin_amdgcn_readlane(e, 32), __builtin_amdgcn_readlane(e, 48)));
+    for (int k0 = 0; k0 < emax; k0 += 16) {
+      const int k = k0 + ql;
+      const bool in = k < e;
+      const int v = in ? a.g.col[e0 + k] : 0;
+      const int at = (in && has_ea) ? (int)a.g.eattr[e0 + k] : 0;
+      const int u = in ? (int)rmap[k] : 0;
+      const bool keep = in && u <= v;
+      const uint32_t kept = (uint32_t)(((uint64_t)__ballot(keep) >> (grp << 4)) & 0xFFFFull);   // this group's 16 bits
+      if (keep) {
+        const int p = pos + 4 * __popc(kept & ((1u << ql) - 1u));
+        const int t1 = slut[GTOK_ZLUT_BOND0 + ((at >= 1 && at <= 4) ? at : 0)], t2 = node_id(u), t3 = node_id(v);
+        if (p + 3 < cap) {
+          *reinterpret_cast<I32x4 *>(orow + p) = I32x4{t_bond, t1, t2, t3};   // dword-aligned 16-byte store
+        } else {
+          put(p, t_bond); put(p + 1, t1); put(p + 2, t2);
+        }
+      }
+      pos += 4 * __popc(kept);
+    }
+    // ---- tail, length, padding
+    int len = 0;
+    if (valid) {
+      if (ql == 0) {
+        put(pos, slut[GTOK_ZLUT_Q]);
+        put(pos + 1, slut[GTOK_ZLUT_REGRESSION]);
+        put(pos + 2, slut[GTOK_ZLUT_P]);
+      }
+      const int64_t T = (int64_t)pos + 5;   // text tokens incl. label and <eos>
+      if (T <= (int64_t)a.max_len + 1) {
+        len = (int)(T - 2);
+      } else {                               // :217-221 tokens[:max_len-1] + ['<eos>']
+        len = a.max_len;
+        if (ql == 0 && a.max_len >= 1 && a.max_len - 1 < ld) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          orow[a.max_len - 1] = slut[GTOK_ZLUT_EOS];
+        }
+      }
+      if (ql == 0) a.out_len[g] = len;
+      const int lr = min(len, ld), nrem = ld - lr, nvec = nrem >> 2;
+      int32_t *__restrict__ tail = orow + lr;
+      for (int t = ql; t < nvec; t += 16) reinterpret_cast<I32x4 *>(tail)[t] = I32x4{pad, pad, pad, pad};
+      if (ql < (nrem & 3)) tail[(nvec << 2) + ql] = pad;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // graph-token grammar from the edge list
 // ---------------------------------------------------------------------------------------------
 struct SynthLds { int rp, tok, stride; };
@@ -594,19 +705,23 @@ static bool csr_ok(const gtok_csr *g) {
 
 using namespace gtok;
 
-// lane per graph for simple symmetric batches in list order, u8-indexable, big enough to fill the chip;
-// GTOK_IBTT_KERNEL=lane|wave pins a kernel (tests run both)
-static bool ibtt_zinc_use_lane(const gtok_csr *g) {
+// 0 = wave per graph (any batch), 1 = lane per graph, 2 = 16 lanes per graph.  1 and 2 need simple symmetric
+// batches in list order; 2 is the default for them, GTOK_IBTT_KERNEL=lane|quad|wave pins a kernel (tests run all)
+static int ibtt_zinc_choose(const gtok_csr *g) {
   const char *pin = std::getenv("GTOK_IBTT_KERNEL");
-  const bool lane_ok = (g->flags & GTOK_CSR_SIMPLE_SYMMETRIC) && !g->eorder && g->max_nodes <= 255 && g->max_edges <= 255;
-  bool lane = lane_ok && g->num_graphs >= 65536;
-  if (pin && pin[0] == 'l' && lane_ok) lane = true;
-  if (pin && pin[0] == 'w') lane = false;
-  return lane;
+  const bool list_ok = (g->flags & GTOK_CSR_SIMPLE_SYMMETRIC) && !g->eorder;
+  const bool lane_ok = list_ok && g->max_nodes <= 255 && g->max_edges <= 255;
+  const bool quad_ok = list_ok && g->max_nodes <= 65535 && g->max_edges <= 6000;   // 4 x maxe u16 of LDS
+  int k = quad_ok && g->num_graphs >= 1024 ? 2 : 0;
+  if (pin && pin[0] == 'l' && lane_ok) k = 1;
+  if (pin && pin[0] == 'q' && quad_ok) k = 2;
+  if (pin && pin[0] == 'w') k = 0;
+  return k;
 }
 
 extern "C" const char *gtok_ibtt_zinc_kernel_name(const gtok_csr *g) {
-  return !g ? "" : (ibtt_zinc_use_lane(g) ? "ibtt_zinc_lane_kernel" : "ibtt_zinc_kernel");
+  static const char *names[] = {"ibtt_zinc_kernel", "ibtt_zinc_lane_kernel", "ibtt_zinc_quad_kernel"};
+  return !g ? "" : names[ibtt_zinc_choose(g)];
 }
 
 extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut_len, int32_t max_len,
@@ -616,8 +731,33 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
   if (g->num_graphs == 0) return GTOK_OK;   // an empty batch is a no-op
   if (!csr_ok(g) || !lut || lut_len < GTOK_ZLUT_NODE0 || !out_ids || !out_len) return GTOK_E_INVAL;
   if (g->max_nodes > 65535 || g->max_edges > 65535) return GTOK_E_TOO_LARGE;
-  {  // lane per graph: simple symmetric batches in list order, u8-indexable, big enough to fill the chip
-    if (ibtt_zinc_use_lane(g)) {
+  const int which = ibtt_zinc_choose(g);
+  if (which == 2) {
+    ZincQuadArgs q;
+    q.g = *g; q.lut = lut; q.lut_len = lut_len; q.max_len = max_len; q.pad_id = pad_id;
+    q.maxe = g->max_edges > 0 ? g->max_edges : 1;
+    int off = 0;
+    q.off_map = off; off += align_up(4 * q.maxe * 2, 16);
+    q.off_lut = off; off += align_up(lut_len * 4, 16);
+    q.lds = off;
+    int dev = 0, ncu = 256, occ = 1;
+    if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(ibtt_zinc_quad_kernel), 64,
+                                                     (size_t)q.lds) != hipSuccess || occ < 1)
+      occ = 1;
+    occ = gtok::resident_waves(occ);
+    q.units = (g->num_graphs + 3) / 4;
+    int nb = ncu * occ;
+    if (nb > q.units) nb = q.units;
+    q.upb = (q.units + nb - 1) / nb;
+    nb = (q.units + q.upb - 1) / q.upb;
+    q.out = out_ids; q.ld = ld; q.out_len = out_len;
+    hipLaunchKernelGGL(ibtt_zinc_quad_kernel, dim3(nb), dim3(64), (size_t)q.lds, (hipStream_t)stream, q);
+    return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+  }
+  {  // lane per graph
+    if (which == 1) {
       ZincLaneArgs z;
       z.g = *g; z.lut = lut; z.lut_len = lut_len; z.max_len = max_len; z.pad_id = pad_id;
       z.cap_n = g->chunk_nodes > 0 ? g->chunk_nodes : 64 * g->max_nodes;

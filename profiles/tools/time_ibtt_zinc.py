@@ -27,4 +27,4 @@ for ld in (240, 64, 8):
         gtok.ops.ibtt_zinc(b, lut, 1024, vocab["<pad>"], ld=ld, out=(ids, ln))
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 20
-    print(f"ld {ld:4d}  {ms:7.4f} ms  {G / ms / 1e3:8.1f} M graphs/s  max len {int(ln.max())}", flush=True)
+    print(f"{os.environ.get('GTOK_IBTT_KERNEL', 'auto'):5s} ld {ld:4d}  {ms:7.4f} ms  {G / ms / 1e3:8.1f} M graphs/s  max len {int(ln.max())}", flush=True)

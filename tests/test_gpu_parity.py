@@ -248,11 +248,11 @@ def test_c_abi_error_codes():
     assert e_ids.shape == (0, 8) and e_ln.numel() == 0
 
 
-@pytest.mark.parametrize("pin", ["lane", "wave"])
+@pytest.mark.parametrize("pin", ["lane", "quad", "wave"])
 @pytest.mark.parametrize("max_len,ld", [(1024, None), (64, 64), (10, 12), (1, 4), (0, 4), (1024, 40), (57, 60)])
 def test_ibtt_zinc_both_kernels(pin, max_len, ld, monkeypatch):
-    """The lane-per-graph IBTT kernel (simple symmetric batches in list order) and the wave-per-graph one give
-    the oracle's ids, including every truncation corner."""
+    """The lane-per-graph and 16-lanes-per-graph IBTT kernels (simple symmetric batches in list order) and the
+    wave-per-graph one give the oracle's ids, including every truncation corner."""
     monkeypatch.setenv("GTOK_IBTT_KERNEL", pin)
     d = gtok.synth.zinc_like(3000, seed=91)
     batch, coo = both(d)
