@@ -249,7 +249,7 @@ def test_c_abi_error_codes():
 
 
 @pytest.mark.parametrize("pin", ["lane", "quad", "wave"])
-@pytest.mark.parametrize("max_len,ld", [(1024, None), (64, 64), (10, 12), (1, 4), (0, 4), (1024, 40), (57, 60)])
+@pytest.mark.parametrize("max_len,ld", [(1024, None), (64, 64), (10, 12), (1, 4), (0, 4), (1024, 40), (57, 60), (1024, 1500), (64, 67), (200, 241)])
 def test_ibtt_zinc_both_kernels(pin, max_len, ld, monkeypatch):
     """The lane-per-graph and 16-lanes-per-graph IBTT kernels (simple symmetric batches in list order) and the
     wave-per-graph one give the oracle's ids, including every truncation corner."""
