@@ -407,17 +407,55 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
   const int t_atom = slut[GTOK_ZLUT_ATOM], t_bond = slut[GTOK_ZLUT_BOND];
   auto node_id = [&](int i) { return (GTOK_ZLUT_NODE0 + i < a.lut_len) ? slut[GTOK_ZLUT_NODE0 + i] : pad; };
 
+  // Software pipeline over the block's units: a unit's loads form a chain header -> (row pointers, types,
+  // neighbour ids), and vmcnt retires in order, so loads issued behind the previous unit's row stores wait for
+  // them.  The header of unit+2 and the data of unit+1 are therefore requested BEFORE unit's rows are stored;
+  // in steady state a unit finds everything it needs in registers.  The first 64 atoms / 128 entries of a
+  // molecule travel this way (unconditional loads at clamped, always-valid indices: one basic block, all in
+  // flight together); longer molecules finish with plain loops.
+  const int64_t Etot = sload(a.g.edge_ptr, G);
+  const int Ntot = sload(a.g.node_ptr, G);
+  const bool ld_na = has_na && Ntot > 0, ld_ea = has_ea && Etot > 0, ld_col = Etot > 0;
+  struct Hdr { int nb0, n, e; int64_t e0; };
+  struct Dat { int rs[4], re[4], x[4], v[8], at[8]; };
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  auto load_hdr = [&](int unit) -> Hdr {
+    Hdr h{0, 0, 0, 0};
+    const int g = unit * 4 + grp;
+    if (unit < u1 && g < G) {
+      h.nb0 = a.g.node_ptr[g]; h.n = a.g.node_ptr[g + 1] - h.nb0;
+      h.e0 = a.g.edge_ptr[g]; h.e = min((int)(a.g.edge_ptr[g + 1] - h.e0), a.maxe);
+    }
+    return h;
+  };
+  auto load_dat = [&](int unit, const Hdr &h) -> Dat {
+    Dat d;
+    const int g = (unit < u1 && unit * 4 + grp < G) ? unit * 4 + grp : 0;   // idle groups read graph 0's first words
+    const int32_t *__restrict__ rp = a.g.rowptr + h.nb0 + g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = ql + 16 * j;
+      d.rs[j] = rp[min(i, h.n)];
+      d.re[j] = rp[min(i + 1, h.n)];
+      d.x[j] = ld_na ? (int)a.g.nattr[min(max(h.nb0 + min(i, h.n - 1), 0), Ntot - 1)] : 255;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t k = min(max(h.e0 + min(ql + 16 * j, h.e - 1), (int64_t)0), Etot - 1);
+      d.v[j] = ld_col ? a.g.col[k] : 0;
+      d.at[j] = ld_ea ? (int)a.g.eattr[k] : 0;
+    }
+    return d;
+  };
+  Hdr hdr = load_hdr(u0);
+  Dat dat = load_dat(u0, hdr);
+  Hdr hdr_next = load_hdr(u0 + 1);
   for (int unit = u0; unit < u1; ++unit) {
     const int g = unit * 4 + grp;
     const bool valid = g < G;
-    int nb0 = 0, n = 0, e = 0;
-    int64_t e0 = 0;
-    if (valid) {
-      nb0 = a.g.node_ptr[g]; n = a.g.node_ptr[g + 1] - nb0;
-      e0 = a.g.edge_ptr[g]; e = min((int)(a.g.edge_ptr[g + 1] - e0), a.maxe);
-    }
+    const int nb0 = hdr.nb0, n = hdr.n, e = hdr.e;
+    const int64_t e0 = hdr.e0;
     // the group's row: in LDS (ROWS) or in the slab
     int32_t *__restrict__ orow = ROWS ? srow + grp * ld : a.out + (int64_t)g * ld;
     auto put = [&](int p, int t) { if (p < cap) orow[p] = t; };
@@ -425,24 +463,26 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
     // ---- lane = node: entry -> row map, <atom> TYPE pairs
     wave_sync();   // the previous unit's map and rows are no longer read
     if (valid && ql == 0) put(0, slut[GTOK_ZLUT_BOS]);
-    for (int i = ql; i < n; i += 16) {
-      const int rs = rpg[i], re = min(rpg[i + 1], e);
-      const int x = has_na ? (int)a.g.nattr[nb0 + i] : 255;   // :168-169, 'X' for x outside 0..8 (:104)
+    auto node_step = [&](int i, int rs, int re, int x) {   // :168-169, 'X' for x outside 0..8 (:104)
+      re = min(re, e);
       for (int k = rs; k < re; ++k) rmap[k] = (uint16_t)i;
       const int p = 1 + 2 * i, id = slut[GTOK_ZLUT_ATOM0 + (x <= 8 ? x : 9)];
       if (p + 1 < cap) *reinterpret_cast<I32x2 *>(orow + p) = I32x2{t_atom, id};   // dword-aligned 8-byte store
       else put(p, t_atom);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = ql + 16 * j;
+      if (i < n) node_step(i, dat.rs[j], dat.re[j], dat.x[j]);
     }
+    for (int i = ql + 64; i < n; i += 16) node_step(i, rpg[i], rpg[i + 1], has_na ? (int)a.g.nattr[nb0 + i] : 255);
     wave_sync();
     // ---- lane = entry: keep u <= v (first occurrence of {u,v}: zinc_dataset_indexbase.py:176-184)
     int pos = 1 + 2 * n;
     const int emax = max(max(__builtin_amdgcn_readlane(e, 0), __builtin_amdgcn_readlane(e, 16)),
                          max(__builtin_amdgcn_readlane(e, 32), __builtin_amdgcn_readlane(e, 48)));
-    for (int k0 = 0; k0 < emax; k0 += 16) {
-      const int k = k0 + ql;
+    auto entry_step = [&](int k, int v, int at) {
       const bool in = k < e;
-      const int v = in ? a.g.col[e0 + k] : 0;
-      const int at = (in && has_ea) ? (int)a.g.eattr[e0 + k] : 0;
       const int u = in ? (int)rmap[k] : 0;
       const bool keep = in && u <= v;
       const uint32_t kept = (uint32_t)(((uint64_t)__ballot(keep) >> (grp << 4)) & 0xFFFFull);   // this group's 16 bits
@@ -456,7 +496,18 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
         }
       }
       pos += 4 * __popc(kept);
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (16 * j < emax) entry_step(ql + 16 * j, dat.v[j], dat.at[j]);
+    for (int k0 = 128; k0 < emax; k0 += 16) {
+      const int k = k0 + ql;
+      entry_step(k, k < e ? a.g.col[e0 + k] : 0, (k < e && has_ea) ? (int)a.g.eattr[e0 + k] : 0);
     }
+    // ---- next units' requests go out ahead of this unit's row stores
+    hdr = hdr_next;
+    dat = load_dat(unit + 1, hdr);
+    hdr_next = load_hdr(unit + 2);
     // ---- tail, length
     int len = 0;
     if (valid) {
