@@ -26,9 +26,17 @@ namespace gtok {
 struct alignas(4) Tok3 { int a, b, c; };   // token groups stored with one dword-aligned 12- / 8-byte write
 struct alignas(4) Tok2 { int a, b; };
 
-__device__ __forceinline__ int kth_bit_serial(uint64_t w, int k) {   // per lane; k is small (degree-bounded)
-  while (k-- > 0) w &= w - 1;
-  return __builtin_ctzll(w);
+// k-th (0-based) set bit of w, per lane, k < popcount(w): branch-free halving on popcounts.  (A clear-lowest-bit
+// loop runs max-over-lanes(k) times for the whole wave; picks from `live` have k up to the molecule's size.)
+__device__ __forceinline__ int kth_bit64(uint64_t w, int k) {
+  uint32_t x = (uint32_t)w;
+  int base = 0, c = __popc(x);
+  if (k >= c) { k -= c; x = (uint32_t)(w >> 32); base = 32; }
+  c = __popc(x & 0xFFFFu); if (k >= c) { k -= c; x >>= 16; base += 16; }
+  c = __popc(x & 0xFFu);   if (k >= c) { k -= c; x >>= 8;  base += 8; }
+  c = __popc(x & 0xFu);    if (k >= c) { k -= c; x >>= 4;  base += 4; }
+  c = __popc(x & 0x3u);    if (k >= c) { k -= c; x >>= 2;  base += 2; }
+  return base + ((k >= (int)(x & 1u)) ? 1 : 0);
 }
 
 struct SentLaneArgs {
@@ -233,8 +241,9 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
     auto edge_tok = [&](int at) __attribute__((always_inline)) -> int {
       return remap ? remap_edge_type(at, edge_off) : edge_off + at;
     };
-    // first visit of v; pred >= 0: reached over the trail edge (pred, v) whose edge-type token is `et`
-    auto visit = [&](int v, int pred, int et) __attribute__((always_inline)) {
+    // first visit of v; pred >= 0: reached over the trail edge (pred, v) whose edge-type token is `et`.
+    // Returns v's row: the next step starts from it.
+    auto visit = [&](int v, int pred, int et) __attribute__((always_inline)) -> Row {
       const int my = nvis;
       const Row r = load_row(v);
       const int deg = r.re - r.rs;
@@ -297,33 +306,36 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
         }
         emit(T_RADJ);
       }
+      return r;
     };
 
     if (valid) {
       emit(GTOK_SENT_SOS);
       if (n > 0) {
-        cur = (int)below((uint32_t)n);
-        visit(cur, -1, 0);
+        Row rc{0, 0, 0, 0, 0, 0};   // row of cur, carried from step to step (empty before the first visit)
+        const uint64_t nodes = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        // Every step draws exactly one decision, so the draw, the k-th-member pick and the visit are written ONCE
+        // and the step's kind only selects their operands.  (With one copy per kind, a wave whose lanes are in
+        // different kinds - nearly every step - ran the Philox refill, the pick and the visit once per kind.)
         while (pos < lim) {
-          const Row rc = load_row(cur);
           const uint64_t row = row_mask(rc) & ~vis;
-          if (row) {   // extend the trail over an uncovered edge (always towards an unvisited node)
-            const int nxt = kth_bit_serial(row, (int)below((uint32_t)__popcll(row)));
-            const int et = LAB ? edge_tok(el[entry_of(rc, nxt)]) : 0;   // type of the listed entry cur->nxt
-            visit(nxt, cur, et);
-            cur = nxt;
-          } else if (live) {   // dead end: restart from a visited node that still owns uncovered edges
-            cur = kth_bit_serial(live, (int)below((uint32_t)__popcll(live)));
+          // 0: extend the trail over an uncovered edge (always towards an unvisited node); 1: dead end, restart from
+          // a visited node that still owns uncovered edges; 2: another component or an isolated node
+          const int kind = row ? 0 : (live ? 1 : 2);
+          if (kind == 2 && nvis >= n) break;
+          const uint64_t set = kind == 0 ? row : (kind == 1 ? live : (~vis & nodes));
+          const int pick = kth_bit64(set, (int)below((uint32_t)__popcll(set)));
+          if (kind == 1) {
             emit(T_RESET);
-            emit(pos_base + AT(vidx, cur));
-          } else if (nvis < n) {   // another component or an isolated node
-            const uint64_t un = ~vis & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
-            cur = kth_bit_serial(un, (int)below((uint32_t)(n - nvis)));
-            emit(T_RESET);
-            visit(cur, -1, 0);
+            emit(pos_base + AT(vidx, pick));
+            rc = load_row(pick);
           } else {
-            break;
+            int et = 0;
+            if (kind == 0) { if (LAB) et = edge_tok(el[entry_of(rc, pick)]); }   // type of the listed entry cur->pick
+            else if (nvis > 0) emit(T_RESET);   // (the walk's first node is a component start without RESET)
+            rc = visit(pick, kind == 0 ? cur : -1, et);
           }
+          cur = pick;
         }
       }
       emit(T_EOS);
