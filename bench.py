@@ -209,12 +209,18 @@ def main():
             iname = gtok.lib().gtok_ibtt_zinc_kernel_name(ctypes.byref(_cs)).decode()
         else:
             iname = "ibtt_synth_kernel"
+        itraffic = None
+        if os.path.exists(tpath):
+            rec = json.load(open(tpath)).get(f"ibtt:{args.workload}:{G}")
+            if rec:
+                itraffic = rec["hbm_bytes_per_launch"]
         out["ibtt"] = dict(kernel=iname,
                            graphs_per_sec_per_gpu=round(G * args.steps / iwall, 1),
                            tokens_per_sec_per_gpu=round(itok * args.steps / iwall, 1), kernel_ms=round(ik * 1e3, 4),
                            slab_width=ild, avg_tokens_per_graph=round(itok / G, 2),
                            roofline=dict(bound="hbm", achieved=round(ib / ik / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                                         frac=round(ib / ik / 1e9 / HBM_PEAK_GBS, 5), algorithmic_bytes_per_launch=int(ib),
+                                         frac=round(ib / ik / 1e9 / HBM_PEAK_GBS, 5), traffic=itraffic,
+                                         algorithmic_bytes_per_launch=int(ib),
                                          padded_slab_bytes_per_launch=int(4 * G * ild)))
 
     # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own

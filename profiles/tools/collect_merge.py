@@ -1,0 +1,40 @@
+"""Turn gpurun_out/collect_<tag>/ (profiles/tools/collect.sh) into the committed summaries under profiles/<tag>/:
+bench JSON lines, per-kernel stats CSVs, one PMC summary per workload, and profiles/pmc_traffic.json
+(HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE KiB: gfx950 FETCH_SIZE counts half the fetched bytes,
+/opt/skills/guides/MI355X_MICROARCH.md, HBM section)."""
+import collections, csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = f"gpurun_out/collect_{tag}", f"profiles/{tag}"
+os.makedirs(dst, exist_ok=True)
+traffic = {}
+for wl in ("zinc_full", "synth_er"):
+    shutil.copy(f"{src}/bench_{wl}.json", f"{dst}/bench_{wl}_final.json")
+    for f in glob.glob(f"{src}/stats_{wl}/**/*_kernel_stats.csv", recursive=True):
+        shutil.copy(f, f"{dst}/bench_{wl}_kernel_stats_final.csv")
+    agg = collections.defaultdict(list)
+    for f in glob.glob(f"{src}/pmc_{wl}_*/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "gtok" in r["Kernel_Name"]:
+                agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    kern = {}
+    for (k, c), v in sorted(agg.items()):
+        kern.setdefault(k, {})[c] = {"calls": len(v), "mean": sum(v) / len(v)}
+    for k, c in kern.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            c["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
+    json.dump({"command": "profiles/tools/collect.sh: rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 bench.py "
+                          f"--steps 5 --warmup 1 --workload {wl} --no-cpu-baseline, one pass per counter group",
+               "note": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; hbm_bytes_per_launch = (2*FETCH + WRITE) * 1024",
+               "kernels": kern}, open(f"{dst}/pmc_summary_{wl}_final.json", "w"), indent=1)
+    bench = json.loads(open(f"{src}/bench_{wl}.json").read().strip().splitlines()[-1])
+    G, mode = bench["config"]["graphs_per_gpu"], bench["config"]["slab_width_mode"]
+    for k, c in kern.items():
+        if "hbm_bytes_per_launch" not in c:
+            continue
+        leg = "sent" if "sent" in k else ("ibtt" if "ibtt" in k else None)
+        if leg:
+            key = f"{leg}:{wl}:{G}:{mode}" if leg == "sent" else f"{leg}:{wl}:{G}"
+            traffic[key] = {"hbm_bytes_per_launch": c["hbm_bytes_per_launch"], "kernel": k.replace("void ", ""),
+                            "source": f"{dst}/pmc_summary_{wl}_final.json"}
+json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(traffic, indent=1))
