@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
 // ---------------------------------------------------------------------------------------------
 // graph-token grammar from the edge list
 // ---------------------------------------------------------------------------------------------
-struct SynthLds { int rp, tok, stride; };
+struct SynthLds { int rp, tok, lut, stride; };
 struct SynthArgs {
   gtok_csr g;
   const int32_t *lut; const int32_t *query;
@@ -576,37 +576,76 @@ __global__ void __launch_bounds__(256) ibtt_synth_kernel(const SynthArgs a) {
   unsigned char *base = smem + (size_t)wave * a.l.stride;
   int32_t *rp = reinterpret_cast<int32_t *>(base + a.l.rp);
   int32_t *tok = reinterpret_cast<int32_t *>(base + a.l.tok);
-  const int32_t *__restrict__ lut = a.lut;
-  const int pad = a.pad_id, tcap = a.tcap;
+  int32_t *lut = reinterpret_cast<int32_t *>(base + a.l.lut);   // the wave's own copy: no workgroup barrier anywhere
+  const int pad = a.pad_id, tcap = a.tcap, G = a.g.num_graphs;
+  const bool has_order = a.g.eorder != nullptr;
+  for (int i = lane; i < a.lut_len; i += kWave) lut[i] = a.lut[i];
+  wave_sync();
   auto put = [&](int64_t q, int v) { if (q < tcap) tok[q] = v; };
   auto node_id = [&](int i) { return (GTOK_SLUT_NODE0 + i < a.lut_len) ? lut[GTOK_SLUT_NODE0 + i] : pad; };
 
+  // Software pipeline over the wave's graphs: a graph's loads form the chain header -> (row pointers, the entries that
+  // survive the cut), and vmcnt retires in order, so loads issued behind the previous row's 2.4 KB of stores wait for
+  // HBM to take them.  Graph +2's header (scalar loads) and graph +1's first 320 row pointers / 256 entries are
+  // therefore requested before graph's row is stored; longer graphs finish with plain loops.
+  struct Hdr { int nb0, nfull, n, e, elim; int64_t e0; };
+  struct Dat { int rp[5], col[4], ord[4]; };
+  const int64_t Etot = sload(a.g.edge_ptr, G);
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  auto load_hdr = [&](int unit) -> Hdr {
+    Hdr h{0, 0, 0, 0, 0, 0};
+    const int g = unit * wpb + wave;
+    if (unit < u1 && g < G) {
+      h.nb0 = sload(a.g.node_ptr, g);
+      h.nfull = sload(a.g.node_ptr, g + 1) - h.nb0;
+      h.n = min(h.nfull, a.maxn);
+      h.e0 = sload(a.g.edge_ptr, g);
+      h.e = (int)(sload(a.g.edge_ptr, g + 1) - h.e0);
+      // "u v <e>" at 1+3p for the edge at original position p; only entries whose tokens survive the cut are
+      // touched when the order is the identity
+      h.elim = has_order ? h.e : min(h.e, (tcap + 1) / 3 + 1);
+    }
+    return h;
+  };
+  auto load_dat = [&](int unit, const Hdr &h) -> Dat {
+    Dat d;
+    const int g = (unit < u1 && unit * wpb + wave < G) ? unit * wpb + wave : 0;   // past the end: graph 0's first words
+    const int32_t *__restrict__ rpg = a.g.rowptr + h.nb0 + g;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) d.rp[j] = rpg[min(lane + kWave * j, h.n)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t k = min(max(h.e0 + min(lane + kWave * j, h.elim - 1), (int64_t)0), Etot - 1);
+      d.col[j] = Etot > 0 ? a.g.col[k] : 0;
+      d.ord[j] = (has_order && Etot > 0) ? a.g.eorder[k] : lane + kWave * j;
+    }
+    return d;
+  };
+  Hdr hdr = load_hdr(u0);
+  Dat dat = load_dat(u0, hdr);
+  Hdr hdr_next = load_hdr(u0 + 1);
   for (int unit = u0; unit < u1; ++unit) {
     const int g = unit * wpb + wave;
-    if (g >= a.g.num_graphs) break;
-    const int nb0 = a.g.node_ptr[g];
-    const int nfull = a.g.node_ptr[g + 1] - nb0;
-    const int n = min(nfull, a.maxn);
-    const int64_t e0 = a.g.edge_ptr[g];
-    const int e = (int)(a.g.edge_ptr[g + 1] - e0);
+    if (g >= G) break;
+    const int nb0 = hdr.nb0, nfull = hdr.nfull, n = hdr.n, e = hdr.e, elim = hdr.elim;
+    const int64_t e0 = hdr.e0;
     const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
 
-    for (int i = lane; i <= n; i += kWave) rp[i] = rpg[i];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { const int i = lane + kWave * j; if (i <= n) rp[i] = dat.rp[j]; }
+    for (int i = lane + 5 * kWave; i <= n; i += kWave) rp[i] = rpg[i];
     wave_sync();
-    // "u v <e>" at 1+3p for the edge at original position p; only entries whose
-    // tokens survive the cut are touched when the order is the identity
-    const int elim = a.g.eorder ? e : min(e, (tcap + 1) / 3 + 1);
-    for (int k = lane; k < elim; k += kWave) {
-      const int p = a.g.eorder ? a.g.eorder[e0 + k] : k;
+    auto entry = [&](int k, int v, int p) {
       const int64_t q = 1 + 3 * (int64_t)p;
       if (q < tcap) {
-        const int v = a.g.col[e0 + k];
         const int u = row_of(rp, n, k);
         put(q, node_id(u)); put(q + 1, node_id(v)); put(q + 2, lut[GTOK_SLUT_E]);
       }
-    }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int k = lane + kWave * j; if (k < elim) entry(k, dat.col[j], dat.ord[j]); }
+    for (int k = lane + 4 * kWave; k < elim; k += kWave) entry(k, a.g.col[e0 + k], has_order ? a.g.eorder[e0 + k] : k);
     const int64_t qn = 1 + 3 * (int64_t)e;
     for (int i = lane; i < nfull; i += kWave) put(qn + 1 + i, node_id(i));
     int nq = 0;
@@ -619,6 +658,10 @@ __global__ void __launch_bounds__(256) ibtt_synth_kernel(const SynthArgs a) {
       for (int i = 0; i < nq; ++i) put(qq + 1 + i, a.query[4 * (int64_t)g + 1 + i]);
       put(qq + 1 + nq, lut[GTOK_SLUT_P]);
     }
+    // ---- the next graphs' requests go out ahead of this row's stores
+    hdr = hdr_next;
+    dat = load_dat(unit + 1, hdr);
+    hdr_next = load_hdr(unit + 2);
     wave_sync();
     const int64_t T = 1 + 3 * (int64_t)e + 1 + nfull + 1 + nq + 1;
     const int len = (int)min(T, (int64_t)a.max_len);
@@ -923,6 +966,7 @@ extern "C" int gtok_ibtt_synth(const gtok_csr *g, const int32_t *lut, int32_t lu
   int off = 0;
   a.l.rp = off; off += align_up((a.maxn + 1) * 4, 16);
   a.l.tok = off; off += align_up(a.tcap * 4, 16);
+  a.l.lut = off; off += align_up(lut_len * 4, 16);
   a.l.stride = align_up(off, 16);
   if (a.l.stride > 160 * 1024) return GTOK_E_TOO_LARGE;
   int wpb = 4;

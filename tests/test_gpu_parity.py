@@ -262,3 +262,27 @@ def test_ibtt_zinc_both_kernels(pin, max_len, ld, monkeypatch):
     ids, ln = gtok.ops.ibtt_zinc(batch.to(DEV), lut, max_len, vocab["<pad>"], ld=ld)
     ref, rln = orc.ibtt_zinc(coo, lut.numpy(), max_len, vocab["<pad>"], ids.shape[1])
     _cmp(ids, ln, ref, rln, f"ibtt_zinc[{pin}]")
+
+
+@pytest.mark.parametrize("pin", ["lane", "lds"])
+def test_ticket_queues_survive_many_launches(pin, monkeypatch):
+    """The dynamically scheduled kernels take a slot of a 256-entry ring of device counters per launch and re-arm it
+    when their last wave retires: 600 launches on two streams must keep giving the oracle's tokens."""
+    monkeypatch.setenv("GTOK_SENT_KERNEL", pin)
+    d = gtok.synth.zinc_like(700, seed=71)
+    batch, coo = both(d, False)
+    b = batch.to(DEV)
+    ld = gtok.ops.sent_safe_ld(batch, False, 1024)
+    ref = {k: orc.sent(coo, 40, 1024, 3, k, ld=ld) for k in (0, 1)}
+    side = torch.cuda.Stream(device=DEV)
+    outs = []
+    for i in range(300):
+        outs.append((0, gtok.ops.sent(b, 40, 1024, 3, 0, ld=ld)))
+        with torch.cuda.stream(side):
+            outs.append((1, gtok.ops.sent(b, 40, 1024, 3, 1, ld=ld)))
+        if len(outs) >= 40:
+            torch.cuda.synchronize()
+            for k, (ids, ln) in outs:
+                _cmp(ids, ln, ref[k][0], ref[k][1], f"launch {i} epoch {k} [{pin}]")
+            outs = []
+    torch.cuda.synchronize()
