@@ -286,3 +286,35 @@ def test_ticket_queues_survive_many_launches(pin, monkeypatch):
                 _cmp(ids, ln, ref[k][0], ref[k][1], f"launch {i} epoch {k} [{pin}]")
             outs = []
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("pin", ["reg", "lane"])
+def test_hip_graph_capture_and_replay(pin, monkeypatch):
+    """The launchers only enqueue on the caller's stream, so a tokenisation pass (SENT + IBTT into preallocated
+    slabs) can be captured once in a HIP graph and replayed; replays must keep matching the oracle (the lane
+    kernel's ticket-counter slot is baked into the captured launch and re-arms itself after every replay)."""
+    monkeypatch.setenv("GTOK_SENT_KERNEL", pin)
+    d = gtok.synth.zinc_like(2000, seed=81)
+    batch, coo = both(d)
+    b = batch.to(DEV)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ld = gtok.ops.sent_safe_ld(batch, True, 1024)
+    vocab = zinc_vocab(40)
+    lut = gtok.ops.zinc_lut(vocab, 40).to(DEV)
+    s_out = (torch.empty((2000, ld), dtype=torch.int32, device=DEV), torch.empty(2000, dtype=torch.int32, device=DEV))
+    i_out = (torch.empty((2000, 256), dtype=torch.int32, device=DEV), torch.empty(2000, dtype=torch.int32, device=DEV))
+    gtok.ops.sent(b, 37, 1024, 9, 4, ld=ld, out=s_out, **kw)             # warm-up: first launch allocates the counters
+    gtok.ops.ibtt_zinc(b, lut, 1024, vocab["<pad>"], ld=256, out=i_out)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gtok.ops.sent(b, 37, 1024, 9, 4, ld=ld, out=s_out, **kw)
+        gtok.ops.ibtt_zinc(b, lut, 1024, vocab["<pad>"], ld=256, out=i_out)
+    ref, rln = orc.sent(coo, 37, 1024, 9, 4, ld=ld, **kw)
+    iref, irln = orc.ibtt_zinc(coo, lut.cpu().numpy(), 1024, vocab["<pad>"], 256)
+    for rep in range(3):
+        s_out[0].fill_(-1); i_out[0].fill_(-1)
+        graph.replay()
+        torch.cuda.synchronize()
+        _cmp(s_out[0], s_out[1], ref, rln, f"graph replay {rep}: sent")
+        _cmp(i_out[0], i_out[1], iref, irln, f"graph replay {rep}: ibtt")
