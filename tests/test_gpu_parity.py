@@ -318,3 +318,33 @@ def test_hip_graph_capture_and_replay(pin, monkeypatch):
         torch.cuda.synchronize()
         _cmp(s_out[0], s_out[1], ref, rln, f"graph replay {rep}: sent")
         _cmp(i_out[0], i_out[1], iref, irln, f"graph replay {rep}: ibtt")
+
+
+def _symmetric_er(num_graphs, seed, min_nodes, max_nodes, p_lo, p_hi):
+    """ER graphs listed in both directions, row-sorted (PyG-coalesced style), with atom / bond types."""
+    d = gtok.synth.er_batch(num_graphs, seed=seed, min_nodes=min_nodes, max_nodes=max_nodes, min_sparsity=p_lo, max_sparsity=p_hi)
+    rng = np.random.default_rng(seed + 1)
+    nc, ec = d["node_counts"], d["edge_counts"]
+    gid = np.repeat(np.arange(num_graphs), ec)
+    bond = rng.integers(0, 6, gid.size)
+    src = np.concatenate([d["src"], d["dst"]]); dst = np.concatenate([d["dst"], d["src"]])
+    gg = np.concatenate([gid, gid]); ea = np.concatenate([bond, bond])
+    order = np.lexsort((dst, src, gg))
+    return dict(node_counts=nc, edge_counts=2 * ec, src=src[order], dst=dst[order], edge_attr=ea[order],
+                x=rng.integers(0, 12, int(nc.sum())))
+
+
+@pytest.mark.parametrize("pin", ["quad", "wave"])
+def test_ibtt_zinc_large_symmetric_graphs(pin, monkeypatch):
+    """The 16-lanes-per-molecule kernel on graphs far beyond molecule size: more than 64 nodes and more than 128
+    entries per graph take its plain-loop tails (the first 64 / 128 travel through the register pipeline)."""
+    monkeypatch.setenv("GTOK_IBTT_KERNEL", pin)
+    d = _symmetric_er(1100, 5, 2, 150, 0.03, 0.12)
+    batch, coo = both(d)
+    assert batch.flags & 1 and batch.eorder is None and batch.max_nodes > 64 and batch.max_edges > 128
+    vocab = zinc_vocab(160)
+    lut = gtok.ops.zinc_lut(vocab, 160)
+    for max_len, ld in ((8192, None), (300, 300), (1024, 5000)):
+        ids, ln = gtok.ops.ibtt_zinc(batch.to(DEV), lut, max_len, vocab["<pad>"], ld=ld)
+        ref, rln = orc.ibtt_zinc(coo, lut.numpy(), max_len, vocab["<pad>"], ids.shape[1])
+        _cmp(ids, ln, ref, rln, f"ibtt_zinc large [{pin}] max_len={max_len}")
