@@ -223,6 +223,24 @@ def main():
                                          algorithmic_bytes_per_launch=int(ib),
                                          padded_slab_bytes_per_launch=int(4 * G * ild)))
 
+    # the corpus pass of build_vocab_from_texts, from the CSR (graph-token corpora; outside the timed region)
+    if not zinc and not args.no_ibtt:
+        nid = max_nodes
+        if nid <= 1024:
+            vc = torch.zeros(nid, dtype=torch.int64, device=dev)
+            vf = torch.full((nid,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+            fv = lambda k: gtok.ops.vocab_stats_synth(batch, nid, out=(vc, vf))
+            for _ in range(args.warmup):
+                fv(0)
+            vwall, vk_ms = timed_loop(fv, args.steps, multi)
+            vb = 4.0 * (host.num_nodes_total + G) + 4.0 * host.num_edges_total
+            vk = float(np.mean(vk_ms)) * 1e-3
+            out["vocab_stats"] = dict(kernel="vocab_stats_synth_kernel", graphs_per_sec_per_gpu=round(G * args.steps / vwall, 1),
+                                      kernel_ms=round(vk * 1e3, 4),
+                                      roofline=dict(bound="hbm", achieved=round(vb / vk / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                                    frac=round(vb / vk / 1e9 / HBM_PEAK_GBS, 5), traffic=None,
+                                                    algorithmic_bytes_per_launch=int(vb)))
+
     # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
     if multi:
         gtok.dist.gather_tokens(ids, lens[-1], world * G, 5)

@@ -672,6 +672,86 @@ __global__ void __launch_bounds__(256) ibtt_synth_kernel(const SynthArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// node-id token statistics of the graph-token texts (corpus pass of build_vocab_from_texts)
+// ---------------------------------------------------------------------------------------------
+// Wave per graph over a contiguous range; the wave keeps a private histogram / first-position table in LDS
+// (every graph hits the same few hundred ids: global atomics would serialise) and merges it into the global
+// tables once, when its range is done.  Lane = row for the `u` side (a row's endpoints share u: one add of the
+// degree), lane = entry for the `v` side, lane = node for the <n> list.
+struct VocabArgs {
+  gtok_csr g;
+  const int32_t *query_nodes;
+  int64_t graph_base;
+  int num_ids, stride;   // LDS bytes per wave
+  unsigned long long *count, *first;
+  int units, upb;
+};
+
+__global__ void __launch_bounds__(256) vocab_stats_synth_kernel(const VocabArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
+  unsigned long long *fst = reinterpret_cast<unsigned long long *>(smem + (size_t)wave * a.stride);
+  unsigned int *cnt = reinterpret_cast<unsigned int *>(fst + a.num_ids);
+  const int K = a.num_ids, G = a.g.num_graphs;
+  const bool has_order = a.g.eorder != nullptr;
+  for (int i = lane; i < K; i += kWave) { fst[i] = ~0ull >> 1; cnt[i] = 0; }
+  wave_sync();
+  // A wave walks its graphs in increasing index, and a graph's <n> list names every id below its node count:
+  // once a graph with N nodes is done, ids < N already hold a first position from an earlier (smaller) graph
+  // key, so later graphs with <= N nodes only count (half the LDS atomics of the pass).
+  int seen_n = 0;
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * wpb + wave;
+    if (g >= G) break;
+    const int nb0 = sload(a.g.node_ptr, g), n = sload(a.g.node_ptr, g + 1) - nb0;
+    const int64_t e0 = sload(a.g.edge_ptr, g);
+    const int e = (int)(sload(a.g.edge_ptr, g + 1) - e0);
+    const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
+    const unsigned long long gkey = (unsigned long long)(a.graph_base + g) << 32;
+    const bool fresh = n > seen_n;   // some id of this graph may not have been seen yet
+    auto hit = [&](int id, unsigned int times, unsigned long long key) {
+      if ((unsigned)id < (unsigned)K) {
+        atomicAdd(&cnt[id], times);
+        if (fresh || id >= seen_n) atomicMin(&fst[id], key);
+      }
+    };
+    for (int u = lane; u < n; u += kWave) {   // "u v <e>" of the edge at list position p: u at 1+3p, v at 2+3p
+      const int rs = rpg[u], re = min(rpg[u + 1], e);
+      if (re > rs) {
+        int pmin = rs;                        // identity order: the row's first entry is its first listed one
+        if (has_order && fresh) { pmin = a.g.eorder[e0 + rs]; for (int k = rs + 1; k < re; ++k) pmin = min(pmin, a.g.eorder[e0 + k]); }
+        hit(u, (unsigned)(re - rs), gkey | (unsigned long long)(1 + 3 * (int64_t)pmin));
+      }
+      hit(u, 1u, gkey | (unsigned long long)(2 + 3 * (int64_t)e + u));   // the <n> list: node u at 1+3E+1+u
+    }
+    for (int k0 = 0; k0 < e; k0 += 8 * kWave) {   // 8 loads in flight per lane (clamped, unconditional: one basic block)
+      int v[8], p[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = min(k0 + lane + kWave * j, e - 1);
+        v[j] = a.g.col[e0 + k];
+        p[j] = (has_order && fresh) ? a.g.eorder[e0 + k] : k;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + lane + kWave * j < e) hit(v[j], 1u, gkey | (unsigned long long)(2 + 3 * (int64_t)p[j]));
+    }
+    if (a.query_nodes && lane < 2) {          // "<q> TASK qu qv": after the <n> list (1+3E+1+N), <q> and TASK
+      const int qn = a.query_nodes[2 * (int64_t)g + lane];
+      if (qn >= 0) hit(qn, 1u, gkey | (unsigned long long)(4 + 3 * (int64_t)e + n + lane));
+    }
+    wave_sync();   // this graph's positions are in before a later graph may skip them
+    seen_n = max(seen_n, n);
+  }
+  wave_sync();
+  for (int i = lane; i < K; i += kWave)
+    if (cnt[i]) { atomicAdd(&a.count[i], (unsigned long long)cnt[i]); atomicMin(&a.first[i], fst[i]); }
+}
+
+// ---------------------------------------------------------------------------------------------
 // TokenDataset on raw text
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool py_isspace(uint32_t c) {
@@ -979,6 +1059,25 @@ extern "C" int gtok_ibtt_synth(const gtok_csr *g, const int32_t *lut, int32_t lu
   const Launch L = plan(reinterpret_cast<const void *>(ibtt_synth_kernel), g->num_graphs, wpb, lds);
   a.out = out_ids; a.ld = ld; a.out_len = out_len; a.units = L.units; a.upb = L.upb;
   hipLaunchKernelGGL(ibtt_synth_kernel, dim3(L.nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_vocab_stats_synth(const gtok_csr *g, const int32_t *query_nodes, int64_t graph_base,
+                                      int32_t num_ids, int64_t *count, int64_t *first, void *stream) {
+  if (!g || g->num_graphs < 0 || num_ids <= 0) return GTOK_E_INVAL;
+  if (g->num_graphs == 0) return GTOK_OK;
+  if (!csr_ok(g) || !count || !first) return GTOK_E_INVAL;
+  if (num_ids > 1024) return GTOK_E_TOO_LARGE;
+  VocabArgs a;
+  a.g = *g; a.query_nodes = query_nodes; a.graph_base = graph_base; a.num_ids = num_ids;
+  a.stride = align_up(num_ids * 12, 16);
+  a.count = reinterpret_cast<unsigned long long *>(count);
+  a.first = reinterpret_cast<unsigned long long *>(first);
+  const int wpb = 4;
+  const size_t lds = (size_t)wpb * a.stride;
+  const Launch L = plan(reinterpret_cast<const void *>(vocab_stats_synth_kernel), g->num_graphs, wpb, lds);
+  a.units = L.units; a.upb = L.upb;
+  hipLaunchKernelGGL(vocab_stats_synth_kernel, dim3(L.nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 

@@ -46,3 +46,13 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     dist.all_gather_into_tensor(all_ids, ids.contiguous())
     dist.all_gather_into_tensor(all_ln, ln.contiguous())
     return all_ids[:num_graphs], all_ln[:num_graphs]
+
+
+def reduce_vocab_stats(count: torch.Tensor, first: torch.Tensor):
+    """Combine the ranks' node-id token statistics (ops.vocab_stats_synth on each rank's block, graph_base = the
+    block's first global index): counts add, first positions take the minimum.  In place; every rank ends with
+    the corpus-wide tables and builds the same vocab (data_loader.vocab_from_stats)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(count, op=dist.ReduceOp.SUM)
+        dist.all_reduce(first, op=dist.ReduceOp.MIN)
+    return count, first

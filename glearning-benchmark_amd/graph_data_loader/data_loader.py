@@ -225,6 +225,63 @@ def build_vocab_from_texts(texts: List[str], min_freq: int = 1, max_tokens: Opti
     return vocab, {i: t for t, i in vocab.items()}
 
 
+def vocab_from_stats(count, first, node_counts, edge_counts, task: Optional[str] = None, label_tokens=None,
+                     query_nodes=None, min_freq: int = 1, max_tokens: Optional[int] = None, graph_base: int = 0):
+    """build_vocab_from_texts (reference :451-463) for a graph-token corpus that was never rendered as text:
+    `count` / `first` are the node-id token statistics (ops.vocab_stats_synth on the device, or the oracle's
+    restatement), the handful of other tokens (task name, labels) are counted here from per-graph arrays.
+    Texts are `<bos> u v <e> ... <n> 0 .. N-1 <q> TASK [qu qv] <p> LABEL <eos>` (docs/synthetic_data.md:46-68).
+    Returns (vocab, inverse) equal to build_vocab_from_texts(texts, min_freq, max_tokens) on those texts."""
+    import numpy as np
+    count = np.asarray(count, dtype=np.int64); first = np.asarray(first, dtype=np.int64)
+    nc = np.asarray(node_counts, dtype=np.int64); ec = np.asarray(edge_counts, dtype=np.int64)
+    G = int(nc.size)
+    entries = []   # (token, count, first-seen key)
+    for i in np.nonzero(count)[0]:
+        entries.append((str(int(i)), int(count[i]), int(first[i])))
+    gkey = (np.arange(G, dtype=np.int64) + graph_base) << 32
+    q_pos = 2 + 3 * ec + nc                       # position of <q> in graph g's text
+    if task is not None and G:
+        entries.append((task, G, int(gkey[0] + q_pos[0] + 1)))
+    nq = np.zeros(G, np.int64)
+    if query_nodes is not None:
+        nq = (np.asarray(query_nodes).reshape(G, 2) >= 0).sum(1)
+    if label_tokens is not None:
+        lab = np.asarray(label_tokens, dtype=object)
+        has = np.array([t is not None for t in lab], bool)
+        toks, first_idx, cnts = np.unique(lab[has].astype(str), return_index=True, return_counts=True)
+        where = np.nonzero(has)[0][first_idx]
+        for t, g, c in zip(toks, where, cnts):   # LABEL sits after <q> [TASK] [qu qv] <p>
+            entries.append((str(t), int(c), int(gkey[g] + q_pos[g] + (1 if task is not None else 0) + nq[g] + 2)))
+    # structure tokens are all in SPECIAL already; Counter.most_common = count descending, ties by first appearance
+    entries.sort(key=lambda r: (-r[1], r[2]))
+    vocab = {tok: i for i, tok in enumerate(SPECIAL)}
+    for tok, c, _ in entries:
+        if tok in vocab:
+            continue
+        if c < min_freq:
+            break
+        vocab[tok] = len(vocab)
+        if max_tokens and len(vocab) >= max_tokens:
+            break
+    return vocab, {i: t for t, i in vocab.items()}
+
+
+def build_vocab_from_graphs(batch, num_ids: int, task: Optional[str] = None, label_tokens=None, query_nodes=None,
+                            min_freq: int = 1, max_tokens: Optional[int] = None):
+    """build_vocab_from_texts without the texts: node-id token statistics on the device (one launch over the
+    CSR-resident corpus), then vocab_from_stats.  `batch` is a device GraphBatch; query_nodes int32 [G, 2] or None."""
+    import numpy as np
+    q = None
+    if query_nodes is not None:
+        q = torch.as_tensor(np.asarray(query_nodes, dtype=np.int32).reshape(-1, 2))
+    count, first = _ops.vocab_stats_synth(batch, num_ids, q)
+    nc = (batch.node_ptr[1:] - batch.node_ptr[:-1]).cpu().numpy()
+    ec = (batch.edge_ptr[1:] - batch.edge_ptr[:-1]).cpu().numpy()
+    return vocab_from_stats(count.cpu().numpy(), first.cpu().numpy(), nc, ec, task, label_tokens, query_nodes,
+                            min_freq, max_tokens)
+
+
 # ------------------------------------------------------------------------------------------------ dataset
 class TokenDataset(Dataset):
     """Eager text -> ids, like the reference (:465-486), but the whole corpus goes through ONE

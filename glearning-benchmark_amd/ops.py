@@ -168,6 +168,32 @@ def collate(ids: torch.Tensor, ln: torch.Tensor, index: torch.Tensor, pad_id: in
 # ------------------------------------------------------------------------------------------------
 # text -> ids (TokenDataset)
 # ------------------------------------------------------------------------------------------------
+def vocab_stats_synth(batch: GraphBatch, num_ids: int, query_nodes: Optional[torch.Tensor] = None, graph_base: int = 0,
+                      out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Occurrence count and first position ((graph_base + g) << 32 | position in the text) of every node-id token
+    `str(i)`, i < num_ids, in the graph-token texts this batch stands for: the corpus pass of
+    build_vocab_from_texts (data_loader.py:451-463) on the device.  query_nodes: int32 [G, 2] (u, v), negative = none.
+    `out` = (count, first) int64 [num_ids] to ACCUMULATE into (shards / ranks); fresh tables otherwise."""
+    dev = batch.device
+    _need_gpu(batch.col, "vocab_stats_synth")
+    if out is None:
+        count = torch.zeros(num_ids, dtype=torch.int64, device=dev)
+        first = torch.full((num_ids,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    else:
+        count, first = out
+        if count.dtype != torch.int64 or first.dtype != torch.int64 or count.numel() != num_ids or first.numel() != num_ids:
+            raise ValueError("out must be two int64 [num_ids] tensors")
+    if query_nodes is not None:
+        if query_nodes.dtype != torch.int32 or tuple(query_nodes.shape) != (batch.num_graphs, 2):
+            raise ValueError("query_nodes must be int32 [G, 2]")
+        query_nodes = query_nodes.to(dev).contiguous()
+    cs = batch.c_struct()
+    _lib.check(_lib.lib().gtok_vocab_stats_synth(ctypes.byref(cs), None if query_nodes is None else query_nodes.data_ptr(),
+                                                 int(graph_base), int(num_ids), count.data_ptr(), first.data_ptr(),
+                                                 _stream(dev)), "gtok_vocab_stats_synth")
+    return count, first
+
+
 def _fnv1a(b: bytes) -> int:
     h = 2166136261
     for c in b:

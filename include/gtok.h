@@ -20,11 +20,15 @@
  *   gtok_remap_zinc    trainer/train_agtt.py:171-244 on an existing token slab
  *   gtok_collate       data_loader.py:488-497 and trainer/train_agtt.py:276-302
  *                      (gather rows of a batch, pad to the batch max, bool mask)
+ *   gtok_vocab_stats_synth  the corpus pass of build_vocab_from_texts
+ *                      (data_loader.py:451-463) for graph-token corpora held as
+ *                      CSR: per node-id token, occurrence count and first position
  *
  * Conventions: all pointers are DEVICE pointers borrowed from the caller
  * (never freed or retained), `stream` is a hipStream_t passed as void*, the
- * call only enqueues work on that stream (no allocation, no synchronisation:
- * safe under hipGraph capture), outputs are caller-allocated.  Return value is
+ * call only enqueues work on that stream (no synchronisation; the only allocation
+ * is a small per-device block of work-queue counters on a device's FIRST launch,
+ * so warm up once before capturing a hipGraph), outputs are caller-allocated.  Return value is
  * 0 or a negative GTOK_E_* code; nothing throws across the ABI.  Re-entrant.
  *
  * Output convention of every tokenizer entry point: out_ids is a row-major
@@ -191,6 +195,22 @@ int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len,
                  const int64_t *index, int32_t batch, int32_t pad_id,
                  int64_t *out_x, uint8_t *out_attn, int32_t out_ld,
                  int32_t *batch_max, void *stream);
+
+/* Node-id token statistics of the graph-token texts this batch stands for
+ * (`<bos> u v <e> ... <n> 0 .. N-1 <q> TASK [qu qv] <p> LABEL <eos>`,
+ * graph_token_dataset_autograph.py / docs/synthetic_data.md:46-68) - the corpus
+ * pass of build_vocab_from_texts (data_loader.py:451-463) without the texts:
+ * for every id i < num_ids,
+ *   count[i] += occurrences of the token str(i): edge endpoints (list order),
+ *               the <n> list, the two query arguments (query_nodes[g] = (u, v),
+ *               NULL or negative entries = none);
+ *   first[i]  = min(first[i], (graph_base + g) << 32 | token position in the text
+ *               of graph g) over those occurrences.
+ * The caller initialises count to 0 and first to INT64_MAX; calls ACCUMULATE, so
+ * shards, ranks and epochs can be summed / min-reduced.  num_ids <= 1024.      */
+int gtok_vocab_stats_synth(const gtok_csr *g, const int32_t *query_nodes,
+                           int64_t graph_base, int32_t num_ids, int64_t *count,
+                           int64_t *first, void *stream);
 
 /* Which SENT kernel gtok_sent() will run for this batch ("sent_lane_kernel": lane per graph, needs
  * GTOK_CSR_SIMPLE_SYMMETRIC and a large batch; "sent_reg_kernel": wave per graph, <= 64 nodes;

@@ -110,6 +110,15 @@ def collate(ids, ln, index, pad_id, out_ld):
     return X, A.astype(bool), int(m[0])
 
 
+def vocab_stats_synth(coo: Coo, num_ids, query_nodes=None, graph_base=0):
+    """(count, first) int64 [num_ids]: what build_vocab_from_texts would see for the tokens str(0..num_ids-1)."""
+    count = np.zeros(num_ids, np.int64); first = np.full(num_ids, np.iinfo(np.int64).max, np.int64)
+    q = None if query_nodes is None else np.ascontiguousarray(query_nodes, dtype=np.int32)
+    lib().oracle_vocab_stats_synth(ctypes.c_int32(coo.G), _p(coo.node_ptr), _p(coo.edge_ptr), _p(coo.src), _p(coo.dst),
+                                   _p(q), ctypes.c_int64(graph_base), ctypes.c_int32(num_ids), _p(count), _p(first))
+    return count, first
+
+
 def remap_zinc(ids, ln, idx_off, node_off, edge_off):
     ids = np.ascontiguousarray(ids, np.int32); ln = _i32(ln)
     out = np.empty_like(ids)

@@ -31,6 +31,13 @@ def _worker(rank, world, port, G, q):
         ref_ids, ref_ln = orc.sent(coo, int(coo.node_counts.max()), 1024, 11, 2, ld=160, **kw)
         ok = (max_nodes == int(coo.node_counts.max()) and tuple(full_ids.shape) == (G, 160)
               and np.array_equal(full_ids.numpy(), ref_ids) and np.array_equal(full_ln.numpy(), ref_ln))
+        # corpus-wide vocab statistics from per-rank tables (SUM / MIN all-reduce)
+        s = gtok.synth.graph_token_like(G, seed=78, with_text=False)
+        sc = orc.Coo(s["node_counts"], s["edge_counts"], s["src"], s["dst"])
+        c, f = orc.vocab_stats_synth(sc.slice(lo, hi), 64, graph_base=lo)
+        c, f = gtok.dist.reduce_vocab_stats(torch.from_numpy(c), torch.from_numpy(f))
+        wc, wf = orc.vocab_stats_synth(sc, 64)
+        ok = ok and np.array_equal(c.numpy(), wc) and np.array_equal(f.numpy(), wf)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

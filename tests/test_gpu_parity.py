@@ -348,3 +348,41 @@ def test_ibtt_zinc_large_symmetric_graphs(pin, monkeypatch):
         ids, ln = gtok.ops.ibtt_zinc(batch.to(DEV), lut, max_len, vocab["<pad>"], ld=ld)
         ref, rln = orc.ibtt_zinc(coo, lut.numpy(), max_len, vocab["<pad>"], ids.shape[1])
         _cmp(ids, ln, ref, rln, f"ibtt_zinc large [{pin}] max_len={max_len}")
+
+
+@pytest.mark.parametrize("task", ["cycle_check", "shortest_path"])
+def test_vocab_stats_synth_and_vocab_from_graphs(task):
+    """§8f-1: node-id token statistics on the device == the oracle's restatement (sorted and unsorted edge lists,
+    query arguments, shards accumulated into one table), and the vocab built from them == build_vocab_from_texts."""
+    import importlib
+    dl = importlib.import_module("glearning-benchmark_amd.graph_data_loader.data_loader")
+    d = gtok.synth.graph_token_like(900, seed=12, task=task, min_nodes=2, max_nodes=70)
+    q = None
+    if task == "shortest_path":
+        q = np.array([qq if qq is not None else (-1, -1) for qq in d["queries"]], np.int32)
+    tq = None if q is None else torch.from_numpy(q)
+    for shuffle in (False, True):
+        dd = dict(d)
+        if shuffle:   # edge lists in arbitrary order inside each graph: the CSR keeps the list position in eorder
+            rng = np.random.default_rng(3)
+            gid = np.repeat(np.arange(900), d["edge_counts"])
+            order = np.lexsort((rng.random(gid.size), gid))
+            dd["src"], dd["dst"] = d["src"][order], d["dst"][order]
+        batch, coo = both(dd, False)
+        assert (batch.eorder is not None) == shuffle
+        want = orc.vocab_stats_synth(coo, 80, q, graph_base=1000)
+        count, first = gtok.ops.vocab_stats_synth(batch.to(DEV), 80, tq, graph_base=1000)
+        assert np.array_equal(count.cpu().numpy(), want[0]) and np.array_equal(first.cpu().numpy(), want[1]), shuffle
+        # two shards accumulated into the same tables
+        acc = None
+        for lo, hi in ((0, 400), (400, 900)):
+            acc = gtok.ops.vocab_stats_synth(batch.shard(lo, hi).to(DEV), 80, None if tq is None else tq[lo:hi],
+                                             graph_base=1000 + lo, out=acc)
+        assert np.array_equal(acc[0].cpu().numpy(), want[0]) and np.array_equal(acc[1].cpu().numpy(), want[1])
+    batch, _ = both(d, False)
+    tails = [t.split("<p>")[1].split()[0] for t in d["texts"]]
+    tname = "has_cycle" if task == "cycle_check" else "shortest_distance"
+    for min_freq, max_tokens in ((1, None), (1, 50), (4, 600)):
+        want, _ = dl.build_vocab_from_texts(d["texts"], min_freq, max_tokens)
+        got, _ = dl.build_vocab_from_graphs(batch.to(DEV), 80, tname, tails, q, min_freq, max_tokens)
+        assert got == want

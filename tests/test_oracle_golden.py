@@ -189,3 +189,27 @@ def test_sent_truncation_is_a_prefix_and_epochs_differ():
     # shard invariance: graph_base continues the global index
     part, pl = orc.sent(coo.slice(100, 200), 37, 1024, 5, 0, ld=512, graph_base=100, **kw)
     assert np.array_equal(part, full[100:]) and np.array_equal(pl, fl[100:])
+
+
+@pytest.mark.parametrize("task", ["cycle_check", "shortest_path"])
+def test_vocab_from_graph_statistics_equals_vocab_from_texts(task):
+    """§8f-1: the corpus pass of build_vocab_from_texts (pinned to the reference by test_vocab_builders_match_reference)
+    replaced by node-id token statistics computed from the edge lists: same vocab, same ids, for every cut."""
+    import importlib
+    dl = importlib.import_module("glearning-benchmark_amd.graph_data_loader.data_loader")
+    d = gtok.synth.graph_token_like(700, seed=11, task=task, min_nodes=3, max_nodes=60)
+    coo = orc.Coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"])
+    q = None
+    if task == "shortest_path":
+        q = np.array([qq if qq is not None else (-1, -1) for qq in d["queries"]], np.int32)
+    count, first = orc.vocab_stats_synth(coo, 64, q)
+    tails = [t.split("<p>")[1].split()[0] for t in d["texts"]]       # the label token of every text
+    tname = "has_cycle" if task == "cycle_check" else "shortest_distance"
+    for min_freq, max_tokens in ((1, None), (1, 40), (5, None), (300, 600)):
+        want, _ = dl.build_vocab_from_texts(d["texts"], min_freq, max_tokens)
+        got, _ = dl.vocab_from_stats(count, first, d["node_counts"], d["edge_counts"], tname, tails, q, min_freq, max_tokens)
+        assert got == want, (task, min_freq, max_tokens)
+    # statistics of shards add up / min-reduce to the statistics of the corpus (how ranks combine theirs)
+    a = orc.vocab_stats_synth(coo.slice(0, 300), 64, None if q is None else q[:300], 0)
+    b = orc.vocab_stats_synth(coo.slice(300, 700), 64, None if q is None else q[300:], 300)
+    assert np.array_equal(a[0] + b[0], count) and np.array_equal(np.minimum(a[1], b[1]), first)
