@@ -386,3 +386,50 @@ def test_vocab_stats_synth_and_vocab_from_graphs(task):
         want, _ = dl.build_vocab_from_texts(d["texts"], min_freq, max_tokens)
         got, _ = dl.build_vocab_from_graphs(batch.to(DEV), 80, tname, tails, q, min_freq, max_tokens)
         assert got == want
+
+
+def _rings_with_chords(sizes, chords, seed):
+    """Simple symmetric graphs (ring + random chords), both directions listed, row-sorted, typed."""
+    rng = np.random.default_rng(seed)
+    ncs, ecs, srcs, dsts = [], [], [], []
+    for n in sizes:
+        pairs = {(i, (i + 1) % n) if i < (i + 1) % n else ((i + 1) % n, i) for i in range(n)} if n > 2 else set()
+        while len(pairs) < min((n if n > 2 else 0) + chords, n * (n - 1) // 2) and n > 3:
+            a, b = sorted(rng.integers(0, n, 2).tolist())
+            if a != b:
+                pairs.add((a, b))
+        e = np.array(sorted(pairs), np.int64).reshape(-1, 2)
+        s = np.concatenate([e[:, 0], e[:, 1]]); t = np.concatenate([e[:, 1], e[:, 0]])
+        o = np.lexsort((t, s))
+        ncs.append(n); ecs.append(s.size); srcs.append(s[o]); dsts.append(t[o])
+    src, dst = np.concatenate(srcs), np.concatenate(dsts)
+    N = int(np.sum(ncs))
+    return dict(node_counts=np.array(ncs), edge_counts=np.array(ecs), src=src, dst=dst,
+                x=rng.integers(0, 30, N), edge_attr=np.minimum(src, dst) % 7)   # symmetric edge types
+
+
+@pytest.mark.parametrize("top", [64, 65, 128, 129, 256, 257, 512])
+def test_sent_at_the_size_boundaries_of_the_kernels(top, monkeypatch):
+    """Batches whose largest graph sits exactly at / just past 64, 128, 256 nodes (lane / register kernels stop at
+    64; the LDS kernel switches its word count W at each power of two) and at the 512-node limit; 254 entries is
+    the most a lane-kernel graph may list (u8 row pointers)."""
+    sizes = [top, top - 1, top - 2, 3, 1, 0] * 3
+    chords = 63 if top == 64 else 40          # 64-node ring + 63 chords = 127 edges = 254 entries
+    d = _rings_with_chords(sizes, chords, seed=top)
+    batch, coo = both(d)
+    assert batch.flags & 1
+    pins = ["lane", "reg", "lds"] if top <= 64 else ["lds"]
+    for pin in pins:
+        monkeypatch.setenv("GTOK_SENT_KERNEL", pin)
+        for labeled in (True, False):
+            b2, c2 = both(d, labeled)
+            kw = dict(labeled=labeled, num_node_types=28 if labeled else 0, num_edge_types=5 if labeled else 0)
+            for max_len in (4096, 100):
+                ids, ln = gtok.ops.sent(b2.to(DEV), top, max_len, 7, 1, **kw)
+                ref, rln = orc.sent(c2, top, max_len, 7, 1, ld=ids.shape[1], **kw)
+                _cmp(ids, ln, ref, rln, f"sent boundary top={top} [{pin}] labeled={labeled} max_len={max_len}")
+    if top == 512:
+        big = _rings_with_chords([513, 4], 3, seed=1)
+        bb, _ = both(big, False)
+        with pytest.raises(gtok.GtokError):
+            gtok.ops.sent(bb.to(DEV), 513, 64, 0)
