@@ -241,6 +241,38 @@ def main():
                                                     frac=round(vb / vk / 1e9 / HBM_PEAK_GBS, 5), traffic=None,
                                                     algorithmic_bytes_per_launch=int(vb)))
 
+    # TokenDataset's text -> ids on the graph-token TEXT of a bounded slice of the same corpus (the
+    # texts are rendered on the host, which is the slow part; outside the timed region)
+    if not zinc and not args.no_ibtt:
+        S = min(G, 4096)
+        nc, ec = d["node_counts"][:S], d["edge_counts"][:S]
+        eptr = np.concatenate([[0], np.cumsum(ec)])
+        texts = []
+        for g in range(S):
+            u = d["src"][eptr[g]:eptr[g + 1]].tolist(); v = d["dst"][eptr[g]:eptr[g + 1]].tolist()
+            body = " ".join(f"{a} {b} <e>" for a, b in zip(u, v))
+            texts.append(" ".join(t for t in ("<bos>", body, "<n>", " ".join(map(str, range(int(nc[g])))),
+                                              "<q> has_cycle <p> yes <eos>") if t))
+        tb, tp = gtok.ops.pack_texts(texts)
+        tb, tp = tb.to(dev), tp.to(dev)
+        table = gtok.ops.VocabTable(vocab, dev)
+        tids = torch.empty((S, ild), dtype=torch.int32, device=dev); tln = torch.empty(S, dtype=torch.int32, device=dev)
+        ft = lambda k: gtok.ops.text_to_ids(tb, tp, table, max_len, True, ld=ild, out=(tids, tln))
+        for _ in range(args.warmup):
+            ft(0)
+        twall, tk_ms = timed_loop(ft, args.steps, multi)
+        same = bool(torch.equal(tids, iids[:S]) and torch.equal(tln, iln[:S]))     # the CSR path emits the same ids
+        tk = float(np.mean(tk_ms)) * 1e-3
+        # the tokenizer stops at max_len tokens: algorithmic read = the text up to the end of the last kept token
+        need = sum(len(" ".join(t.split()[:max_len])) for t in texts)
+        tbytes = float(need) + 4.0 * float(tln.sum().item()) + 4.0 * S
+        out["text_to_ids"] = dict(kernel="text_ids_kernel", texts=S, text_bytes=int(tb.numel()), text_bytes_needed=int(need),
+                                  graphs_per_sec_per_gpu=round(S * args.steps / twall, 1), kernel_ms=round(tk * 1e3, 4),
+                                  equals_csr_path=same,
+                                  roofline=dict(bound="hbm", achieved=round(tbytes / tk / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                                frac=round(tbytes / tk / 1e9 / HBM_PEAK_GBS, 5), traffic=None,
+                                                algorithmic_bytes_per_launch=int(tbytes)))
+
     # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
     if multi:
         gtok.dist.gather_tokens(ids, lens[-1], world * G, 5)

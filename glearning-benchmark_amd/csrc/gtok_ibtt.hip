@@ -763,69 +763,159 @@ struct TextArgs {
   gtok_vocab_table v;
   int strip_label, cap, max_len, pad_id;
   int32_t *out; int ld; int32_t *out_len;
-  int units, upb, tok_stride;
+  int units, upb;
+  int off_vocab, off_wave, ring_off, tok_off, wave_stride;   // LDS: [vocab slots (VLDS)] then per wave: text ring, tokens
 };
 
-__global__ void __launch_bounds__(256) text_ids_kernel(const TextArgs a) {
+// The text of one graph is read ONCE, 16 bytes per lane and load, into a 2 KB LDS ring (the chunk being split and
+// the next one, so a token may run up to 1 KB past its chunk; beyond that bytes come from global), the chunk after
+// that is requested before the current one is processed, and - VLDS - the vocab table is copied into LDS once per
+// workgroup as 24-byte slots {id, length, first 19 key bytes} (longer keys finish their compare in global memory).
+// The previous version read the text a byte per lane and hashed / probed straight from global memory: ~10
+// dependent round trips per 64 bytes of text.
+constexpr int kTextChunk = 1024, kTextRing = 2 * kTextChunk, kSlotBytes = 24, kSlotKey = 19;
+
+template <bool VLDS>
+__global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
-  int32_t *tok = reinterpret_cast<int32_t *>(smem + (size_t)wave * a.tok_stride);
+  unsigned char *vs = smem + a.off_vocab;
+  unsigned char *wbase = smem + a.off_wave + (size_t)wave * a.wave_stride;
+  uint8_t *ring = wbase + a.ring_off;
+  int32_t *tok = reinterpret_cast<int32_t *>(wbase + a.tok_off);
   const int cap = a.cap;
   const uint32_t mask = (uint32_t)a.v.capacity - 1u;
+  const int64_t total = a.text_ptr[a.num_texts];
+
+  if (VLDS) {   // slot s: id (4 B), length (1 B; 255 = empty), key bytes (one unaligned 16-byte load + 3 bytes)
+    // bytes readable at key_bytes = the end of the last key (the ABI carries no length): found first, so that the
+    // vector loads below never leave the array
+    int *kb_end = reinterpret_cast<int *>(smem + a.off_wave - 16);
+    if (threadIdx.x == 0) *kb_end = 0;
+    __syncthreads();
+    int my_end = 0;
+    for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
+      const int off = a.v.key_off[sl];
+      if (off >= 0) my_end = max(my_end, off + a.v.key_len[sl]);
+    }
+    atomicMax(kb_end, my_end);
+    __syncthreads();
+    const int kb_total = *kb_end;
+    for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
+      unsigned char *d = vs + (size_t)sl * kSlotBytes;
+      const int off = a.v.key_off[sl], len = off < 0 ? 255 : min(a.v.key_len[sl], 254);
+      uint32_t w[5] = {0, 0, 0, 0, 0};
+      if (off >= 0) {
+        if (off + 20 <= kb_total) {
+          const U8x16 x = *reinterpret_cast<const U8x16 *>(a.v.key_bytes + off);
+          w[0] = x.a; w[1] = x.b; w[2] = x.c; w[3] = x.d;
+          w[4] = (uint32_t)a.v.key_bytes[off + 16] | ((uint32_t)a.v.key_bytes[off + 17] << 8) | ((uint32_t)a.v.key_bytes[off + 18] << 16);
+        } else {
+          for (int j = 0; j < kSlotKey && off + j < kb_total; ++j) w[j >> 2] |= (uint32_t)a.v.key_bytes[off + j] << (8 * (j & 3));
+        }
+      }
+      *reinterpret_cast<int32_t *>(d) = a.v.id[sl];
+      d[4] = (unsigned char)len;
+      for (int j = 0; j < kSlotKey; ++j) d[5 + j] = (unsigned char)((j < len) ? (w[j >> 2] >> (8 * (j & 3))) & 255u : 0u);
+    }
+    __syncthreads();   // the only workgroup barrier: before any wave can leave
+  }
+  auto load16 = [&](int64_t abs) -> U8x16 {   // never touches bytes past the end of the blob
+    if (abs + 16 <= total) return *reinterpret_cast<const U8x16 *>(a.bytes + abs);
+    uint32_t w[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+    for (int b = 0; b < 16; ++b)
+      if (abs + b < total) w[b >> 2] = (w[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | ((uint32_t)a.bytes[abs + b] << (8 * (b & 3)));
+    return U8x16{w[0], w[1], w[2], w[3]};
+  };
+  U8x16a *ring16 = reinterpret_cast<U8x16a *>(ring);
 
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
   for (int unit = u0; unit < u1; ++unit) {
     const int g = unit * wpb + wave;
     if (g >= a.num_texts) break;
-    const uint8_t *__restrict__ s = a.bytes + a.text_ptr[g];
-    const int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
+    const int64_t t0 = a.text_ptr[g];
+    const uint8_t *__restrict__ s = a.bytes + t0;
+    const int64_t n = a.text_ptr[g + 1] - t0;
+    // ring <- chunks 0 and 1
+    wave_sync();
+    {
+      const U8x16 x0 = load16(t0 + lane * 16), x1 = load16(t0 + kTextChunk + lane * 16);
+      ring16[lane] = U8x16a{x0.a, x0.b, x0.c, x0.d};
+      ring16[64 + lane] = U8x16a{x1.a, x1.b, x1.c, x1.d};
+    }
+    wave_sync();
     int count = 0;
     bool prev_sp = true;  // carry: was the byte before this chunk whitespace
     bool done = false;
-    for (int64_t b0 = 0; b0 < n && count < a.max_len && !done; b0 += kWave) {
-      const int64_t i = b0 + lane;
-      const uint32_t c = (i < n) ? s[i] : 32u;
-      const bool sp = py_isspace(c);
-      const uint64_t spm = __ballot(sp);
-      const bool before = lane == 0 ? prev_sp : ((spm >> (lane - 1)) & 1ull);
-      const bool start = !sp && before;
-      const uint64_t sm = __ballot(start);
-      prev_sp = (spm >> 63) & 1ull;
-      if (sm == 0) continue;
-      int id = a.pad_id;
-      bool is_p = false;
-      const int t = count + __popcll(sm & lanemask_lt());
-      if (start && t < a.max_len) {
-        // hash the token (FNV-1a), then probe the open-addressing table
-        uint32_t h = 2166136261u;
-        int len = 0;
-        for (int64_t j = i; j < n; ++j) {
-          const uint32_t cj = s[j];
-          if (py_isspace(cj)) break;
-          h = (h ^ cj) * 16777619u;
-          ++len;
+    for (int64_t c0 = 0; c0 < n && count < a.max_len && !done; c0 += kTextChunk) {
+      const int64_t have = c0 + kTextRing;                       // bytes below this offset are in the ring
+      const U8x16 nxt = load16(t0 + c0 + kTextRing + lane * 16);   // chunk +2: in flight while this one is split
+      auto byte_at = [&](int64_t j) -> uint32_t { return j < have ? ring[j & (kTextRing - 1)] : s[j]; };
+      for (int sub = 0; sub < kTextChunk / kWave && count < a.max_len && !done; ++sub) {
+        const int64_t b0 = c0 + sub * kWave;
+        if (b0 >= n) break;
+        const int64_t i = b0 + lane;
+        const uint32_t c = (i < n) ? ring[i & (kTextRing - 1)] : 32u;
+        const bool sp = py_isspace(c);
+        const uint64_t spm = __ballot(sp);
+        const bool before = lane == 0 ? prev_sp : ((spm >> (lane - 1)) & 1ull);
+        const bool start = !sp && before;
+        const uint64_t sm = __ballot(start);
+        prev_sp = (spm >> 63) & 1ull;
+        if (sm == 0) continue;
+        int id = a.pad_id;
+        bool is_p = false;
+        const int t = count + __popcll(sm & lanemask_lt());
+        if (start && t < a.max_len) {
+          // hash the token (FNV-1a), then probe the open-addressing table
+          uint32_t h = 2166136261u;
+          int len = 0;
+          for (int64_t j = i; j < n; ++j) {
+            const uint32_t cj = byte_at(j);
+            if (py_isspace(cj)) break;
+            h = (h ^ cj) * 16777619u;
+            ++len;
+          }
+          is_p = (len == 3) && c == '<' && byte_at(i + 1) == 'p' && byte_at(i + 2) == '>';
+          for (uint32_t slot = h & mask, probes = 0; probes <= mask; slot = (slot + 1) & mask, ++probes) {
+            if (VLDS) {
+              const unsigned char *d = vs + (size_t)slot * kSlotBytes;
+              const int kl = d[4];
+              if (kl == 255) break;
+              if (kl != min(len, 254)) continue;
+              bool eq = true;
+              for (int j = 0; j < min(len, kSlotKey) && eq; ++j) eq = d[5 + j] == byte_at(i + j);
+              if (eq && len > kSlotKey) {   // long key: the rest (and keys of 254+ bytes: everything) from global
+                const int off = a.v.key_off[slot];
+                eq = a.v.key_len[slot] == len;
+                for (int j = kSlotKey; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == byte_at(i + j);
+              }
+              if (eq) { id = *reinterpret_cast<const int32_t *>(d); break; }
+            } else {
+              const int off = a.v.key_off[slot];
+              if (off < 0) break;
+              if (a.v.key_len[slot] != len) continue;
+              bool eq = true;
+              for (int j = 0; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == byte_at(i + j);
+              if (eq) { id = a.v.id[slot]; break; }
+            }
+          }
+          if (t < cap) tok[t] = id;
         }
-        is_p = (len == 3) && s[i] == '<' && s[i + 1] == 'p' && s[i + 2] == '>';
-        for (uint32_t slot = h & mask, probes = 0; probes <= mask; slot = (slot + 1) & mask, ++probes) {
-          const int off = a.v.key_off[slot];
-          if (off < 0) break;
-          if (a.v.key_len[slot] != len) continue;
-          bool eq = true;
-          for (int j = 0; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == s[i + j];
-          if (eq) { id = a.v.id[slot]; break; }
+        uint64_t pm = a.strip_label ? (uint64_t)__ballot(start && is_p) : 0ull;
+        if (pm) {  // data_loader.py:479-481: keep up to and including the first <p>
+          const int first = __ffsll((unsigned long long)pm) - 1;
+          count += __popcll(sm & ((2ull << first) - 1ull));
+          done = true;
+        } else {
+          count += __popcll(sm);
         }
-        if (t < cap) tok[t] = id;
       }
-      uint64_t pm = a.strip_label ? (uint64_t)__ballot(start && is_p) : 0ull;
-      if (pm) {  // data_loader.py:479-481: keep up to and including the first <p>
-        const int first = __ffsll((unsigned long long)pm) - 1;
-        count += __popcll(sm & ((2ull << first) - 1ull));
-        done = true;
-      } else {
-        count += __popcll(sm);
-      }
+      wave_sync();   // every lane is done with chunk c0: its half of the ring takes chunk +2
+      ring16[((c0 / kTextChunk) & 1) * 64 + lane] = U8x16a{nxt.a, nxt.b, nxt.c, nxt.d};
+      wave_sync();
     }
     wave_sync();
     const int len = min(count, a.max_len);
@@ -1094,18 +1184,26 @@ extern "C" int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr, i
   a.bytes = bytes; a.text_ptr = text_ptr; a.num_texts = num_texts; a.v = *vocab;
   a.strip_label = strip_label; a.pad_id = vocab->pad_id; a.max_len = max_len;
   a.cap = max_len < ld ? max_len : ld;
-  a.tok_stride = align_up((a.cap > 0 ? a.cap : 1) * 4, 16);
-  if (a.tok_stride > 160 * 1024) return GTOK_E_TOO_LARGE;
-  int wpb = 4;
-  while (wpb > 1 && wpb * a.tok_stride > 64 * 1024) wpb >>= 1;
-  const size_t lds = (size_t)wpb * a.tok_stride;
+  const bool vlds = vocab->capacity <= 1024;   // 24 KB of slots per workgroup
+  a.off_vocab = 0;
+  a.off_wave = vlds ? align_up(vocab->capacity * kSlotBytes, 16) + 16 : 0;   // + one scratch word for the staging pass
+  a.ring_off = 0;
+  a.tok_off = kTextRing;
+  const int64_t wave_bytes = kTextRing + (int64_t)align_up((a.cap > 0 ? a.cap : 1) * 4, 16);
+  if (wave_bytes + a.off_wave > 160 * 1024) return GTOK_E_TOO_LARGE;
+  a.wave_stride = (int)wave_bytes;
+  int wpb = vlds ? 8 : 4;   // the LDS vocab is per workgroup: more waves share one copy
+  while (wpb > 1 && a.off_wave + wpb * a.wave_stride > 64 * 1024) wpb >>= 1;
+  const size_t lds = (size_t)a.off_wave + (size_t)wpb * a.wave_stride;
+  typedef void (*K)(const TextArgs);
+  K kern = vlds ? (K)text_ids_kernel<true> : (K)text_ids_kernel<false>;
   if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void *>(text_ids_kernel),
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GTOK_E_LAUNCH;
-  const Launch L = plan(reinterpret_cast<const void *>(text_ids_kernel), num_texts, wpb, lds);
+  const Launch L = plan(reinterpret_cast<const void *>(kern), num_texts, wpb, lds);
   a.out = out_ids; a.ld = ld; a.out_len = out_len; a.units = L.units; a.upb = L.upb;
-  hipLaunchKernelGGL(text_ids_kernel, dim3(L.nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kern, dim3(L.nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 

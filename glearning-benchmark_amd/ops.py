@@ -246,14 +246,14 @@ def pack_texts(texts: Sequence[str]) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def text_to_ids(text_bytes: torch.Tensor, text_ptr: torch.Tensor, table: VocabTable, max_len: int,
-                strip_label: bool = True, ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                strip_label: bool = True, ld: Optional[int] = None, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
     _need_gpu(text_bytes, "text_to_ids")
     dev = text_bytes.device
     text_ptr = text_ptr.to(dev, dtype=torch.int64).contiguous()
     G = int(text_ptr.numel()) - 1
     if ld is None:
         ld = _round4(max_len)
-    ids, ln = _alloc_out(G, ld, dev)
+    ids, ln = _alloc_out(G, ld, dev, out)
     vs = table.c_struct()
     check(lib().gtok_text_to_ids(text_bytes.data_ptr(), text_ptr.data_ptr(), G, ctypes.byref(vs), int(strip_label),
                                  max_len, ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)), "gtok_text_to_ids")

@@ -433,3 +433,33 @@ def test_sent_at_the_size_boundaries_of_the_kernels(top, monkeypatch):
         bb, _ = both(big, False)
         with pytest.raises(gtok.GtokError):
             gtok.ops.sent(bb.to(DEV), 513, 64, 0)
+
+
+def test_text_to_ids_long_tokens_chunk_borders_and_big_vocab():
+    """The text kernel splits 1 KB chunks out of a 2 KB LDS ring: tokens that straddle chunk borders, tokens longer
+    than the ring (bytes past it come from global memory), keys longer than the 19 bytes an LDS vocab slot holds, and
+    a vocab too large for LDS (> 1024 slots: table probed in global memory) must all give the oracle's ids."""
+    rng = np.random.default_rng(9)
+    words = ["<bos>", "<e>", "<n>", "<q>", "<p>", "yes", "shortest_distance", "a_token_of_exactly_24_by", "k" * 19, "k" * 20,
+             "L" * 1500, "M" * 3000, "q"] + [str(i) for i in range(300)]
+    texts = []
+    for t in range(40):
+        toks = [words[int(j)] for j in rng.integers(0, len(words), int(rng.integers(1, 900)))]
+        seps = [" " * int(rng.integers(1, 4)) if rng.random() < 0.9 else "\n\t " for _ in toks]
+        texts.append("".join(a + b for a, b in zip(toks, seps)))
+    texts += ["w" * 1023 + " x", "w" * 1024 + " x", "w" * 1025 + " x y", " " * 2047 + "q", "q" * 2049, ""]
+    small = {"<pad>": 0}
+    for w in words:
+        small.setdefault(w, len(small))
+    big = dict(small)
+    for i in range(3000):
+        big.setdefault(f"val_{i}", len(big))
+    tb, tp = gtok.ops.pack_texts(texts)
+    for vocab in (small, big):
+        table = gtok.ops.VocabTable(vocab, DEV)
+        assert (table.capacity <= 1024) == (vocab is small)
+        for strip in (True, False):
+            for max_len in (2048, 37):
+                ids, ln = gtok.ops.text_to_ids(tb.to(DEV), tp, table, max_len, strip_label=strip)
+                ref, rln = orc.text_to_ids(texts, vocab, max_len, ids.shape[1], strip_label=strip)
+                _cmp(ids, ln, ref, rln, f"text vocab={len(vocab)} strip={strip} max_len={max_len}")
