@@ -393,10 +393,15 @@ struct ZincQuadArgs {
 // stores with the padding merged in (the rows are adjacent in the slab): every line is written once, in full.
 // Without it (slabs too wide for LDS) tokens and padding go out as they are produced, in 100-250 byte pieces,
 // and the store stream is twice as expensive (measured 0.068 vs 0.035 ms for ZINC-full's 240 MB slab).
-template <bool ROWS>
+// GS = lanes per molecule (16 or 8): 64 / GS molecules per wave.  Eight lanes halve the instructions per molecule
+// (a molecule's ~50 entries fill 7 passes of 8 lanes instead of 4 passes of 16 with a third of the lanes idle) as
+// long as the molecules are small; NP / EP = node / entry passes whose loads travel through the register pipeline.
+template <bool ROWS, int GS>
 __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a) {
+  constexpr int NG = kWave / GS, NP = GS == 16 ? 4 : 6, EP = GS == 16 ? 8 : 12;
+  constexpr uint32_t kGroupBits = (1u << GS) - 1u;
   extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = lane_id(), grp = lane >> 4, ql = lane & 15;
+  const int lane = lane_id(), grp = lane / GS, ql = lane % GS;
   uint16_t *rmap = reinterpret_cast<uint16_t *>(smem + a.off_map) + grp * a.maxe;
   int32_t *slut = reinterpret_cast<int32_t *>(smem + a.off_lut);
   int32_t *srow = reinterpret_cast<int32_t *>(smem + a.off_row);
@@ -417,12 +422,12 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
   const int Ntot = sload(a.g.node_ptr, G);
   const bool ld_na = has_na && Ntot > 0, ld_ea = has_ea && Etot > 0, ld_col = Etot > 0;
   struct Hdr { int nb0, n, e; int64_t e0; };
-  struct Dat { int rs[4], re[4], x[4], v[8], at[8]; };
+  struct Dat { int rs[NP], re[NP], x[NP], v[EP], at[EP]; };
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
   auto load_hdr = [&](int unit) -> Hdr {
     Hdr h{0, 0, 0, 0};
-    const int g = unit * 4 + grp;
+    const int g = unit * NG + grp;
     if (unit < u1 && g < G) {
       h.nb0 = a.g.node_ptr[g]; h.n = a.g.node_ptr[g + 1] - h.nb0;
       h.e0 = a.g.edge_ptr[g]; h.e = min((int)(a.g.edge_ptr[g + 1] - h.e0), a.maxe);
@@ -431,18 +436,18 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
   };
   auto load_dat = [&](int unit, const Hdr &h) -> Dat {
     Dat d;
-    const int g = (unit < u1 && unit * 4 + grp < G) ? unit * 4 + grp : 0;   // idle groups read graph 0's first words
+    const int g = (unit < u1 && unit * NG + grp < G) ? unit * NG + grp : 0;   // idle groups read graph 0's first words
     const int32_t *__restrict__ rp = a.g.rowptr + h.nb0 + g;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = ql + 16 * j;
+    for (int j = 0; j < NP; ++j) {
+      const int i = ql + GS * j;
       d.rs[j] = rp[min(i, h.n)];
       d.re[j] = rp[min(i + 1, h.n)];
       d.x[j] = ld_na ? (int)a.g.nattr[min(max(h.nb0 + min(i, h.n - 1), 0), Ntot - 1)] : 255;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int64_t k = min(max(h.e0 + min(ql + 16 * j, h.e - 1), (int64_t)0), Etot - 1);
+    for (int j = 0; j < EP; ++j) {
+      const int64_t k = min(max(h.e0 + min(ql + GS * j, h.e - 1), (int64_t)0), Etot - 1);
       d.v[j] = ld_col ? a.g.col[k] : 0;
       d.at[j] = ld_ea ? (int)a.g.eattr[k] : 0;
     }
@@ -452,7 +457,7 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
   Dat dat = load_dat(u0, hdr);
   Hdr hdr_next = load_hdr(u0 + 1);
   for (int unit = u0; unit < u1; ++unit) {
-    const int g = unit * 4 + grp;
+    const int g = unit * NG + grp;
     const bool valid = g < G;
     const int nb0 = hdr.nb0, n = hdr.n, e = hdr.e;
     const int64_t e0 = hdr.e0;
@@ -471,21 +476,22 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
       else put(p, t_atom);
     };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = ql + 16 * j;
+    for (int j = 0; j < NP; ++j) {
+      const int i = ql + GS * j;
       if (i < n) node_step(i, dat.rs[j], dat.re[j], dat.x[j]);
     }
-    for (int i = ql + 64; i < n; i += 16) node_step(i, rpg[i], rpg[i + 1], has_na ? (int)a.g.nattr[nb0 + i] : 255);
+    for (int i = ql + GS * NP; i < n; i += GS) node_step(i, rpg[i], rpg[i + 1], has_na ? (int)a.g.nattr[nb0 + i] : 255);
     wave_sync();
     // ---- lane = entry: keep u <= v (first occurrence of {u,v}: zinc_dataset_indexbase.py:176-184)
     int pos = 1 + 2 * n;
-    const int emax = max(max(__builtin_amdgcn_readlane(e, 0), __builtin_amdgcn_readlane(e, 16)),
-                         max(__builtin_amdgcn_readlane(e, 32), __builtin_amdgcn_readlane(e, 48)));
+    int emax = 0;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) emax = max(emax, __builtin_amdgcn_readlane(e, q * GS));
     auto entry_step = [&](int k, int v, int at) {
       const bool in = k < e;
       const int u = in ? (int)rmap[k] : 0;
       const bool keep = in && u <= v;
-      const uint32_t kept = (uint32_t)(((uint64_t)__ballot(keep) >> (grp << 4)) & 0xFFFFull);   // this group's 16 bits
+      const uint32_t kept = (uint32_t)((uint64_t)__ballot(keep) >> (grp * GS)) & kGroupBits;   // this group's lanes
       if (keep) {
         const int p = pos + 4 * __popc(kept & ((1u << ql) - 1u));
         const int t1 = slut[GTOK_ZLUT_BOND0 + ((at >= 1 && at <= 4) ? at : 0)], t2 = node_id(u), t3 = node_id(v);
@@ -498,9 +504,9 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
       pos += 4 * __popc(kept);
     };
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (16 * j < emax) entry_step(ql + 16 * j, dat.v[j], dat.at[j]);
-    for (int k0 = 128; k0 < emax; k0 += 16) {
+    for (int j = 0; j < EP; ++j)
+      if (GS * j < emax) entry_step(ql + GS * j, dat.v[j], dat.at[j]);
+    for (int k0 = GS * EP; k0 < emax; k0 += GS) {
       const int k = k0 + ql;
       entry_step(k, k < e ? a.g.col[e0 + k] : 0, (k < e && has_ea) ? (int)a.g.eattr[e0 + k] : 0);
     }
@@ -531,15 +537,18 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
     if (ROWS) {
       // ---- the four rows leave together: ld is a multiple of 4 here, so a 16-byte vector never spans two rows
       wave_sync();
-      const int g0 = unit * 4, rows = min(4, G - g0), vpr = ld >> 2;
+      const int g0 = unit * NG, rows = min(NG, G - g0), vpr = ld >> 2;
       I32x4 *__restrict__ dst = reinterpret_cast<I32x4 *>(a.out + (int64_t)g0 * ld);
       const U8x16a *src = reinterpret_cast<const U8x16a *>(srow);
-      const int l0 = min(__builtin_amdgcn_readlane(len, 0), ld), l1 = min(__builtin_amdgcn_readlane(len, 16), ld);
-      const int l2 = min(__builtin_amdgcn_readlane(len, 32), ld), l3 = min(__builtin_amdgcn_readlane(len, 48), ld);
+      int rl[NG];
+#pragma unroll
+      for (int q = 0; q < NG; ++q) rl[q] = min(__builtin_amdgcn_readlane(len, q * GS), ld);
       int r = 0, c = lane;                      // vector t = lane + 64 j of the unit sits in row r, column 4c
       while (c >= vpr) { c -= vpr; ++r; }
       while (r < rows) {
-        const int lr = r == 0 ? l0 : (r == 1 ? l1 : (r == 2 ? l2 : l3));
+        int lr = rl[0];
+#pragma unroll
+        for (int q = 1; q < NG; ++q) lr = r == q ? rl[q] : lr;
         const U8x16a w = src[r * vpr + c];
         const int c4 = c << 2;
         dst[r * vpr + c] = I32x4{c4 + 0 < lr ? (int)w.a : pad, c4 + 1 < lr ? (int)w.b : pad,
@@ -550,7 +559,7 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
     } else if (valid) {
       const int lr = min(len, ld), nrem = ld - lr, nvec = nrem >> 2;
       int32_t *__restrict__ tail = orow + lr;
-      for (int t = ql; t < nvec; t += 16) reinterpret_cast<I32x4 *>(tail)[t] = I32x4{pad, pad, pad, pad};
+      for (int t = ql; t < nvec; t += GS) reinterpret_cast<I32x4 *>(tail)[t] = I32x4{pad, pad, pad, pad};
       if (ql < (nrem & 3)) tail[(nvec << 2) + ql] = pad;
     }
   }
@@ -1029,15 +1038,22 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
     q.g = *g; q.lut = lut; q.lut_len = lut_len; q.max_len = max_len; q.pad_id = pad_id;
     q.maxe = g->max_edges > 0 ? g->max_edges : 1;
     int off = 0;
-    q.off_map = off; off += align_up(4 * q.maxe * 2, 16);
+    // 8 lanes per molecule while molecules are small (the register pipeline covers 48 nodes / 96 entries), else 16
+    const char *gs_pin = std::getenv("GTOK_IBTT_GROUP");
+    int gs = (g->max_nodes <= 48 && g->max_edges <= 96) ? 8 : 16;
+    if (gs_pin && (gs_pin[0] == '8')) gs = 8;
+    if (gs_pin && (gs_pin[0] == '1')) gs = 16;
+    const int ng = 64 / gs;
+    q.off_map = off; off += align_up(ng * q.maxe * 2, 16);
     q.off_lut = off; off += align_up(lut_len * 4, 16);
-    // rows assembled in LDS when four of them fit next to the map (and 16-byte vectors do not span rows)
-    const bool rows = (ld % 4) == 0 && off + 16 * (int64_t)ld <= 16 * 1024;
+    // rows assembled in LDS when the unit's rows fit next to the map (and 16-byte vectors do not span rows)
+    const bool rows = (ld % 4) == 0 && off + 4 * ng * (int64_t)ld <= 16 * 1024;
     q.off_row = off;
-    if (rows) off += 16 * ld;
+    if (rows) off += 4 * ng * ld;
     q.lds = off;
     typedef void (*K)(const ZincQuadArgs);
-    K kern = rows ? (K)ibtt_zinc_quad_kernel<true> : (K)ibtt_zinc_quad_kernel<false>;
+    K kern = gs == 8 ? (rows ? (K)ibtt_zinc_quad_kernel<true, 8> : (K)ibtt_zinc_quad_kernel<false, 8>)
+                     : (rows ? (K)ibtt_zinc_quad_kernel<true, 16> : (K)ibtt_zinc_quad_kernel<false, 16>);
     int dev = 0, ncu = 256, occ = 1;
     if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1045,7 +1061,7 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
                                                      (size_t)q.lds) != hipSuccess || occ < 1)
       occ = 1;
     if (occ > 32) occ = 32;   // ~60 SGPRs: 8 waves per SIMD are resident (measured: 24 -> 32 waves per CU still pays)
-    q.units = (g->num_graphs + 3) / 4;
+    q.units = (g->num_graphs + ng - 1) / ng;
     int nb = ncu * occ;
     if (nb > q.units) nb = q.units;
     q.upb = (q.units + nb - 1) / nb;
