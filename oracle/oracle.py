@@ -148,6 +148,21 @@ def sent(coo: Coo, max_num_nodes, max_len, seed, epoch=0, labeled=False, num_nod
     return out, ln
 
 
+def sent_roundtrip(coo: Coo, ids, ln, max_num_nodes, max_len, seed, epoch=0, labeled=False, num_node_types=0,
+                   graph_base=0, nthreads=1):
+    """status int32 [G]: 0 = the (un-remapped) row decodes exactly to the input graph (a row cut at max_len: to a
+    part of it); see oracle_sent_roundtrip in the C file for the other codes."""
+    ids = np.ascontiguousarray(ids, np.int32); ln = _i32(ln)
+    status = np.empty(coo.G, np.int32)
+    lib().oracle_sent_roundtrip(ctypes.c_int32(coo.G), _p(coo.node_ptr), _p(coo.edge_ptr), _p(coo.x), _p(coo.src),
+                                _p(coo.dst), _p(coo.edge_attr), ctypes.c_int32(int(labeled)), ctypes.c_int32(max_num_nodes),
+                                ctypes.c_int32(num_node_types), ctypes.c_int32(max_len),
+                                ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(epoch & (2 ** 64 - 1)),
+                                ctypes.c_int64(graph_base), _p(ids), ctypes.c_int32(ids.shape[1]), _p(ln), _p(status),
+                                ctypes.c_int32(nthreads))
+    return status
+
+
 # ------------------------------------------------------------------------------------------------
 # SENT decoder (pure Python, small cases): token stream -> graph, used for the losslessness and
 # reference-visible-invariant property tests (SURVEY.md §8c (ii)).

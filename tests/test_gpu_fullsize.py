@@ -47,6 +47,19 @@ def test_sent_zinc_full_bit_exact_and_properties(zinc_full):
     assert torch.equal(part, ids[lo:hi]) and torch.equal(pln, ln[lo:hi])
 
 
+def test_sent_zinc_full_every_row_decodes_to_its_molecule(zinc_full):
+    """Round trip at corpus scale: every one of the 249,456 un-remapped rows the GPU wrote is decoded back (C decoder,
+    visit order replayed by the oracle) and equals its input molecule exactly - atoms, bonds, atom and bond types, no
+    bond twice, none missing.  Independent of the bit-for-bit comparison above: it checks the SENT spec, not the port."""
+    d, host, dev, coo = zinc_full
+    ids, ln = gtok.ops.sent(dev, 37, 1024, 11, 0, labeled=True, num_node_types=28, num_edge_types=6, ld=192)
+    assert int(ln.max()) <= 192
+    st = orc.sent_roundtrip(coo, ids.cpu().numpy(), ln.cpu().numpy(), 37, 1024, 11, 0, labeled=True, num_node_types=28,
+                            nthreads=THREADS)
+    assert not st.any(), (int((st != 0).sum()), st[st != 0][:10])
+    assert bool((ids[torch.arange(ZINC_FULL, device=DEV), (ln - 1).long()] == 4).all())     # every row is complete
+
+
 def test_sent_zinc_full_lossless_sample(zinc_full):
     d, host, dev, coo = zinc_full
     ids, ln = gtok.ops.sent(dev, 37, 1024, 11, 0, labeled=True, num_node_types=28, num_edge_types=6, ld=192)
@@ -85,6 +98,9 @@ def test_large_graphs_bit_exact():
     ref, rln = orc.sent(coo, 256, 600, 3, 1, ld=600, nthreads=THREADS)
     assert np.array_equal(ln.cpu().numpy(), rln) and np.array_equal(ids.cpu().numpy(), ref)
     assert float((ln == 600).float().mean()) > 0.5, "the truncation path must be hot in this configuration"
+    # round trip: rows cut at max_len decode to a part of their graph, the others to all of it
+    st = orc.sent_roundtrip(coo, ids.cpu().numpy(), ln.cpu().numpy(), 256, 600, 3, 1, nthreads=THREADS)
+    assert not st.any(), (int((st != 0).sum()), st[st != 0][:10])
     vocab = {t: i for i, t in enumerate(["<pad>", "<bos>", "<e>", "<n>", "<q>", "<p>", "<eos>", "yes", "no", "has_cycle"]
                                         + [str(i) for i in range(256)])}
     lut = gtok.ops.synth_lut(vocab, 256)

@@ -213,3 +213,43 @@ def test_vocab_from_graph_statistics_equals_vocab_from_texts(task):
     a = orc.vocab_stats_synth(coo.slice(0, 300), 64, None if q is None else q[:300], 0)
     b = orc.vocab_stats_synth(coo.slice(300, 700), 64, None if q is None else q[300:], 300)
     assert np.array_equal(a[0] + b[0], count) and np.array_equal(np.minimum(a[1], b[1]), first)
+
+
+def test_sent_roundtrip_decodes_every_row_to_its_input_graph():
+    """oracle_sent_roundtrip (C decoder + exact comparison through the replayed visit order): every row of the
+    oracle's own output is lossless - complete rows cover the whole graph, rows cut at max_len a part of it -
+    and damaged rows are reported, not accepted."""
+    cases = [(gtok.synth.zinc_like(3000, seed=31), True, 37, 28),
+             (gtok.synth.zinc_like(800, seed=32, coalesced=False), True, 37, 28),
+             (gtok.synth.graph_token_like(500, seed=33, with_text=False), False, 49, 0),
+             (gtok.synth.er_batch(60, seed=34, min_nodes=100, max_nodes=300), False, 300, 0),
+             (edge_case_graphs(), True, 8, 28), (edge_case_graphs(), False, 8, 0)]
+    for d, labeled, nn, ntypes in cases:
+        _, coo = both(d, labeled)
+        for max_len in (4096, 40):
+            ids, ln = orc.sent(coo, nn, max_len, 5, 3, labeled=labeled, num_node_types=ntypes, graph_base=77, ld=max_len)
+            st = orc.sent_roundtrip(coo, ids, ln, nn, max_len, 5, 3, labeled=labeled, num_node_types=ntypes, graph_base=77)
+            assert not st.any(), (labeled, max_len, np.nonzero(st)[0][:5], st[st != 0][:5])
+            if ln.max() < max_len:
+                assert (ids[np.arange(coo.G), ln - 1] == 4).all()      # no row was cut: every one ends with EOS
+    # damage: drop a token, swap two position tokens, change an edge type, duplicate a bracket member
+    d = gtok.synth.zinc_like(400, seed=35)
+    _, coo = both(d, True)
+    ids, ln = orc.sent(coo, 37, 4096, 1, 0, labeled=True, num_node_types=28, ld=400)
+    rng = np.random.default_rng(0)
+    bad = ids.copy(); bln = ln.copy()
+    for g in range(coo.G):
+        row, L = bad[g], int(ln[g])
+        kind = g % 3
+        if kind == 0:                       # lose a token in the middle
+            p = int(rng.integers(1, L - 1)); row[p:L - 1] = row[p + 1:L]; bln[g] = L - 1
+        elif kind == 1:                     # an edge-type token becomes another type
+            et = np.nonzero(row[:L] >= 6 + 37 + 28)[0]
+            if et.size:
+                row[et[0]] = 6 + 37 + 28 + (row[et[0]] - (6 + 37 + 28) + 1) % 5
+            else:
+                row[L - 1] = 1
+        else:                               # the row stops claiming completeness too early: EOS right after the first node
+            row[3] = 4
+    st = orc.sent_roundtrip(coo, bad, bln, 37, 4096, 1, 0, labeled=True, num_node_types=28)
+    assert (st != 0).mean() > 0.97, (st != 0).mean()
