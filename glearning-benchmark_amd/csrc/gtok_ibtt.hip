@@ -982,6 +982,22 @@ __global__ void __launch_bounds__(256) collate_kernel(const int32_t *__restrict_
   }
 }
 
+// one wave per row: first column holding `token` (ballot + ffs over 64-column chunks), -1 if none
+__global__ void __launch_bounds__(256) find_token_kernel(const int64_t *__restrict__ x, int rows, int ld, int64_t token,
+                                                         int32_t *__restrict__ pos) {
+  const int lane = lane_id();
+  const int r = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave_id();
+  if (r >= rows) return;
+  const int64_t *__restrict__ row = x + (int64_t)r * ld;
+  int found = -1;
+  for (int c0 = 0; c0 < ld; c0 += kWave) {
+    const int i = c0 + lane;
+    const uint64_t hit = __ballot(i < ld && row[i] == token);
+    if (hit) { found = c0 + __builtin_ctzll(hit); break; }
+  }
+  if (lane == 0) pos[r] = found;
+}
+
 struct Launch { int nb, upb, units; };
 static Launch plan(const void *kern, int num_items, int wpb, size_t lds) {
   int dev = 0, ncu = 256, occ = 1;
@@ -1248,6 +1264,14 @@ extern "C" int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len, 
     hipLaunchKernelGGL(collate_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, ld, len,
                        index, batch, pad_id, out_x, out_attn, out_ld);
   }
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_find_token(const int64_t *x, int32_t rows, int32_t ld, int64_t token, int32_t *pos, void *stream) {
+  if (rows < 0 || ld < 0) return GTOK_E_INVAL;
+  if (rows == 0) return GTOK_OK;
+  if (!pos || (ld > 0 && !x)) return GTOK_E_INVAL;
+  hipLaunchKernelGGL(find_token_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, ld, token, pos);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 

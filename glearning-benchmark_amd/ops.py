@@ -168,6 +168,18 @@ def collate(ids: torch.Tensor, ln: torch.Tensor, index: torch.Tensor, pad_id: in
 # ------------------------------------------------------------------------------------------------
 # text -> ids (TokenDataset)
 # ------------------------------------------------------------------------------------------------
+def find_token(x: torch.Tensor, token: int) -> torch.Tensor:
+    """First column of `token` in every row of an int64 [B, L] batch (-1: absent): the `<q>` search of
+    trainer/train_ibtt.py:88-103 / train_agtt.py:78-114 as one launch (query nodes sit at pos + 2, pos + 3)."""
+    _need_gpu(x, "find_token")
+    if x.dtype != torch.int64 or x.dim() != 2 or not x.is_contiguous():
+        raise ValueError("find_token expects a contiguous int64 [B, L] tensor")
+    pos = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+    _lib.check(_lib.lib().gtok_find_token(x.data_ptr(), int(x.shape[0]), int(x.shape[1]), int(token), pos.data_ptr(),
+                                          _stream(x.device)), "gtok_find_token")
+    return pos
+
+
 def vocab_stats_synth(batch: GraphBatch, num_ids: int, query_nodes: Optional[torch.Tensor] = None, graph_base: int = 0,
                       out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Occurrence count and first position ((graph_base + g) << 32 | position in the text) of every node-id token

@@ -20,6 +20,7 @@
  *   gtok_remap_zinc    trainer/train_agtt.py:171-244 on an existing token slab
  *   gtok_collate       data_loader.py:488-497 and trainer/train_agtt.py:276-302
  *                      (gather rows of a batch, pad to the batch max, bool mask)
+ *   gtok_find_token    the `<q>` search of trainer/train_ibtt.py:88-103 on a collated batch
  *   gtok_vocab_stats_synth  the corpus pass of build_vocab_from_texts
  *                      (data_loader.py:451-463) for graph-token corpora held as
  *                      CSR: per node-id token, occurrence count and first position
@@ -195,6 +196,13 @@ int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len,
                  const int64_t *index, int32_t batch, int32_t pad_id,
                  int64_t *out_x, uint8_t *out_attn, int32_t out_ld,
                  int32_t *batch_max, void *stream);
+
+/* First position of `token` in every row of an int64 [rows, ld] batch (what gtok_collate
+ * returns): pos[r] = the smallest i with x[r, i] == token, -1 if there is none.  This is the
+ * per-sample `<q>` search of trainer/train_ibtt.py:88-103 and trainer/train_agtt.py:78-114 (the
+ * query nodes sit at pos + 2 and pos + 3) as one launch.                                      */
+int gtok_find_token(const int64_t *x, int32_t rows, int32_t ld, int64_t token, int32_t *pos,
+                    void *stream);
 
 /* Node-id token statistics of the graph-token texts this batch stands for
  * (`<bos> u v <e> ... <n> 0 .. N-1 <q> TASK [qu qv] <p> LABEL <eos>`,

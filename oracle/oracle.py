@@ -110,6 +110,17 @@ def collate(ids, ln, index, pad_id, out_ld):
     return X, A.astype(bool), int(m[0])
 
 
+def find_token(x, token):
+    """trainer/train_ibtt.py:88-97: `(x[b] == q).nonzero()[0]` per sample, -1 when the token is absent."""
+    x = np.asarray(x)
+    out = np.full(x.shape[0], -1, np.int32)
+    for b in range(x.shape[0]):
+        hits = np.nonzero(x[b] == token)[0]
+        if hits.size:
+            out[b] = hits[0]
+    return out
+
+
 def vocab_stats_synth(coo: Coo, num_ids, query_nodes=None, graph_base=0):
     """(count, first) int64 [num_ids]: what build_vocab_from_texts would see for the tokens str(0..num_ids-1)."""
     count = np.zeros(num_ids, np.int64); first = np.full(num_ids, np.iinfo(np.int64).max, np.int64)

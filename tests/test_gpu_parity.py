@@ -463,3 +463,28 @@ def test_text_to_ids_long_tokens_chunk_borders_and_big_vocab():
                 ids, ln = gtok.ops.text_to_ids(tb.to(DEV), tp, table, max_len, strip_label=strip)
                 ref, rln = orc.text_to_ids(texts, vocab, max_len, ids.shape[1], strip_label=strip)
                 _cmp(ids, ln, ref, rln, f"text vocab={len(vocab)} strip={strip} max_len={max_len}")
+
+
+def test_find_token_on_collated_batches():
+    """§8f-3: the model-side `<q>` search (first occurrence per row, -1 when absent) on the int64 batch gtok_collate
+    hands to the model."""
+    rng = np.random.default_rng(4)
+    for B, L in ((128, 600), (1, 1), (5, 64), (7, 65), (300, 1023), (4, 0)):
+        x = rng.integers(0, 50, (B, L)).astype(np.int64)
+        if L:
+            x[::3] = np.where(x[::3] == 4, 5, x[::3])      # every third row has no <q> (token 4) at all
+            if B > 2 and L > 2:
+                x[1, -1] = 4; x[2, 0] = 4
+        got = gtok.ops.find_token(torch.from_numpy(x).to(DEV), 4)
+        assert np.array_equal(got.cpu().numpy(), orc.find_token(x, 4)), (B, L)
+    d = gtok.synth.graph_token_like(200, seed=21, task="shortest_path")
+    vocab = {t: i for i, t in enumerate(["<pad>", "<bos>", "<e>", "<n>", "<q>", "<p>", "<eos>", "yes", "no", "shortest_distance"]
+                                        + [str(i) for i in range(64)])}
+    tb, tp = gtok.ops.pack_texts(d["texts"])
+    ids, ln = gtok.ops.text_to_ids(tb.to(DEV), tp, gtok.ops.VocabTable(vocab, DEV), 4096)   # no text is cut before <q>
+    X, A = gtok.ops.collate(ids, ln, torch.arange(200), vocab["<pad>"], int(ln.max()))
+    qpos = gtok.ops.find_token(X, vocab["<q>"]).cpu().numpy()
+    Xh = X.cpu().numpy()
+    assert (qpos >= 0).all()
+    for g, (u, v) in enumerate(d["queries"]):               # "<q> shortest_distance u v <p>": u at +2, v at +3
+        assert Xh[g, qpos[g] + 2] == vocab[str(u)] and Xh[g, qpos[g] + 3] == vocab[str(v)]
