@@ -165,6 +165,74 @@ class GraphBatch:
                           flags, _chunk_max(node_counts), _chunk_max(edge_counts))
 
     @staticmethod
+    def from_coo_device(node_counts, edge_counts, src, dst, x=None, edge_attr=None, device="cuda",
+                        check_symmetric: bool = True) -> "GraphBatch":
+        """from_coo() with the heavy passes (row sort, row pointers, symmetry check) done by torch on the GPU:
+        the same arrays, bit for bit, built in milliseconds instead of seconds for 10^8-entry corpora, and left on
+        the device.  Inputs may be numpy arrays or tensors (host or device); src / dst are LOCAL node ids, the edges of
+        graph g contiguous and in edge_index order."""
+        dev = torch.device(device)
+        t64 = lambda a: torch.as_tensor(a).reshape(-1).to(dev, dtype=torch.int64)
+        nc, ec, s, d = t64(node_counts), t64(edge_counts), t64(src), t64(dst)
+        G = int(nc.numel())
+        if ec.numel() != G:
+            raise ValueError("node_counts and edge_counts differ in length")
+        node_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev); torch.cumsum(nc, 0, out=node_ptr[1:])
+        edge_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev); torch.cumsum(ec, 0, out=edge_ptr[1:])
+        N, E = int(node_ptr[-1]), int(edge_ptr[-1])
+        if s.numel() != E or d.numel() != E:
+            raise ValueError("src/dst length does not match edge_counts")
+        if N + G >= 2 ** 31:
+            raise ValueError("batch too large for int32 node offsets; shard it")
+        gid_e = torch.repeat_interleave(torch.arange(G, device=dev), ec, output_size=E)
+        n_e = nc[gid_e]
+        if E and bool(((s < 0) | (d < 0) | (s >= n_e) | (d >= n_e)).any()):
+            raise ValueError("edge endpoint outside [0, num_nodes)")
+        grow = node_ptr[gid_e] + s                        # global row of every entry
+        sorted_already = bool((grow[1:] >= grow[:-1]).all()) if E else False
+        if sorted_already:
+            perm = None
+        else:
+            perm = torch.sort(grow, stable=True).indices if E else None
+        take = (lambda a: a) if perm is None else (lambda a: a[perm])
+        col = take(d).to(torch.int32)
+        eorder = None if perm is None else (perm - edge_ptr[gid_e[perm]]).to(torch.int32)
+        cnt = torch.bincount(grow, minlength=N) if E else torch.zeros(N, dtype=torch.int64, device=dev)
+        gid_n = torch.repeat_interleave(torch.arange(G, device=dev), nc, output_size=N)
+        excl = torch.cumsum(cnt, 0) - cnt
+        rowptr = torch.empty(N + G, dtype=torch.int32, device=dev)
+        rowptr[torch.arange(N, device=dev) + gid_n] = (excl - edge_ptr[gid_n]).to(torch.int32)
+        rowptr[node_ptr[1:] + torch.arange(G, device=dev)] = ec.to(torch.int32)
+
+        def u8(a, n_expected, what):
+            if a is None:
+                return None
+            a = torch.as_tensor(a).reshape(-1).to(dev, dtype=torch.int64)
+            if a.numel() != n_expected:
+                raise ValueError(f"{what} length does not match")
+            return torch.where((a >= 0) & (a < 255), a, torch.full_like(a, 255)).to(torch.uint8)
+        nattr = u8(x, N, "x")
+        eattr = u8(edge_attr, E, "edge_attr")
+        if eattr is not None:
+            eattr = take(eattr)
+        max_nodes = int(nc.max()) if G else 0
+        flags = 0
+        if check_symmetric and E and not bool((s == d).any()):
+            m = max_nodes + 1
+            fwd = torch.sort((gid_e * m + s) * m + d).values
+            if not bool((fwd[1:] == fwd[:-1]).any()):
+                rev = torch.sort((gid_e * m + d) * m + s).values
+                flags = CSR_SIMPLE_SYMMETRIC if bool(torch.equal(fwd, rev)) else 0
+
+        def chunk_max(c):
+            if c.numel() == 0:
+                return 0
+            pad = (-c.numel()) % 64
+            return int(torch.nn.functional.pad(c, (0, pad)).reshape(-1, 64).sum(1).max())
+        return GraphBatch(G, max_nodes, int(ec.max()) if G else 0, node_ptr.to(torch.int32), edge_ptr, rowptr, col, eorder,
+                          nattr, eattr, flags, chunk_max(nc), chunk_max(ec))
+
+    @staticmethod
     def from_data_list(data_list: Sequence, labeled: Optional[bool] = None) -> "GraphBatch":
         """From PyG-like objects exposing edge_index [2,E], num_nodes (or x), and optionally x / edge_attr."""
         ncs, ecs, srcs, dsts, xs, eas = [], [], [], [], [], []

@@ -488,3 +488,25 @@ def test_find_token_on_collated_batches():
     assert (qpos >= 0).all()
     for g, (u, v) in enumerate(d["queries"]):               # "<q> shortest_distance u v <p>": u at +2, v at +3
         assert Xh[g, qpos[g] + 2] == vocab[str(u)] and Xh[g, qpos[g] + 3] == vocab[str(v)]
+
+
+def test_csr_builder_on_the_device_equals_the_host_builder():
+    """GraphBatch.from_coo_device (torch sort / bincount / cumsum on the GPU) gives the host builder's arrays bit for
+    bit: sorted and unsorted edge lists, typed and untyped, the hand-made edge cases, flags and chunk maxima included."""
+    cases = [(gtok.synth.zinc_like(5000, seed=41), True), (gtok.synth.zinc_like(1500, seed=42, coalesced=False), True),
+             (gtok.synth.graph_token_like(400, seed=43, with_text=False), False),
+             (gtok.synth.er_batch(50, seed=44, min_nodes=10, max_nodes=200), False), (edge_case_graphs(), True),
+             (_rings_with_chords([64, 63, 5, 1, 0], 20, seed=3), True)]
+    for d, labeled in cases:
+        x, ea = (d.get("x"), d.get("edge_attr")) if labeled else (None, None)
+        h = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], x, ea)
+        g = gtok.GraphBatch.from_coo_device(d["node_counts"], d["edge_counts"], d["src"], d["dst"], x, ea, device=DEV)
+        meta = lambda b: (b.num_graphs, b.max_nodes, b.max_edges, b.flags, b.chunk_nodes, b.chunk_edges)
+        assert meta(g) == meta(h)
+        for name in ("node_ptr", "edge_ptr", "rowptr", "col", "eorder", "nattr", "eattr"):
+            a, b = getattr(h, name), getattr(g, name)
+            assert (a is None) == (b is None), name
+            if a is not None:
+                assert a.dtype == b.dtype and torch.equal(a, b.cpu()), name
+    empty = gtok.GraphBatch.from_coo_device([], [], [], [], device=DEV)
+    assert empty.num_graphs == 0 and empty.flags == 0
