@@ -33,3 +33,10 @@ e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 10
 print(f"{G} texts, {tb.numel() / 1e6:.0f} MB of text ({need / 1e6:.0f} MB up to the cut): {ms:.4f} ms  {G / ms / 1e3:.1f} M texts/s  "
       f"{(need + 4.0 * float(ln.sum()) ) / ms / 1e6:.0f} GB/s algorithmic")
+
+if os.environ.get("GTOK_PHASE"):
+    ids2 = torch.empty((G, 608), dtype=torch.int32, device=dev)
+    gtok.ops.text_to_ids(tb, tp, table, 600, True, ld=608, out=(ids2, ln)); torch.cuda.synchronize()
+    ph = ids2[:, -4:].double()
+    npieces = ph[:, 3].sum()
+    print("per piece: classify", float(ph[:, 0].sum() / npieces), "scan", float(ph[:, 1].sum() / npieces), "probe", float(ph[:, 2].sum() / npieces), "pieces/text", float(ph[:, 3].mean()))
