@@ -71,33 +71,57 @@ struct __attribute__((aligned(16))) U8x16a { uint32_t a, b, c, d; };
 // them on separate cache lines.  Every wave's first unit is its own index (no draw); ticket t of queue q is
 // unit first_free + t * kQueues + q.  A wave draws from its home queue and moves round-robin to the next when
 // one runs dry; the next ticket is drawn before the current unit is processed, which hides the round trip.
-// Counter block (host: take_queue_slot): kQueues counters + one retired-wave counter, kQueueStride ints apart,
-// all zero between launches - the last wave to retire re-arms it.
+// Counter block (host: take_queue_slot): kQueues ticket counters, one retired-groups counter and kQueues
+// retired-waves counters, kQueueStride ints apart, all zero between launches - the last wave to retire re-arms it.
 constexpr int kQueues = 16, kQueueStride = 32;   // 128 B apart
 struct Tickets {
   int *ctr;
-  int q, hops, first_free, limit;
+  int q, home_q, first_free, limit;
   __device__ __forceinline__ void init(int *counters, int wave_index, int num_waves, int num_units) {
-    ctr = counters; q = wave_index & (kQueues - 1); hops = 0; first_free = num_waves; limit = num_units;
+    ctr = counters; q = home_q = wave_index & (kQueues - 1); first_free = num_waves; limit = num_units;
   }
   __device__ __forceinline__ int draw(bool lane0) const {   // the ticket lands in lane 0's register
     int t = 0;
     if (lane0) t = atomicAdd(ctr + q * kQueueStride, 1);
     return t;
   }
-  __device__ __forceinline__ int settle(int t, bool lane0) {   // ticket -> unit; `limit` when every queue is dry
+  // ticket -> unit; `limit` when every queue is dry.  A dry home queue is not followed by a walk over the other
+  // fifteen (fifteen dependent atomics, ~40 us, at the very end of every wave's life): lanes 0..15 read the sixteen
+  // counters at once, and the wave moves straight to a queue that still has tickets, or stops.  (A counter only
+  // grows, so a stale read can show tickets that are gone - the draw then comes back dry and the wave looks again -
+  // but never hides one.)
+  __device__ __forceinline__ int settle(int t, bool lane0) {
     int u = first_free + uni(t) * kQueues + q;
     while (u >= limit) {
-      if (++hops == kQueues) return limit;
-      q = (q + 1) & (kQueues - 1);
+      const int lane = lane_id();
+      int left = 0;
+      if (lane < kQueues) {
+        const int cap = (limit - first_free - lane + kQueues - 1) / kQueues;   // tickets queue `lane` can hand out
+        left = cap - __hip_atomic_load(ctr + lane * kQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const uint64_t live = __ballot(left > 0);
+      if (!live) return limit;
+      const uint64_t ahead = live & ~((2ull << q) - 1ull);                     // prefer the next queue after q
+      q = ahead ? __builtin_ctzll(ahead) : __builtin_ctzll(live);
       u = first_free + uni(draw(lane0)) * kQueues + q;
     }
     return u;
   }
-  __device__ __forceinline__ void retire(bool lane0, int lane, int num_waves) const {   // after the last draw
+  // After its last draw every wave retires; the last one out re-arms the block for the next launch that gets it.
+  // One retired-waves counter would be hit by every wave of the grid (6144 atomics on one address = ~90 us when
+  // they bunch up - all of a small launch): the waves retire in kQueues groups (by home queue) on separate lines,
+  // and only each group's last wave touches the global counter.
+  __device__ __forceinline__ void retire(bool lane0, int lane, int num_waves) const {
+    const int home = home_q;
+    const int group = (num_waves - home + kQueues - 1) / kQueues;       // waves whose index is home mod kQueues
     int last = 0;
-    if (lane0) last = atomicAdd(ctr + kQueues * kQueueStride, 1) == num_waves - 1;
-    if (uni(last) && lane <= kQueues)
+    if (lane0) {
+      if (atomicAdd(ctr + (kQueues + 1 + home) * kQueueStride, 1) == group - 1) {
+        const int groups = num_waves < kQueues ? num_waves : kQueues;
+        last = atomicAdd(ctr + kQueues * kQueueStride, 1) == groups - 1;
+      }
+    }
+    if (uni(last) && lane < 2 * kQueues + 1)
       __hip_atomic_store(ctr + lane * kQueueStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
@@ -107,7 +131,7 @@ struct Tickets {
 // slot is clean again when its launch has drained; kSlots launches may be in flight at once (any streams).
 // The first call on a device allocates (not capturable in a hipGraph: warm up once before capturing).
 inline int *take_queue_slot(int dev) {
-  constexpr int kSlots = 256, kMaxDev = 64, kSlotInts = (kQueues + 1) * kQueueStride;
+  constexpr int kSlots = 256, kMaxDev = 64, kSlotInts = (2 * kQueues + 1) * kQueueStride;
   static std::mutex mu;
   static int *ring[kMaxDev] = {};
   static std::atomic<unsigned> seq{0};
