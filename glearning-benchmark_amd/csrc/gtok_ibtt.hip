@@ -935,6 +935,167 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// graph-token text -> edge list (graph_token_dataset_autograph.py:14-158), canonical texts
+// ---------------------------------------------------------------------------------------------
+// `<bos> (INT INT <e>)* <n> INT* [<q> WORD [INT INT]] [<p> WORD] ...`: for a text in this form the reference's
+// left-to-right scan takes exactly the `INT INT <e>` triples before `<n>` as edges, the integers after `<n>` as the
+// node list, the two integers after `<q> shortest_distance` as the query and the word after `<p>` as the label.
+// Token k (k >= 1) of the edge zone is the source (k % 3 == 1) or target (k % 3 == 2) of edge (k - 1) / 3, so every
+// token lane writes its own value: no sequential scan.  Anything else - a token out of place, an integer of more
+// than 9 digits, a second <n>/<q>/<p> - sets status 1 and the host parser takes that record (the reference's scan has
+// corner semantics, int() included, that are not worth a kernel).  Wave per text, 64 bytes per step, lane = byte.
+enum { T_INT = 0, T_BOS, T_E, T_N, T_Q, T_P, T_EOS, T_OTHER };
+constexpr int32_t kNoLabel = INT32_MIN;
+struct ParseArgs {
+  const uint8_t *bytes; const int64_t *text_ptr; int num_texts;
+  const int64_t *edge_ptr; int32_t *src, *dst;   // pass 2 only (NULL in pass 1)
+  int32_t *num_edges, *num_nodes, *query, *label, *status;
+  int units, upb;
+};
+
+__global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a) {
+  const int lane = lane_id();
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
+  const bool fill = a.edge_ptr != nullptr;
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * wpb + wave;
+    if (g >= a.num_texts) break;
+    const uint8_t *__restrict__ s = a.bytes + a.text_ptr[g];
+    const int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
+    const int64_t ebase = fill ? a.edge_ptr[g] : 0;
+    const int64_t ecap = fill ? a.edge_ptr[g + 1] - ebase : 0;
+    auto lit = [&](int64_t i, int len, const char *w, int wl) -> bool {   // token == literal (upper-cased text)
+      if (len != wl) return false;
+      for (int j = 0; j < wl; ++j) {
+        uint32_t c = s[i + j];
+        if (c >= 'a' && c <= 'z') c -= 32;
+        if (c != (uint32_t)w[j]) return false;
+      }
+      return true;
+    };
+    int count = 0, tn = -1, tq = -1, q_t = -1, p_t = -1, cnt_n = 0, cnt_q = 0, cnt_p = 0;
+    int max_end = -1, max_node = -1, nnodes = 0, bad = 0;
+    int sd = 0, qu = -1, qv = -1, qu_ok = 0, qv_ok = 0, label = kNoLabel;
+    bool prev_sp = true;
+    for (int64_t b0 = 0; b0 < n; b0 += kWave) {
+      const int64_t i = b0 + lane;
+      const uint32_t c = (i < n) ? s[i] : 32u;
+      const bool sp = py_isspace(c);
+      const uint64_t spm = __ballot(sp);
+      const bool before = lane == 0 ? prev_sp : ((spm >> (lane - 1)) & 1ull);
+      const bool start = !sp && before;
+      const uint64_t sm = __ballot(start);
+      prev_sp = (spm >> 63) & 1ull;
+      if (sm == 0) continue;
+      const int t = count + __popcll(sm & lanemask_lt());
+      // classify the token that starts here
+      int type = T_OTHER, val = 0, len = 0, lab = kNoLabel;
+      bool is_sd = false;
+      if (start) {
+        bool digits = true;
+        for (int64_t j = i; j < n; ++j) {
+          const uint32_t cj = s[j];
+          if (py_isspace(cj)) break;
+          if (cj >= '0' && cj <= '9') { if (len < 9) val = val * 10 + (int)(cj - '0'); }
+          else digits = false;
+          ++len;
+        }
+        if (digits) { type = T_INT; if (len > 9) bad = 1; }
+        else if (c == '<') {
+          if (lit(i, len, "<E>", 3)) type = T_E;
+          else if (lit(i, len, "<N>", 3)) type = T_N;
+          else if (lit(i, len, "<Q>", 3)) type = T_Q;
+          else if (lit(i, len, "<P>", 3)) type = T_P;
+          else if (lit(i, len, "<BOS>", 5)) type = T_BOS;
+          else if (lit(i, len, "<EOS>", 5)) type = T_EOS;
+          // the reference compares these tags case-sensitively: an upper-case variant is not a tag
+          if (type != T_OTHER) for (int j = 1; j < len - 1; ++j) if (s[i + j] < 'a') type = T_OTHER;
+        } else {
+          is_sd = len == 17;
+          if (is_sd) { const char *w = "shortest_distance"; for (int j = 0; j < 17; ++j) is_sd = is_sd && s[i + j] == (uint8_t)w[j]; }
+          // label words (reference :80-113, upper-cased): YES / NO / LENk / INF / INFINITY
+          if (lit(i, len, "YES", 3)) lab = 1;
+          else if (lit(i, len, "NO", 2)) lab = 0;
+          else if (len > 3 && len <= 12 && lit(i, 3, "LEN", 3)) {
+            int k = 0; bool ok = true;
+            for (int j = 3; j < len; ++j) { const uint32_t cj = s[i + j]; ok = ok && cj >= '0' && cj <= '9'; k = k * 10 + (int)(cj - '0'); }
+            if (ok) lab = k - 1; else lab = kNoLabel + 1;     // LEN<junk>: the reference tries the next <p>: not canonical
+          }
+        }
+      }
+      // ---- structure (token indices are uniform values, token lanes report through ballots / readlane)
+      auto first_t = [&](uint64_t m) -> int { return count + __popcll(sm & ((1ull << __builtin_ctzll(m)) - 1ull)); };
+      auto lane_of = [&](int tt) -> int {   // start lane of token tt if it starts in this piece, else -1
+        const int k = tt - count;
+        if (k < 0 || k >= __popcll(sm)) return -1;
+        uint64_t m = sm;
+        for (int q = 0; q < k; ++q) m &= m - 1;
+        return __builtin_ctzll(m);
+      };
+      const uint64_t nm = __ballot(start && type == T_N), qm = __ballot(start && type == T_Q), pm = __ballot(start && type == T_P);
+      cnt_n += __popcll(nm); cnt_q += __popcll(qm); cnt_p += __popcll(pm);
+      if (tn < 0 && nm) tn = first_t(nm);
+      if (p_t < 0 && pm) p_t = first_t(pm);
+      if (tn >= 0 && tq < 0) {
+        const uint64_t em = __ballot(start && t > tn && type != T_INT);
+        if (em) tq = first_t(em);
+      }
+      if (start) {
+        if (t == 0) { if (type != T_BOS) bad = 1; }
+        else if (tn < 0 || t < tn) {                       // edge zone: (INT INT <e>)*
+          const int r = (t - 1) % 3;
+          if (type != (r == 2 ? T_E : T_INT)) bad = 1;
+          else if (r != 2) {
+            max_end = max(max_end, val);
+            const int64_t k = (t - 1) / 3;
+            if (fill && k < ecap) { if (r == 0) a.src[ebase + k] = val; else a.dst[ebase + k] = val; }
+          }
+        } else if (t > tn && (tq < 0 || t < tq)) {         // node list
+          max_node = max(max_node, val); ++nnodes;
+        } else if (t == tq) {
+          if (type != T_Q && type != T_P && type != T_EOS) bad = 1;
+        }
+      }
+      if (q_t < 0 && qm) q_t = first_t(qm);
+      if (q_t >= 0) {                                       // <q> WORD [INT INT]
+        int l;
+        if ((l = lane_of(q_t + 1)) >= 0) sd = __builtin_amdgcn_readlane((int)is_sd, l);
+        if ((l = lane_of(q_t + 2)) >= 0) { qu_ok = __builtin_amdgcn_readlane((int)(type == T_INT), l); qu = __builtin_amdgcn_readlane(val, l); }
+        if ((l = lane_of(q_t + 3)) >= 0) { qv_ok = __builtin_amdgcn_readlane((int)(type == T_INT), l); qv = __builtin_amdgcn_readlane(val, l); }
+      }
+      if (p_t >= 0) {
+        const int l = lane_of(p_t + 1);
+        if (l >= 0) label = __builtin_amdgcn_readlane(lab, l);
+      }
+      count += __popcll(sm);
+    }
+    // wave-wide results
+    const uint64_t anybad = __ballot(bad != 0);
+    int me = max_end, mn = max_node, nn = nnodes;
+    for (int off = 32; off > 0; off >>= 1) {
+      me = max(me, __shfl_xor(me, off)); mn = max(mn, __shfl_xor(mn, off)); nn += __shfl_xor(nn, off);
+    }
+    int status = anybad ? 1 : 0;
+    if (tn < 0 || cnt_n != 1 || cnt_q > 1 || cnt_p > 1) status = 1;
+    if (tn >= 0 && (tn - 1) % 3 != 0) status = 1;           // an unfinished triple before <n>
+    if (q_t >= 0 && q_t != tq) status = 1;                  // <q> somewhere else than right after the node list
+    if (label == kNoLabel + 1) status = 1;
+    if (lane == 0) {
+      const int ne = tn >= 0 ? (tn - 1) / 3 : 0;
+      a.num_edges[g] = ne;
+      a.num_nodes[g] = nn > 0 ? mn + 1 : (ne > 0 ? me + 1 : 0);
+      const bool has_q = q_t >= 0 && sd && qu_ok && qv_ok;
+      a.query[2 * (int64_t)g] = has_q ? qu : -1;
+      a.query[2 * (int64_t)g + 1] = has_q ? qv : -1;
+      a.label[g] = label;
+      a.status[g] = status;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // remap_zinc_tokens over a slab; batch collate
 // ---------------------------------------------------------------------------------------------
 __global__ void remap_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out, int ld,
@@ -1264,6 +1425,23 @@ extern "C" int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len, 
     hipLaunchKernelGGL(collate_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, ld, len,
                        index, batch, pad_id, out_x, out_attn, out_ld);
   }
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_parse_graph_text(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts,
+                                     const int64_t *edge_ptr, int32_t *src, int32_t *dst, int32_t *num_edges,
+                                     int32_t *num_nodes, int32_t *query_nodes, int32_t *label, int32_t *status,
+                                     void *stream) {
+  if (num_texts < 0) return GTOK_E_INVAL;
+  if (num_texts == 0) return GTOK_OK;
+  if (!bytes || !text_ptr || !num_edges || !num_nodes || !query_nodes || !label || !status) return GTOK_E_INVAL;
+  if (edge_ptr && (!src || !dst)) return GTOK_E_INVAL;
+  ParseArgs a;
+  a.bytes = bytes; a.text_ptr = text_ptr; a.num_texts = num_texts; a.edge_ptr = edge_ptr; a.src = src; a.dst = dst;
+  a.num_edges = num_edges; a.num_nodes = num_nodes; a.query = query_nodes; a.label = label; a.status = status;
+  const Launch L = plan(reinterpret_cast<const void *>(parse_graph_text_kernel), num_texts, 4, 0);
+  a.units = L.units; a.upb = L.upb;
+  hipLaunchKernelGGL(parse_graph_text_kernel, dim3(L.nb), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 

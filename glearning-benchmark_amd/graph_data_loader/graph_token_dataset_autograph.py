@@ -109,6 +109,29 @@ def parse_graph_from_json(record: dict, task: str = "cycle_check"):
     return edges, num_nodes, label
 
 
+def parse_texts_on_device(texts: List[str], device="cuda"):
+    """[(edges, num_nodes, label, query)] for graph-token texts - what parse_graph_from_json / parse_query_nodes_from_text
+    give for records that carry only `text` - with the parsing done by ONE pair of launches (gtok_parse_graph_text)
+    instead of a Python loop per token.  Texts outside the canonical grammar (status != 0: rare, hand-edited files) go
+    through the host parsers above, so the result equals the host path for every input."""
+    ops = _root().ops
+    tb, tp = ops.pack_texts(texts)
+    r = ops.parse_graph_texts(tb.to(device), tp)
+    st = r["status"].cpu().numpy(); nn = r["num_nodes"].cpu().numpy(); lab = r["label"].cpu().numpy()
+    q = r["query"].cpu().numpy(); ep = r["edge_ptr"].cpu().numpy()
+    src, dst = r["src"].cpu().numpy(), r["dst"].cpu().numpy()
+    out = []
+    for g, text in enumerate(texts):
+        if st[g] != 0:
+            edges, n, label = parse_graph_from_json({"text": text})
+            out.append((edges, n, label, parse_query_nodes_from_text(text)))
+            continue
+        edges = list(zip(src[ep[g]:ep[g + 1]].tolist(), dst[ep[g]:ep[g + 1]].tolist()))
+        out.append((edges, int(nn[g]), None if lab[g] == ops.NO_LABEL else int(lab[g]),
+                    None if q[g, 0] < 0 else (int(q[g, 0]), int(q[g, 1]))))
+    return out
+
+
 class GraphTokenDatasetForAutoGraph:
     """Same constructor arguments and sampling rules as the reference class; holds the graphs in memory
     (no processed/*.pt cache: that file format belongs to PyG) and exposes them both as items and as CSR."""

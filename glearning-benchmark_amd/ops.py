@@ -168,6 +168,36 @@ def collate(ids: torch.Tensor, ln: torch.Tensor, index: torch.Tensor, pad_id: in
 # ------------------------------------------------------------------------------------------------
 # text -> ids (TokenDataset)
 # ------------------------------------------------------------------------------------------------
+NO_LABEL = -2 ** 31
+
+
+def parse_graph_texts(text_bytes: torch.Tensor, text_ptr: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """graph-token texts -> edges / node counts / query nodes / labels on the device (the reference's
+    parse_graph_from_text + parse_query_nodes_from_text + parse_label_from_text + the num_nodes rule).  Returns
+    device tensors: num_edges, num_nodes, label (NO_LABEL = none), status int32 [G]; query int32 [G, 2] (-1 = none);
+    edge_ptr int64 [G+1]; src, dst int32 [sum E] in text order.  status != 0 marks a text outside the canonical
+    grammar: ignore its other fields and parse it on the host."""
+    _need_gpu(text_bytes, "parse_graph_texts")
+    dev = text_bytes.device
+    text_ptr = text_ptr.to(dev, dtype=torch.int64).contiguous()
+    G = int(text_ptr.numel()) - 1
+    i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    ne, nn, q, lab, st = i32(G), i32(G), i32(G, 2), i32(G), i32(G)
+    L = _lib.lib()
+    _lib.check(L.gtok_parse_graph_text(text_bytes.data_ptr(), text_ptr.data_ptr(), G, None, None, None, ne.data_ptr(),
+                                       nn.data_ptr(), q.data_ptr(), lab.data_ptr(), st.data_ptr(), _stream(dev)),
+               "gtok_parse_graph_text")
+    edge_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.where(st == 0, ne, torch.zeros_like(ne)).to(torch.int64), 0, out=edge_ptr[1:])
+    E = int(edge_ptr[-1]) if G else 0
+    src, dst = i32(max(E, 1)), i32(max(E, 1))
+    if G:
+        _lib.check(L.gtok_parse_graph_text(text_bytes.data_ptr(), text_ptr.data_ptr(), G, edge_ptr.data_ptr(), src.data_ptr(),
+                                           dst.data_ptr(), ne.data_ptr(), nn.data_ptr(), q.data_ptr(), lab.data_ptr(),
+                                           st.data_ptr(), _stream(dev)), "gtok_parse_graph_text")
+    return dict(num_edges=ne, num_nodes=nn, query=q, label=lab, status=st, edge_ptr=edge_ptr, src=src[:E], dst=dst[:E])
+
+
 def find_token(x: torch.Tensor, token: int) -> torch.Tensor:
     """First column of `token` in every row of an int64 [B, L] batch (-1: absent): the `<q>` search of
     trainer/train_ibtt.py:88-103 / train_agtt.py:78-114 as one launch (query nodes sit at pos + 2, pos + 3)."""

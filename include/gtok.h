@@ -20,6 +20,7 @@
  *   gtok_remap_zinc    trainer/train_agtt.py:171-244 on an existing token slab
  *   gtok_collate       data_loader.py:488-497 and trainer/train_agtt.py:276-302
  *                      (gather rows of a batch, pad to the batch max, bool mask)
+ *   gtok_parse_graph_text  graph_token_dataset_autograph.py:14-158 (text -> edges, query, label)
  *   gtok_find_token    the `<q>` search of trainer/train_ibtt.py:88-103 on a collated batch
  *   gtok_vocab_stats_synth  the corpus pass of build_vocab_from_texts
  *                      (data_loader.py:451-463) for graph-token corpora held as
@@ -196,6 +197,21 @@ int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len,
                  const int64_t *index, int32_t batch, int32_t pad_id,
                  int64_t *out_x, uint8_t *out_attn, int32_t out_ld,
                  int32_t *batch_max, void *stream);
+
+/* graph-token text -> edge list: parse_graph_from_text / parse_query_nodes_from_text /
+ * parse_label_from_text (graph_token_dataset_autograph.py:14-113) and the num_nodes rule of
+ * parse_graph_from_json (:116-158) for texts in the canonical form
+ *   <bos> (INT INT <e>)* <n> INT* [<q> WORD [INT INT]] [<p> WORD] ...
+ * Texts as for gtok_text_to_ids.  Two passes: with edge_ptr == NULL only the per-text results are
+ * written (num_edges[g], num_nodes[g], query_nodes[2g..] = (u, v) or (-1, -1), label[g] = 1/0 for
+ * yes/no, K-1 for lenK, INT32_MIN for none, status[g]); the caller prefix-sums num_edges into
+ * edge_ptr[G+1] and calls again with src/dst to receive the edges in text order.  status 1 marks a
+ * text that is not in that form (token out of place, integer of more than 9 digits, several
+ * <n>/<q>/<p>, `len` + junk): its other outputs are undefined and the host parser must take it. */
+int gtok_parse_graph_text(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts,
+                          const int64_t *edge_ptr, int32_t *src, int32_t *dst, int32_t *num_edges,
+                          int32_t *num_nodes, int32_t *query_nodes, int32_t *label, int32_t *status,
+                          void *stream);
 
 /* First position of `token` in every row of an int64 [rows, ld] batch (what gtok_collate
  * returns): pos[r] = the smallest i with x[r, i] == token, -1 if there is none.  This is the

@@ -110,6 +110,60 @@ def collate(ids, ln, index, pad_id, out_ld):
     return X, A.astype(bool), int(m[0])
 
 
+def parse_graph_text(text, task_query=True):
+    """One graph-token text -> (edges, num_nodes, query or None, label or None), restating
+    graph_data_loader/graph_token_dataset_autograph.py: parse_graph_from_text :14-55 (greedy `int int <e>` scan up to the
+    first <n>, then the integer list), parse_query_nodes_from_text :58-78, parse_label_from_text :80-113 and the
+    num_nodes rule of parse_graph_from_json :116-158.  Pure Python: small cases only."""
+    toks = text.split()
+    edges, nodes = [], []
+    i = 0
+    while i < len(toks):
+        if i + 2 < len(toks) and toks[i + 2] == "<e>":
+            try:
+                edges.append((int(toks[i]), int(toks[i + 1])))
+                i += 3
+            except ValueError:
+                i += 1
+        elif toks[i] == "<n>" and i + 1 < len(toks):
+            i += 1
+            while i < len(toks) and toks[i] not in ("<q>", "<p>", "<eos>"):
+                try:
+                    nodes.append(int(toks[i]))
+                    i += 1
+                except ValueError:
+                    break
+            break
+        else:
+            i += 1
+    query = None
+    for i, tok in enumerate(toks):
+        if tok == "<q>" and i + 3 < len(toks) and toks[i + 1] == "shortest_distance":
+            try:
+                query = (int(toks[i + 2]), int(toks[i + 3]))
+                break
+            except ValueError:
+                pass
+    label = None
+    for i in range(len(toks) - 1):
+        if toks[i] != "<p>":
+            continue
+        lab = toks[i + 1].upper()
+        if lab in ("YES", "NO"):
+            label = int(lab == "YES")
+            break
+        if lab.startswith("LEN"):
+            try:
+                label = int(lab[3:]) - 1
+                break
+            except ValueError:
+                pass
+        if lab in ("INF", "INFINITY"):
+            break
+    num_nodes = max(nodes) + 1 if nodes else (max(max(a, b) for a, b in edges) + 1 if edges else 0)
+    return edges, num_nodes, query, label
+
+
 def find_token(x, token):
     """trainer/train_ibtt.py:88-97: `(x[b] == q).nonzero()[0]` per sample, -1 when the token is absent."""
     x = np.asarray(x)

@@ -34,6 +34,18 @@ ms = s.elapsed_time(e) / 10
 print(f"{G} texts, {tb.numel() / 1e6:.0f} MB of text ({need / 1e6:.0f} MB up to the cut): {ms:.4f} ms  {G / ms / 1e3:.1f} M texts/s  "
       f"{(need + 4.0 * float(ln.sum()) ) / ms / 1e6:.0f} GB/s algorithmic")
 
+# the same texts through the device parser (text -> edges / nodes / query / label: the whole text is read)
+r = gtok.ops.parse_graph_texts(tb, tp); torch.cuda.synchronize()
+assert int(r["status"].sum()) == 0
+s2, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s2.record()
+for _ in range(3):
+    r = gtok.ops.parse_graph_texts(tb, tp)
+e2.record(); torch.cuda.synchronize()
+ms2 = s2.elapsed_time(e2) / 3
+print(f"parse_graph_texts (two passes + prefix sum): {ms2:.3f} ms  {G / ms2 / 1e3:.1f} M texts/s  {tb.numel() * 2 / ms2 / 1e6:.0f} GB/s of text read, "
+      f"{int(r['edge_ptr'][-1])} edges")
+
 if os.environ.get("GTOK_PHASE"):
     ids2 = torch.empty((G, 608), dtype=torch.int32, device=dev)
     gtok.ops.text_to_ids(tb, tp, table, 600, True, ld=608, out=(ids2, ln)); torch.cuda.synchronize()

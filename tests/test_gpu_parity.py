@@ -510,3 +510,44 @@ def test_csr_builder_on_the_device_equals_the_host_builder():
                 assert a.dtype == b.dtype and torch.equal(a, b.cpu()), name
     empty = gtok.GraphBatch.from_coo_device([], [], [], [], device=DEV)
     assert empty.num_graphs == 0 and empty.flags == 0
+
+
+def test_graph_token_text_parser_on_the_device():
+    """§8f-2 / a13: gtok_parse_graph_text == the oracle's restatement of the reference parsers on canonical texts
+    (both tasks, INF labels, empty graphs); anything else is flagged (status 1) and parse_texts_on_device hands it to
+    the host parser, so the mirror's result equals the host path for every text."""
+    import importlib
+    gm = importlib.import_module("glearning-benchmark_amd.graph_data_loader.graph_token_dataset_autograph")
+    texts = []
+    for task in ("cycle_check", "shortest_path"):
+        texts += gtok.synth.graph_token_like(300, seed=51, task=task, min_nodes=2, max_nodes=60)["texts"]
+    texts += ["<bos> <n> 0 1 2 <q> has_cycle <p> no <eos>",                      # no edges: nodes from the list
+              "<bos> 0 1 <e> 1 2 <e> <n> <q> has_cycle <p> YES <eos>",          # empty node list: max endpoint + 1
+              "<bos> 3 4 <e> <n> 0 1 2 3 4 <q> shortest_distance 3 4 <p> len1 <eos>",
+              "<bos> 3 4 <e> <n> 0 1 2 3 4 <q> shortest_distance 0 3 <p> INF <eos>",
+              "<bos> 0 1 <e> <n> 0 1 <p> Len12 <eos>", "<bos> <n> <eos>", "<bos> 007 8 <e> <n> 0 8 <p> no"]
+    canonical = len(texts)
+    texts += ["0 1 <e> <n> 0 1 <q> has_cycle <p> yes <eos>",                     # no <bos>
+              "<bos> 0 1 <e> 2 <e> <n> 0 1 2 <p> yes", "<bos> 0 1 2 <e> <n> 0 1 2 <p> no",   # tokens out of place
+              "<bos> 0 1 <e> <n> 0 x 1 <p> yes", "<bos> 0 1 <e> <p> yes",       # junk in the node list, no <n>
+              "<bos> 0 +1 <e> <n> 0 1 <p> yes", "<bos> 0 12345678901 <e> <n> 0 1 <p> yes",
+              "<bos> 0 1 <e> <n> 0 1 <p> lenx <p> yes", "<bos> 0 1 <E> <n> 0 1 <p> yes", "", "   "]
+    tb, tp = gtok.ops.pack_texts(texts)
+    r = gtok.ops.parse_graph_texts(tb.to(DEV), tp)
+    st = r["status"].cpu().numpy()
+    assert not st[:canonical].any(), np.nonzero(st[:canonical])[0]
+    assert st[canonical:].all(), st[canonical:]
+    ep = r["edge_ptr"].cpu().numpy(); src = r["src"].cpu().numpy(); dst = r["dst"].cpu().numpy()
+    nn = r["num_nodes"].cpu().numpy(); lab = r["label"].cpu().numpy(); q = r["query"].cpu().numpy()
+    for g in range(canonical):
+        edges, n, query, label = orc.parse_graph_text(texts[g])
+        assert list(zip(src[ep[g]:ep[g + 1]].tolist(), dst[ep[g]:ep[g + 1]].tolist())) == edges, g
+        assert nn[g] == n and (None if lab[g] == gtok.ops.NO_LABEL else lab[g]) == label, (g, nn[g], n, lab[g], label)
+        assert (None if q[g, 0] < 0 else (q[g, 0], q[g, 1])) == query, g
+    # the mirror: device parse + host parse of the flagged texts == host parse of everything
+    got = gm.parse_texts_on_device(texts, DEV)
+    for g, text in enumerate(texts):
+        edges, n, label = gm.parse_graph_from_json({"text": text})
+        assert got[g] == (edges, n, label, gm.parse_query_nodes_from_text(text)), (g, text[:60])
+        oe, on, oq, ol = orc.parse_graph_text(text)
+        assert (oe, on, ol, oq) == (edges, n, label, gm.parse_query_nodes_from_text(text)), g   # oracle == mirror too
