@@ -61,6 +61,7 @@ SYMBOLS = {
     "gtok_ibtt_synth": (_I, [ctypes.POINTER(GtokCsr), _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     "gtok_text_to_ids": (_I, [_P, _P, _I, ctypes.POINTER(GtokVocabTable), _I, _I, _P, _I, _P, _P]),
     "gtok_sent": (_I, [ctypes.POINTER(GtokCsr), ctypes.POINTER(GtokSentParams), _P, _I, _P, _P]),
+    "gtok_sent_decode": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "gtok_remap_zinc": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "gtok_collate": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     "gtok_parse_graph_text": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -200,6 +200,96 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SENT decoder: token rows -> graphs in visit-index space (DESIGN.md section 5 read backwards)
+// ---------------------------------------------------------------------------------------------
+// Lane per row (the stream is a sequential grammar): position tokens in first-visit order name nodes 0, 1, 2, ...;
+// a position token after another one is a trail edge; `LADJ [type] pos ... RADJ` lists edges from the current node
+// to earlier ones; RESET breaks the trail; labelled rows carry an edge-type token ahead of every trail step and a
+// node-type token after every first visit.  Output is the edge list (a = the node the edge was written from, b = the
+// other end, t = edge type or -1), the node types, and a status: 0 complete (EOS reached), 1 malformed, 2 an
+// output capacity exceeded, 3 well-formed but cut before EOS (a row truncated at max_len).
+struct DecodeArgs {
+  const int32_t *ids; int ld; const int32_t *len; int rows;
+  int idx_off, node_off, edge_off, labeled;
+  int32_t *num_nodes, *num_edges, *edge_a, *edge_b, *edge_t, *node_type, *status;
+  int ecap, ncap;
+};
+
+__global__ void __launch_bounds__(256) sent_decode_kernel(const DecodeArgs a) {
+  const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (g >= a.rows) return;
+  const int32_t *__restrict__ t = a.ids + (int64_t)g * a.ld;
+  const int L = min(a.len[g], a.ld);
+  int32_t *ea = a.edge_a + (int64_t)g * a.ecap, *eb = a.edge_b + (int64_t)g * a.ecap, *et = a.edge_t + (int64_t)g * a.ecap;
+  int32_t *nt = a.node_type + (int64_t)g * a.ncap;
+  int st = 3, prev = -1, nseen = 0, pending = -1, m = 0, i = 1;
+  auto add = [&](int from, int to, int type) {
+    if (m < a.ecap) { ea[m] = from; eb[m] = to; et[m] = type; } else st = 2;
+    ++m;
+  };
+  if (L < 1 || t[0] != GTOK_SENT_SOS) st = 1;
+  while (st == 3 && i < L) {
+    const int tk = t[i];
+    if (tk == GTOK_SENT_EOS) { st = 0; break; }
+    if (tk == GTOK_SENT_RESET) { prev = -1; pending = -1; ++i; continue; }
+    if (tk == GTOK_SENT_LADJ) {
+      if (prev < 0) { st = 1; break; }
+      ++i;
+      while (i < L && t[i] != GTOK_SENT_RADJ) {
+        int type = -1;
+        if (a.labeled) { type = t[i] - a.edge_off; if (type < 0) { st = 1; break; } if (++i >= L) break; }
+        const int b = t[i] - a.idx_off;
+        if (b < 0 || b >= nseen) { st = 1; break; }
+        add(prev, b, type);
+        ++i;
+      }
+      if (st == 1 || i >= L) break;           // malformed, or cut inside the bracket
+      ++i;
+      continue;
+    }
+    const bool is_pos = tk >= a.idx_off && tk < a.node_off;
+    if (a.labeled && !is_pos) {               // edge type ahead of a trail step
+      if (tk < a.edge_off) { st = 1; break; }
+      pending = tk - a.edge_off; ++i; continue;
+    }
+    if (!is_pos) { st = 1; break; }
+    const int k = tk - a.idx_off;
+    ++i;
+    if (k == nseen) {                         // first visit
+      int type = -1;
+      if (a.labeled) {
+        if (i >= L) { if (nseen < a.ncap) nt[nseen] = -1; else st = 2; ++nseen; break; }   // cut between the position and its type
+        type = t[i] - a.node_off;
+        if (type < 0) { st = 1; break; }      // (a type beyond num_node_types aliases the edge range: the grammar decides)
+        ++i;
+      }
+      if (nseen < a.ncap) nt[nseen] = type; else st = 2;
+      ++nseen;
+    } else if (k > nseen) { st = 1; break; }
+    if (prev >= 0) add(prev, k, pending);
+    pending = -1;
+    prev = k;
+  }
+  a.num_nodes[g] = nseen; a.num_edges[g] = m; a.status[g] = st;
+}
+
+extern "C" int gtok_sent_decode(const int32_t *ids, int32_t ld, const int32_t *len, int32_t num_rows,
+                                int32_t max_num_nodes, int32_t labeled, int32_t num_node_types,
+                                int32_t *num_nodes, int32_t *num_edges, int32_t *edge_a, int32_t *edge_b, int32_t *edge_type,
+                                int32_t edge_cap, int32_t *node_type, int32_t node_cap, int32_t *status, void *stream) {
+  if (num_rows < 0 || ld <= 0 || edge_cap < 0 || node_cap < 0 || max_num_nodes < 0) return GTOK_E_INVAL;
+  if (num_rows == 0) return GTOK_OK;
+  if (!ids || !len || !num_nodes || !num_edges || !edge_a || !edge_b || !edge_type || !node_type || !status) return GTOK_E_INVAL;
+  DecodeArgs a;
+  a.ids = ids; a.ld = ld; a.len = len; a.rows = num_rows; a.labeled = labeled;
+  a.idx_off = GTOK_SENT_IDX_OFFSET; a.node_off = a.idx_off + max_num_nodes; a.edge_off = a.node_off + num_node_types;
+  a.num_nodes = num_nodes; a.num_edges = num_edges; a.edge_a = edge_a; a.edge_b = edge_b; a.edge_t = edge_type;
+  a.node_type = node_type; a.status = status; a.ecap = edge_cap; a.ncap = node_cap;
+  hipLaunchKernelGGL(sent_decode_kernel, dim3((num_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
 extern "C" const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_params *p) {
   if (!g || !p) return "";
   static const char *lds[] = {"sent_lds_kernel<W=1>", "sent_lds_kernel<W=2>", "sent_lds_kernel<W=4>", "sent_lds_kernel<W=8>"};

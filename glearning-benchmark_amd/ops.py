@@ -140,6 +140,28 @@ def sent_kernel_name(batch: GraphBatch, max_num_nodes: int, max_len: int, labele
     return lib().gtok_sent_kernel_name(ctypes.byref(cs), ctypes.byref(p)).decode()
 
 
+def sent_decode(ids: torch.Tensor, ln: torch.Tensor, max_num_nodes: int, labeled: bool = False, num_node_types: int = 0,
+                edge_cap: Optional[int] = None, node_cap: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """Un-remapped SENT rows -> graphs in visit-index space (node k = the k-th node the trail visited): num_nodes,
+    num_edges, status int32 [G]; edge_a, edge_b, edge_type int32 [G, edge_cap]; node_type int32 [G, node_cap].
+    status: 0 complete, 1 malformed, 2 capacity exceeded, 3 cut before EOS."""
+    _need_gpu(ids, "sent_decode")
+    if ids.dtype != torch.int32 or ids.dim() != 2 or not ids.is_contiguous():
+        raise ValueError("sent_decode expects a contiguous int32 [G, ld] slab")
+    dev, (G, ld) = ids.device, ids.shape
+    ecap = int(edge_cap) if edge_cap is not None else ld
+    ncap = int(node_cap) if node_cap is not None else max(1, max_num_nodes)
+    i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    out = dict(num_nodes=i32(G), num_edges=i32(G), status=i32(G), edge_a=i32(G, ecap), edge_b=i32(G, ecap),
+               edge_type=i32(G, ecap), node_type=i32(G, ncap))
+    _lib.check(_lib.lib().gtok_sent_decode(ids.data_ptr(), ld, ln.data_ptr(), G, max_num_nodes, int(labeled), num_node_types,
+                                           out["num_nodes"].data_ptr(), out["num_edges"].data_ptr(), out["edge_a"].data_ptr(),
+                                           out["edge_b"].data_ptr(), out["edge_type"].data_ptr(), ecap,
+                                           out["node_type"].data_ptr(), ncap, out["status"].data_ptr(), _stream(dev)),
+               "gtok_sent_decode")
+    return out
+
+
 def remap_zinc(ids: torch.Tensor, ln: torch.Tensor, idx_offset: int, node_idx_offset: int,
                edge_idx_offset: int) -> torch.Tensor:
     _need_gpu(ids, "remap_zinc")

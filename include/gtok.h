@@ -17,6 +17,7 @@
  *                      trainer/train_agtt.py:250 (SENT walk; spec in DESIGN.md,
  *                      upstream parity unpinned), optionally fused with
  *                      remap_zinc_tokens (:171-244) and the query append (:257-267)
+ *   gtok_sent_decode   the SENT spec read backwards (token rows -> graphs in visit-index space)
  *   gtok_remap_zinc    trainer/train_agtt.py:171-244 on an existing token slab
  *   gtok_collate       data_loader.py:488-497 and trainer/train_agtt.py:276-302
  *                      (gather rows of a batch, pad to the batch max, bool mask)
@@ -235,6 +236,19 @@ int gtok_find_token(const int64_t *x, int32_t rows, int32_t ld, int64_t token, i
 int gtok_vocab_stats_synth(const gtok_csr *g, const int32_t *query_nodes,
                            int64_t graph_base, int32_t num_ids, int64_t *count,
                            int64_t *first, void *stream);
+
+/* SENT decoder: un-remapped token rows (gtok_sent with remap_zinc = 0) -> graphs in visit-index space: node
+ * k is the k-th node the trail visited.  Per row: num_nodes, num_edges, the edges in stream order - edge_a =
+ * the node the edge was written from, edge_b = the other end, edge_type = its type token minus the edge offset
+ * (-1 unlabelled) - in [rows, edge_cap] arrays, node types in [rows, node_cap], and status: 0 complete (EOS
+ * reached), 1 malformed, 2 a capacity exceeded (counts are still right), 3 well-formed but cut before EOS (a row
+ * truncated at max_len).  The reverse of the spec in DESIGN.md section 5; with the trail's visit order it gives back
+ * the input graph exactly (oracle_sent_roundtrip checks that for every row).                                      */
+int gtok_sent_decode(const int32_t *ids, int32_t ld, const int32_t *len, int32_t num_rows,
+                     int32_t max_num_nodes, int32_t labeled, int32_t num_node_types,
+                     int32_t *num_nodes, int32_t *num_edges, int32_t *edge_a, int32_t *edge_b,
+                     int32_t *edge_type, int32_t edge_cap, int32_t *node_type, int32_t node_cap,
+                     int32_t *status, void *stream);
 
 /* Which SENT kernel gtok_sent() will run for this batch ("sent_lane_kernel": lane per graph, needs
  * GTOK_CSR_SIMPLE_SYMMETRIC and a large batch; "sent_reg_kernel": wave per graph, <= 64 nodes;

@@ -213,6 +213,22 @@ def sent(coo: Coo, max_num_nodes, max_len, seed, epoch=0, labeled=False, num_nod
     return out, ln
 
 
+def sent_decode_rows(ids, ln, max_num_nodes, labeled=False, num_node_types=0, edge_cap=None, node_cap=None):
+    """C decoder with gtok_sent_decode's outputs (dict of numpy arrays); untouched slots of the [G, cap] arrays are -9."""
+    ids = np.ascontiguousarray(ids, np.int32); ln = _i32(ln)
+    G, ld = ids.shape
+    ecap = ld if edge_cap is None else int(edge_cap)
+    ncap = max(1, max_num_nodes) if node_cap is None else int(node_cap)
+    out = dict(num_nodes=np.empty(G, np.int32), num_edges=np.empty(G, np.int32), status=np.empty(G, np.int32),
+               edge_a=np.full((G, ecap), -9, np.int32), edge_b=np.full((G, ecap), -9, np.int32),
+               edge_type=np.full((G, ecap), -9, np.int32), node_type=np.full((G, ncap), -9, np.int32))
+    lib().oracle_sent_decode(_p(ids), ctypes.c_int32(ld), _p(ln), ctypes.c_int32(G), ctypes.c_int32(max_num_nodes),
+                             ctypes.c_int32(int(labeled)), ctypes.c_int32(num_node_types), _p(out["num_nodes"]),
+                             _p(out["num_edges"]), _p(out["edge_a"]), _p(out["edge_b"]), _p(out["edge_type"]),
+                             ctypes.c_int32(ecap), _p(out["node_type"]), ctypes.c_int32(ncap), _p(out["status"]))
+    return out
+
+
 def sent_roundtrip(coo: Coo, ids, ln, max_num_nodes, max_len, seed, epoch=0, labeled=False, num_node_types=0,
                    graph_base=0, nthreads=1):
     """status int32 [G]: 0 = the (un-remapped) row decodes exactly to the input graph (a row cut at max_len: to a

@@ -551,3 +551,46 @@ def test_graph_token_text_parser_on_the_device():
         assert got[g] == (edges, n, label, gm.parse_query_nodes_from_text(text)), (g, text[:60])
         oe, on, oq, ol = orc.parse_graph_text(text)
         assert (oe, on, ol, oq) == (edges, n, label, gm.parse_query_nodes_from_text(text)), g   # oracle == mirror too
+
+
+def test_sent_decode_kernel_equals_the_oracle_decoder():
+    """§8f-4: gtok_sent_decode == oracle_sent_decode on the GPU's own SENT rows (labelled, unlabelled, cut at max_len,
+    large graphs), on damaged rows (same status, same partial output) and when the output capacities are too small; and
+    the decoded graphs have the node / edge counts of their inputs."""
+    cases = [(gtok.synth.zinc_like(3000, seed=61), True, 37, 28), (gtok.synth.zinc_like(1000, seed=62), False, 37, 0),
+             (gtok.synth.graph_token_like(300, seed=63, with_text=False), False, 49, 0),
+             (gtok.synth.er_batch(40, seed=64, min_nodes=100, max_nodes=200), False, 200, 0), (edge_case_graphs(), True, 8, 28)]
+    for d, labeled, nn, ntypes in cases:
+        batch, coo = both(d, labeled)
+        kw = dict(labeled=labeled, num_node_types=ntypes, num_edge_types=5 if labeled else 0)
+        for max_len in (4096, 50):
+            ids, ln = gtok.ops.sent(batch.to(DEV), nn, max_len, 9, 2, **kw)
+            for ecap, ncap in ((None, None), (7, 3)):
+                got = gtok.ops.sent_decode(ids, ln, nn, labeled, ntypes, ecap, ncap)
+                want = orc.sent_decode_rows(ids.cpu().numpy(), ln.cpu().numpy(), nn, labeled, ntypes, ecap, ncap)
+                for k in ("num_nodes", "num_edges", "status"):
+                    assert np.array_equal(got[k].cpu().numpy(), want[k]), (k, labeled, max_len, ecap)
+                for k, cnt in (("edge_a", "num_edges"), ("edge_b", "num_edges"), ("edge_type", "num_edges"), ("node_type", "num_nodes")):
+                    g_, w_ = got[k].cpu().numpy(), want[k]
+                    valid = np.arange(w_.shape[1])[None, :] < np.minimum(want[cnt], w_.shape[1])[:, None]
+                    assert np.array_equal(g_[valid], w_[valid]), (k, labeled, max_len, ecap)
+            if max_len == 4096 and int(ln.max()) < 4096:
+                got = gtok.ops.sent_decode(ids, ln, nn, labeled, ntypes)
+                assert not got["status"].any()
+                und = np.array([len({(min(a, b), max(a, b)) for a, b in zip(coo.src[coo.edge_ptr[g]:coo.edge_ptr[g + 1]],
+                                                                       coo.dst[coo.edge_ptr[g]:coo.edge_ptr[g + 1]])})
+                                for g in range(coo.G)])
+                assert np.array_equal(got["num_nodes"].cpu().numpy(), coo.node_counts) and np.array_equal(got["num_edges"].cpu().numpy(), und)
+    # damaged rows: identical verdicts
+    d = gtok.synth.zinc_like(600, seed=65)
+    batch, coo = both(d, True)
+    ids, ln = gtok.ops.sent(batch.to(DEV), 37, 4096, 1, 0, labeled=True, num_node_types=28, num_edge_types=5)
+    bad = ids.cpu().numpy().copy(); rng = np.random.default_rng(1)
+    for g in range(coo.G):
+        L = int(ln[g]); p = int(rng.integers(0, L))
+        bad[g, p] = int(rng.integers(0, 120))
+    got = gtok.ops.sent_decode(torch.from_numpy(bad).to(DEV), ln, 37, True, 28)
+    want = orc.sent_decode_rows(bad, ln.cpu().numpy(), 37, True, 28)
+    for k in ("num_nodes", "num_edges", "status"):
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    assert (want["status"] != 0).mean() > 0.3
