@@ -979,58 +979,85 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
     int max_end = -1, max_node = -1, nnodes = 0, bad = 0;
     int sd = 0, qu = -1, qv = -1, qu_ok = 0, qv_ok = 0, label = kNoLabel;
     bool prev_sp = true;
+    // the token that runs into this piece: decimal value so far, length, "digits only so far"
+    uint32_t carry_val = 0; int carry_len = 0; bool carry_dig = true;
+    uint32_t cnext = (lane < n) ? s[lane] : 32u;                  // pieces are loaded one ahead
     for (int64_t b0 = 0; b0 < n; b0 += kWave) {
       const int64_t i = b0 + lane;
-      const uint32_t c = (i < n) ? s[i] : 32u;
+      const uint32_t c = cnext;
+      cnext = (i + kWave < n) ? s[i + kWave] : 32u;
       const bool sp = py_isspace(c);
       const uint64_t spm = __ballot(sp);
       const bool before = lane == 0 ? prev_sp : ((spm >> (lane - 1)) & 1ull);
-      const bool start = !sp && before;
-      const uint64_t sm = __ballot(start);
+      const bool after = lane == 63 ? py_isspace((uint32_t)__builtin_amdgcn_readlane((int)cnext, 0)) : ((spm >> (lane + 1)) & 1ull);
+      const uint64_t sm = __ballot(!sp && before), em = __ballot(!sp && after);   // token starts / ends
       prev_sp = (spm >> 63) & 1ull;
-      if (sm == 0) continue;
-      const int t = count + __popcll(sm & lanemask_lt());
-      // classify the token that starts here
-      int type = T_OTHER, val = 0, len = 0, lab = kNoLabel;
+      if ((~spm) == 0) continue;
+      // Integer tokens without a loop per token: x -> 10 x + digit is an affine map, and affine maps compose
+      // associatively, so one segmented scan over the lanes (segments = tokens) leaves every token's value at its
+      // last byte; "all digits" is a mask test over the token's lanes.
+      const uint64_t le = (2ull << lane) - 1ull;
+      const int seg_lo = (sm & le) ? 63 - __builtin_clzll(sm & le) : 0;
+      const bool cont = !(sm & le);                                 // began in an earlier piece
+      const bool isdig = c >= '0' && c <= '9';
+      const uint64_t ndm = __ballot(!sp && !isdig);
+      uint32_t m = 10u, h = isdig ? c - '0' : 0u;
+#pragma unroll
+      for (int dsh = 1; dsh < kWave; dsh <<= 1) {
+        const uint32_t pm = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - dsh) << 2, (int)m);
+        const uint32_t ph = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - dsh) << 2, (int)h);
+        if (!sp && lane - dsh >= seg_lo) { h = ph * m + h; m = pm * m; }
+      }
+      int len = lane - seg_lo + 1;
+      bool alldig = (ndm & le & ~((1ull << seg_lo) - 1ull)) == 0;
+      if (cont) { h = carry_val * m + h; len += carry_len; alldig = alldig && carry_dig; }
+      const bool open = !((spm >> 63) & 1ull) && !((em >> 63) & 1ull);
+      carry_val = open ? (uint32_t)__builtin_amdgcn_readlane((int)h, 63) : 0u;
+      carry_len = open ? __builtin_amdgcn_readlane(len, 63) : 0;
+      carry_dig = open ? (bool)__builtin_amdgcn_readlane((int)alldig, 63) : true;
+      // the two bytes before this one (tags are three bytes long)
+      const uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 1) << 2, (int)c);
+      const uint32_t p2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 2) << 2, (int)c);
+      if (em == 0) continue;
+      const bool start = (em >> lane) & 1ull;                       // (a token END: the structure code below keys on it)
+      const int t = count + __popcll(em & lanemask_lt());
+      int type = T_OTHER, val = (int)h, lab = kNoLabel;
       bool is_sd = false;
       if (start) {
-        bool digits = true;
-        for (int64_t j = i; j < n; ++j) {
-          const uint32_t cj = s[j];
-          if (py_isspace(cj)) break;
-          if (cj >= '0' && cj <= '9') { if (len < 9) val = val * 10 + (int)(cj - '0'); }
-          else digits = false;
-          ++len;
-        }
-        if (digits) { type = T_INT; if (len > 9) bad = 1; }
-        else if (c == '<') {
-          if (lit(i, len, "<E>", 3)) type = T_E;
-          else if (lit(i, len, "<N>", 3)) type = T_N;
-          else if (lit(i, len, "<Q>", 3)) type = T_Q;
-          else if (lit(i, len, "<P>", 3)) type = T_P;
-          else if (lit(i, len, "<BOS>", 5)) type = T_BOS;
-          else if (lit(i, len, "<EOS>", 5)) type = T_EOS;
+        const int64_t ts = i - len + 1;                             // the token's first byte
+        if (alldig) { type = T_INT; if (len > 9) bad = 1; }
+        else if (len == 3 && lane >= 2) {                           // a tag inside this piece: bytes are in registers
+          if (p2 == '<' && c == '>') type = p1 == 'e' ? T_E : p1 == 'n' ? T_N : p1 == 'q' ? T_Q : p1 == 'p' ? T_P : T_OTHER;
+        } else if (s[ts] == '<') {                                  // <bos> / <eos>, or a tag across two pieces
+          if (lit(ts, len, "<E>", 3)) type = T_E;
+          else if (lit(ts, len, "<N>", 3)) type = T_N;
+          else if (lit(ts, len, "<Q>", 3)) type = T_Q;
+          else if (lit(ts, len, "<P>", 3)) type = T_P;
+          else if (lit(ts, len, "<BOS>", 5)) type = T_BOS;
+          else if (lit(ts, len, "<EOS>", 5)) type = T_EOS;
           // the reference compares these tags case-sensitively: an upper-case variant is not a tag
-          if (type != T_OTHER) for (int j = 1; j < len - 1; ++j) if (s[i + j] < 'a') type = T_OTHER;
-        } else {
+          if (type != T_OTHER) for (int j = 1; j < len - 1; ++j) if (s[ts + j] < 'a') type = T_OTHER;
+        }
+        if (type == T_OTHER && !alldig) {
           is_sd = len == 17;
-          if (is_sd) { const char *w = "shortest_distance"; for (int j = 0; j < 17; ++j) is_sd = is_sd && s[i + j] == (uint8_t)w[j]; }
+          if (is_sd) { const char *w = "shortest_distance"; for (int j = 0; j < 17; ++j) is_sd = is_sd && s[ts + j] == (uint8_t)w[j]; }
           // label words (reference :80-113, upper-cased): YES / NO / LENk / INF / INFINITY
-          if (lit(i, len, "YES", 3)) lab = 1;
-          else if (lit(i, len, "NO", 2)) lab = 0;
-          else if (len > 3 && len <= 12 && lit(i, 3, "LEN", 3)) {
+          if (lit(ts, len, "YES", 3)) lab = 1;
+          else if (lit(ts, len, "NO", 2)) lab = 0;
+          else if (len > 3 && len <= 12 && lit(ts, 3, "LEN", 3)) {
             int k = 0; bool ok = true;
-            for (int j = 3; j < len; ++j) { const uint32_t cj = s[i + j]; ok = ok && cj >= '0' && cj <= '9'; k = k * 10 + (int)(cj - '0'); }
+            for (int j = 3; j < len; ++j) { const uint32_t cj = s[ts + j]; ok = ok && cj >= '0' && cj <= '9'; k = k * 10 + (int)(cj - '0'); }
             if (ok) lab = k - 1; else lab = kNoLabel + 1;     // LEN<junk>: the reference tries the next <p>: not canonical
           }
         }
       }
+      const uint64_t sm_tok = em;   // tokens are indexed in END order below
       // ---- structure (token indices are uniform values, token lanes report through ballots / readlane)
-      auto first_t = [&](uint64_t m) -> int { return count + __popcll(sm & ((1ull << __builtin_ctzll(m)) - 1ull)); };
+      auto first_t = [&](uint64_t m) -> int { return count + __popcll(sm_tok & ((1ull << __builtin_ctzll(m)) - 1ull)); };
       auto lane_of = [&](int tt) -> int {   // start lane of token tt if it starts in this piece, else -1
         const int k = tt - count;
-        if (k < 0 || k >= __popcll(sm)) return -1;
-        uint64_t m = sm;
+        if (k < 0 || k >= __popcll(sm_tok)) return -1;
+        uint64_t m = sm_tok;
         for (int q = 0; q < k; ++q) m &= m - 1;
         return __builtin_ctzll(m);
       };
@@ -1069,7 +1096,7 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
         const int l = lane_of(p_t + 1);
         if (l >= 0) label = __builtin_amdgcn_readlane(lab, l);
       }
-      count += __popcll(sm);
+      count += __popcll(sm_tok);
     }
     // wave-wide results
     const uint64_t anybad = __ballot(bad != 0);
