@@ -6,7 +6,7 @@ fixed vocabulary (remap_zinc_tokens :171-244), `[idx_offset+num_nodes, idx_offse
 appended for shortest_path (:257-267), padding with Graph2TrailTokenizer.pad = 5 even after the remap
 (:285-286), float32 labels iff the first label is a Python float (:296-299).
 """
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 import torch

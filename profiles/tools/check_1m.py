@@ -1,5 +1,5 @@
 """One-off scale check: 1,000,000 ZINC-shaped molecules in one launch, SENT and IBTT bit-exact against the oracle."""
-import importlib, os, sys, time
+import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

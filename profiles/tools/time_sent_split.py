@@ -1,5 +1,5 @@
 """Time gtok_sent on the large-graph corpus at several max_len: max_len=2 is (almost) load+build only."""
-import importlib, os, sys, time
+import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -217,7 +217,6 @@ def test_torch_custom_ops():
 def test_c_abi_error_codes():
     """Bad arguments come back as negative GTOK_E_* codes (nothing throws across the ABI, nothing is launched)."""
     import ctypes
-    from importlib import import_module
     L = gtok.lib()
     lib_mod = gtok._lib
     d = gtok.synth.zinc_like(8, seed=80)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import ROOT, edge_case_graphs, golden, golden_zinc_coo, gtok, orc, zinc_data_list
+from _util import ROOT, edge_case_graphs, golden, golden_zinc_coo, gtok, zinc_data_list
 
 gdl = gtok.graph_data_loader
 
