@@ -160,7 +160,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t v) {
 // every lane tests its own bit, one ballot + ffs picks the winner.
 __device__ __forceinline__ int kth_bit(uint64_t word, int k) {
   const int lane = lane_id();
-  const bool hit = ((word >> lane) & 1ull) && (__popcll(word & lanemask_lt()) == k);
+  const bool hit = ((word >> lane) & 1ull) && ((int)__popcll(word & lanemask_lt()) == k);
   return __ffsll((unsigned long long)__ballot(hit)) - 1;
 }
 

@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
       auto first_t = [&](uint64_t m) -> int { return count + __popcll(sm_tok & ((1ull << __builtin_ctzll(m)) - 1ull)); };
       auto lane_of = [&](int tt) -> int {   // start lane of token tt if it starts in this piece, else -1
         const int k = tt - count;
-        if (k < 0 || k >= __popcll(sm_tok)) return -1;
+        if (k < 0 || k >= (int)__popcll(sm_tok)) return -1;
         uint64_t m = sm_tok;
         for (int q = 0; q < k; ++q) m &= m - 1;
         return __builtin_ctzll(m);
