@@ -645,10 +645,15 @@ __global__ void __launch_bounds__(256) ibtt_synth_kernel(const SynthArgs a) {
     for (int j = 0; j < 5; ++j) { const int i = lane + kWave * j; if (i <= n) rp[i] = dat.rp[j]; }
     for (int i = lane + 5 * kWave; i <= n; i += kWave) rp[i] = rpg[i];
     wave_sync();
+    // only rows that start before the cut can own a surviving entry (row pointers never decrease): the search for an
+    // entry's row runs over those, ~16 rows of a 150-node graph instead of all of them
+    int nrow = 0;
+    for (int b = 0; b < n; b += kWave) nrow += __popcll(__ballot(b + lane < n && rp[b + lane] < elim));
+    nrow = max(nrow, 1);
     auto entry = [&](int k, int v, int p) {
       const int64_t q = 1 + 3 * (int64_t)p;
       if (q < tcap) {
-        const int u = row_of(rp, n, k);
+        const int u = row_of(rp, nrow, k);
         put(q, node_id(u)); put(q + 1, node_id(v)); put(q + 2, lut[GTOK_SLUT_E]);
       }
     };
