@@ -222,6 +222,10 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
       if (pos < cap) orow[pos] = t;
       ++pos;
     };
+    auto emit2 = [&](int t0, int t1) __attribute__((always_inline)) {   // two tokens, one dword-aligned 8-byte store
+      if (pos + 1 < cap) { *reinterpret_cast<Tok2 *>(orow + pos) = Tok2{t0, t1}; pos += 2; }
+      else { emit(t0); emit(t1); }
+    };
     // decision d uses word d&3 of Philox block d>>2; the block is kept as two packed 64-bit values and the word
     // is extracted with mask arithmetic (a select chain over the captured words makes the compiler select
     // ADDRESSES and park them in scratch: two memory round trips per draw)
@@ -301,8 +305,8 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
             const int w = cl[t];
             if (((vis_before >> w) & 1ull) && AT(vidx, w) == k && w != pred) kk = t;
           }
-          if (LAB) emit(edge_tok(el[kk]));
-          emit(pos_base + k);
+          if (LAB) emit2(edge_tok(el[kk]), pos_base + k);
+          else emit(pos_base + k);
         }
         emit(T_RADJ);
       }
@@ -326,8 +330,7 @@ __global__ void __launch_bounds__(64, 2) sent_lane_kernel(const SentLaneArgs a) 
           const uint64_t set = kind == 0 ? row : (kind == 1 ? live : (~vis & nodes));
           const int pick = kth_bit64(set, (int)below((uint32_t)__popcll(set)));
           if (kind == 1) {
-            emit(T_RESET);
-            emit(pos_base + AT(vidx, pick));
+            emit2(T_RESET, pos_base + AT(vidx, pick));
             rc = load_row(pick);
           } else {
             int et = 0;
