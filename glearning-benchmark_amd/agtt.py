@@ -81,6 +81,11 @@ class TokenizedGraphDataset(Dataset):
     def __getitem__(self, idx):
         data = self.pyg_dataset[idx]
         if self._batched:
+            if torch.utils.data.get_worker_info() is not None:
+                # the reference runs this dataset with num_workers: 0 (configs/agtt_*.yaml:21/25, "PyG Data pickling
+                # issues"); a worker process would have to launch kernels on a GPU context it must not inherit
+                raise _ops._lib.GtokError("TokenizedGraphDataset tokenizes on the GPU in the training process: use "
+                                     "DataLoader(num_workers=0), as the reference's AGTT configs do")
             self._graphs()
         if self._batched and not self._mixed_query:
             if self._served is None or self._served[idx]:       # fetched again -> a new random trail

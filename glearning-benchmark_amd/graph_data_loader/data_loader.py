@@ -284,10 +284,14 @@ def build_vocab_from_graphs(batch, num_ids: int, task: Optional[str] = None, lab
 
 # ------------------------------------------------------------------------------------------------ dataset
 class TokenDataset(Dataset):
-    """Eager text -> ids, like the reference (:465-486), but the whole corpus goes through ONE
-    gtok_text_to_ids launch and stays on the device as an int32 slab (`ids`, `lens`).
-    `__getitem__` keeps the reference's (LongTensor[L], LongTensor[]) CPU return so DataLoader workers
-    and the reference's `collate` keep working; `device_batches` is the no-copy path."""
+    """Eager text -> ids, like the reference (:465-486): the whole corpus goes through ONE gtok_text_to_ids
+    launch in `__init__`.  Two copies of the result are kept: the int32 slab on the device (`ids`, `lens`, read by
+    `device_batches`, the no-copy path) and, copied back once right after the launch, `seqs` / `labels` as CPU
+    int64 tensors — what the reference stores.  `__getitem__` only touches the CPU copies, so the object can be
+    handed to `DataLoader(num_workers=2)` workers (trainer/train_ibtt.py:395-402, configs/ibtt_*.yaml): forked
+    workers never see a device tensor, and pickling (spawned workers) drops the device members."""
+
+    _DEVICE_MEMBERS = ("ids", "lens", "_table")
 
     def __init__(self, examples, vocab, max_len=512, strip_label=True, require_label=True, device=None):
         self.vocab, self.max_len = vocab, max_len
@@ -312,21 +316,23 @@ class TokenDataset(Dataset):
             self._table = _ops.VocabTable(vocab, self.device)
             self.ids, self.lens = _ops.text_to_ids(blob.to(self.device), ptr, self._table, max_len, strip_label)
         else:
+            self._table = None
             self.ids = torch.empty((0, 4), dtype=torch.int32, device=self.device)
             self.lens = torch.empty((0,), dtype=torch.int32, device=self.device)
-        self._seqs = None
+        # host copy, made here in the parent process (one D2H of the slab): row i cut at its length
+        ids_h, self._lens_h = self.ids.cpu().to(torch.long), self.lens.cpu()
+        self.seqs: List[torch.Tensor] = [ids_h[i, :l].clone() for i, l in enumerate(self._lens_h.tolist())]
 
-    @property
-    def seqs(self) -> List[torch.Tensor]:
-        if self._seqs is None:
-            ids, lens = self.ids.cpu().to(torch.long), self.lens.cpu().tolist()
-            self._seqs = [ids[i, :l].clone() for i, l in enumerate(lens)]
-        return self._seqs
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in self._DEVICE_MEMBERS:      # a pickled copy (spawned worker) serves __getitem__ only
+            state[k] = None
+        return state
 
     def __len__(self):
         return len(self.labels)
 
-    def __getitem__(self, idx):
+    def __getitem__(self, idx):       # CPU tensors only: safe in DataLoader workers
         return self.seqs[idx], self.labels[idx]
 
     def device_batches(self, batch_size: int, shuffle: bool = False, generator: Optional[torch.Generator] = None,
@@ -335,7 +341,9 @@ class TokenDataset(Dataset):
         pad_id = self.vocab["<pad>"] if pad_id is None else pad_id
         n = len(self)
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
-        lens_h = self.lens.cpu()
+        if self.ids is None:
+            raise GtokError("device_batches on an unpickled TokenDataset copy: the device slab stays with the parent")
+        lens_h = self._lens_h
         y = self._y.to(self.device)
         for s in range(0, n, batch_size):
             idx = order[s:s + batch_size]

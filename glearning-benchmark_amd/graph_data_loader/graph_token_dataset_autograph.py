@@ -133,20 +133,107 @@ def parse_texts_on_device(texts: List[str], device="cuda"):
 
 
 class GraphTokenDatasetForAutoGraph:
-    """Same constructor arguments and sampling rules as the reference class; holds the graphs in memory
-    (no processed/*.pt cache: that file format belongs to PyG) and exposes them both as items and as CSR."""
+    """Same constructor arguments, sampling rules and cache key as the reference class (:161-408).  The graphs are
+    held in memory as items and as the batched CSR the kernels read.  Cache: `<root>/processed/<key>/data.pt` with
+    the reference's key (:233-253) holds `(data, slices)` in the shape InMemoryDataset.collate gives them —
+    attributes concatenated, `slices[name]` the per-item offsets — but as plain dicts of tensors: a pickled
+    torch_geometric `Data` cannot be written or read without torch_geometric.  A `data.pt` that is not in this
+    form (one written by the reference itself) is left alone and the JSON files are processed again."""
 
     def __init__(self, root: str, task: str = "cycle_check", algorithm=None, split: str = "train",
                  use_split_tasks_dirs: bool = True, seed: int = 0, num_graphs: Optional[int] = None,
-                 num_pairs_per_graph: Optional[int] = None, transform=None, pre_transform=None, pre_filter=None):
+                 num_pairs_per_graph: Optional[int] = None, transform=None, pre_transform=None, pre_filter=None,
+                 use_cache: bool = True):
         self.task = task
         self.algorithms = [algorithm] if isinstance(algorithm, str) else (["er"] if algorithm is None else list(algorithm))
         self.algorithm = self.algorithms[0]
         self.split, self.use_split_tasks_dirs, self.seed = split, use_split_tasks_dirs, seed
         self.num_graphs, self.num_pairs_per_graph = num_graphs, num_pairs_per_graph
         self._root, self.transform, self.pre_transform, self.pre_filter = root, transform, pre_transform, pre_filter
-        self._data_list = self.process()
         self._batch = None
+        cached = self._load_cache() if use_cache else None
+        if cached is None:
+            self._data_list = self.process()
+            if use_cache:
+                self._save_cache()
+        else:
+            self._data_list = cached
+
+    # ---- reference :218-253
+    @property
+    def raw_dir(self) -> str:
+        return self._split_dir(self.algorithm)
+
+    @property
+    def processed_dir(self) -> str:
+        name = f"autograph_{self.task}_{'+'.join(sorted(self.algorithms))}_{self.split}"
+        if self.use_split_tasks_dirs:
+            name += "_split"
+        if self.num_graphs is not None:
+            name += f"_ng{self.num_graphs}"
+        if self.num_pairs_per_graph is not None:
+            name += f"_np{self.num_pairs_per_graph}"
+        return os.path.join(self._root, "processed", name)
+
+    @property
+    def processed_file_names(self) -> List[str]:
+        return ["data.pt"]
+
+    @property
+    def processed_paths(self) -> List[str]:
+        return [os.path.join(self.processed_dir, n) for n in self.processed_file_names]
+
+    @staticmethod
+    def collate(data_list):
+        """(data, slices) as InMemoryDataset.collate lays them out: edge_index concatenated along dim 1, y along
+        dim 0, integer attributes as one tensor; slices[name][i]:slices[name][i+1] is item i's part."""
+        n = len(data_list)
+        ecount = torch.tensor([0] + [int(d.edge_index.shape[1]) for d in data_list], dtype=torch.long)
+        has_q = torch.tensor([hasattr(d, "query_u") and hasattr(d, "query_v") for d in data_list], dtype=torch.bool)
+        data = {
+            "edge_index": torch.cat([d.edge_index for d in data_list], dim=1) if n else torch.empty((2, 0), dtype=torch.long),
+            "y": torch.cat([d.y for d in data_list]) if n else torch.empty((0,), dtype=torch.long),
+            "num_nodes": torch.tensor([int(d.num_nodes) for d in data_list], dtype=torch.long),
+            "query_u": torch.tensor([int(getattr(d, "query_u", -1)) for d in data_list], dtype=torch.long),
+            "query_v": torch.tensor([int(getattr(d, "query_v", -1)) for d in data_list], dtype=torch.long),
+            "has_query": has_q,
+        }
+        one = torch.arange(n + 1, dtype=torch.long)
+        slices = {"edge_index": torch.cumsum(ecount, 0), "y": one, "num_nodes": one, "query_u": one, "query_v": one,
+                  "has_query": one}
+        return data, slices
+
+    @staticmethod
+    def _uncollate(data, slices) -> List[Data]:
+        out = []
+        es = slices["edge_index"].tolist()
+        for i in range(len(es) - 1):
+            d = Data(edge_index=data["edge_index"][:, es[i]:es[i + 1]].contiguous(), y=data["y"][i:i + 1].clone(),
+                     num_nodes=int(data["num_nodes"][i]))
+            if bool(data["has_query"][i]):
+                d.query_u, d.query_v = int(data["query_u"][i]), int(data["query_v"][i])
+            out.append(d)
+        return out
+
+    def _load_cache(self) -> Optional[List[Data]]:
+        path = self.processed_paths[0]
+        if not os.path.exists(path) or self.pre_transform is not None or self.pre_filter is not None:
+            return None
+        try:
+            data, slices = torch.load(path, weights_only=True)
+            return self._uncollate(data, slices)
+        except Exception:       # not ours (e.g. the reference's PyG pickle): process again, leave the file alone
+            self._foreign_cache = True
+            return None
+
+    def _save_cache(self) -> None:
+        if getattr(self, "_foreign_cache", False) or self.pre_transform is not None or self.pre_filter is not None:
+            return
+        try:
+            os.makedirs(self.processed_dir, exist_ok=True)
+            torch.save(self.collate(self._data_list), self.processed_paths[0])
+        except OSError:         # read-only data tree: stay in memory
+            pass
 
     def _split_dir(self, algo: str) -> str:
         if self.use_split_tasks_dirs:

@@ -193,3 +193,44 @@ def er_batch_device(num_graphs: int, device, seed: int = 0, min_nodes: int = 10,
     cat = lambda l: torch.cat(l).cpu().numpy()
     return dict(node_counts=n.cpu().numpy().astype(np.int64), edge_counts=cat(counts).astype(np.int64),
                 src=cat(srcs).astype(np.int64), dst=cat(dsts).astype(np.int64))
+
+
+def graph_token_tree(num_graphs: int, seed: int = 1234, task: str = "cycle_check",
+                     algorithms: Sequence[str] = ("er", "ba", "sbm", "path", "star", "complete"),
+                     splits: Sequence[str] = ("train", "test"), min_nodes: int = 10, max_nodes: int = 49,
+                     pairs_per_graph: int = 1, use_split_tasks_dirs: bool = True) -> Dict[str, list]:
+    """A graph-token task directory as {relative path: list of records} (what graph_task_generator.py leaves on
+    disk, README.md:29-35 / docs/synthetic_data.md:73-128): `tasks_{train,test}/<task>/<algo>/<split>/<i>.json`,
+    one file per graph, one record per query — shortest_path files carry `pairs_per_graph` records over the same
+    graph (unreachable pairs are written with `INF`, which the loaders skip).  `num_graphs` graphs per
+    (algorithm, split)."""
+    rng = np.random.default_rng(seed)
+    tree: Dict[str, list] = {}
+    for split in splits:
+        top = ("tasks_test" if split in ("val", "test") else "tasks_train") if use_split_tasks_dirs else "tasks"
+        for alg in algorithms:
+            for i in range(num_graphs):
+                n = int(rng.integers(min_nodes, max_nodes + 1))
+                e = _family_edges(alg, n, rng, float(rng.uniform(0.1, 0.2)))
+                body = " ".join(f"{a} {b} <e>" for a, b in e)
+                head = " ".join(t for t in ("<bos>", body, "<n>", " ".join(map(str, range(n)))) if t)
+                recs = []
+                if task == "cycle_check":
+                    recs.append({"text": f"{head} <q> has_cycle <p> {'yes' if _has_cycle(n, e) else 'no'} <eos>"})
+                else:
+                    for _ in range(pairs_per_graph):
+                        u = int(rng.integers(0, n)); v = int(rng.integers(0, n - 1)); v += v >= u
+                        d = int(_bfs_dist(n, e, u)[v])
+                        recs.append({"text": f"{head} <q> shortest_distance {u} {v} <p> {'len%d' % d if d > 0 else 'INF'} <eos>"})
+                tree[f"{top}/{task}/{alg}/{split}/{i:05d}.json"] = recs
+    return tree
+
+
+def write_tree(root: str, tree: Dict[str, list]) -> None:
+    import json
+    import os
+    for rel, recs in tree.items():
+        path = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(recs, f)

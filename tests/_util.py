@@ -78,6 +78,35 @@ def golden():
     return _golden
 
 
+_golden2 = None
+
+
+def golden2():
+    """Round-2 vectors (reference_vectors_r2.*): GraphTokenDatasetForAutoGraph.process() items, the 1k-record
+    config-1 corpus.  Same generator script, same rules."""
+    global _golden2
+    if _golden2 is None:
+        arr = dict(np.load(os.path.join(GOLDEN_DIR, "reference_vectors_r2.npz")))
+        with open(os.path.join(GOLDEN_DIR, "reference_vectors_r2.json")) as f:
+            meta = json.load(f)
+        _golden2 = (arr, meta)
+    return _golden2
+
+
+def config1_examples(task):
+    """[{'text','label'[,'query_u','query_v']}] of the config-1 fixture, as the reference's loader returned them."""
+    arr, meta = golden2()
+    tag = "config1_" + task
+    texts = bytes(arr[tag + "_texts"]).decode().split("\n")
+    out = []
+    for t, lab, (qu, qv) in zip(texts, meta[tag + "_labels"], meta[tag + "_queries"]):
+        e = {"text": t, "label": lab}
+        if qu is not None:
+            e["query_u"], e["query_v"] = qu, qv
+        out.append(e)
+    return out
+
+
 def golden_zinc_coo():
     arr, _ = golden()
     d = {k: arr["zinc_" + k] for k in ("node_counts", "edge_counts", "src", "dst", "x", "edge_attr", "y")}

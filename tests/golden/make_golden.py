@@ -53,8 +53,27 @@ class _Tok:
     pad = 5
 
 
+class InMemoryDataset:
+    """torch_geometric is absent; this is the base class's part in GraphTokenDatasetForAutoGraph
+    (graph_token_dataset_autograph.py:209-210, :407-408): keep the four constructor arguments, run process(), whose
+    last two lines hand the item list to collate() and torch.save() — captured below instead of written as a PyG
+    pickle (agds_section patches torch.save / torch.load for the duration of the call)."""
+
+    def __init__(self, root=None, transform=None, pre_transform=None, pre_filter=None):
+        self.root, self.transform, self.pre_transform, self.pre_filter = root, transform, pre_transform, pre_filter
+        self.process()
+
+    @property
+    def processed_paths(self):
+        return [os.path.join(self.processed_dir, n) for n in self.processed_file_names]
+
+    @staticmethod
+    def collate(data_list):
+        return list(data_list), {"items": len(data_list)}
+
+
 _mod("torch_geometric"); _mod("torch_geometric.datasets", ZINC=type("ZINC", (), {}))
-_mod("torch_geometric.data", Data=Data, InMemoryDataset=type("InMemoryDataset", (), {}))
+_mod("torch_geometric.data", Data=Data, InMemoryDataset=InMemoryDataset)
 _mod("wandb"); _mod("seaborn")
 _mod("autograph"); _mod("autograph.datamodules"); _mod("autograph.datamodules.data")
 _mod("autograph.datamodules.data.tokenizer", Graph2TrailTokenizer=_Tok)
@@ -295,11 +314,111 @@ def vocab_section():
     meta["map_autograph_token"] = m
 
 
+# ------------------------------------------------------------------------------------------------ round 2
+# Written to reference_vectors_r2.{npz,json} so that the round-1 files stay byte-identical.
+arrays2, meta2 = {}, {}
+
+AGDS_CASES = [
+    dict(task="cycle_check", algorithm=["er", "ba", "path"], split="train"),
+    dict(task="cycle_check", algorithm=["er", "sbm"], split="val", num_graphs=3, seed=5),          # val -> test fallback
+    dict(task="cycle_check", algorithm=["sbm", "ba", "er"], split="test", num_graphs=2, seed=11),
+    dict(task="shortest_path", algorithm=["er", "ba"], split="train", num_pairs_per_graph=2, seed=1),
+    dict(task="shortest_path", algorithm="er", split="test", num_graphs=4, num_pairs_per_graph=1, seed=0),
+    dict(task="shortest_path", algorithm=["star", "complete"], split="train"),                     # regular path, INF skipped
+    dict(task="shortest_path", algorithm=None, split="train", num_graphs=5, seed=7),               # default ['er']
+    dict(task="cycle_check", algorithm=["path", "star"], split="train", use_split_tasks_dirs=False),
+]
+
+
+def _item(d):
+    return dict(edge_index=d.edge_index.tolist(), edge_index_shape=list(d.edge_index.shape), y=d.y.tolist(),
+                y_dtype=str(d.y.dtype), num_nodes=int(d.num_nodes), query_u=getattr(d, "query_u", None),
+                query_v=getattr(d, "query_v", None))
+
+
+def agds_section():
+    """GraphTokenDatasetForAutoGraph.process() (graph_token_dataset_autograph.py:259-408) over a small graph-token
+    tree: per-algorithm file sampling seeded with seed + hash(algo) % 10000 (PYTHONHASHSEED=0 here and in the
+    test), num_pairs_per_graph sampling, val -> test fallback, INF / unlabeled records skipped, query fields."""
+    from graph_data_loader.graph_token_dataset_autograph import GraphTokenDatasetForAutoGraph
+    algs = ("er", "ba", "sbm", "path", "star", "complete")
+    tree = {}
+    tree.update(gtok.synth.graph_token_tree(6, seed=21, task="cycle_check", algorithms=algs, min_nodes=4, max_nodes=12))
+    tree.update(gtok.synth.graph_token_tree(6, seed=22, task="shortest_path", algorithms=algs, min_nodes=4, max_nodes=12,
+                                            pairs_per_graph=5))
+    tree.update(gtok.synth.graph_token_tree(3, seed=23, task="cycle_check", algorithms=("path", "star"), splits=("train",),
+                                            min_nodes=4, max_nodes=9, use_split_tasks_dirs=False))
+    # hand-written records: a single-dict file, explicit fields, a record without label, an empty graph
+    tree["tasks_train/cycle_check/er/train/zz_single.json"] = {"text": "<bos> 0 1 <e> 1 2 <e> 2 0 <e> <n> 0 1 2 <q> has_cycle <p> yes <eos>"}
+    tree["tasks_train/cycle_check/er/train/zz_mixed.json"] = [
+        {"nodes": [0, 1, 2, 5], "edges": [[0, 1], [1, 2]], "label": 0},
+        {"text": "<bos> 0 1 <e> <n> 0 1 <q> has_cycle <p> maybe <eos>"},
+        {"text": "<bos> <q> has_cycle <p> no <eos>"},
+        {"text": "<bos> <n> 0 1 2 <q> has_cycle <p> no <eos>"}]
+    saved = {}
+    real_save, real_load = torch.save, torch.load
+    torch.save = lambda obj, path, *a, **k: saved.__setitem__(path, obj)
+    torch.load = lambda path, *a, **k: saved[path]
+    out = []
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            gtok.synth.write_tree(tmp, tree)
+            for kw in AGDS_CASES:
+                ds = GraphTokenDatasetForAutoGraph(tmp, **kw)
+                items, slices = ds.data, ds.slices
+                out.append(dict(kwargs=kw, processed_dir=os.path.relpath(ds.processed_dir, tmp),
+                                raw_dir=os.path.relpath(ds.raw_dir, tmp), items=[_item(d) for d in items]))
+            try:
+                GraphTokenDatasetForAutoGraph(tmp, task="cycle_check", algorithm=["nope"], split="train")
+                err = None
+            except RuntimeError as e:
+                err = str(e)
+    finally:
+        torch.save, torch.load = real_save, real_load
+    meta2["agds_tree"] = tree
+    meta2["agds_cases"] = out
+    meta2["agds_missing_error"] = err
+
+
+def config1_section():
+    """BASELINE config 1 at the size SURVEY.md section 8d names: ~1,000 graph-token records per task (6 families x 167
+    graphs, 10-49 nodes, seed 1234) -> load_examples_multi_algorithm -> build_vocab_from_texts(max_tokens=600) ->
+    TokenDataset(max_len=600) -> collate of the first batch of 128 (train_ibtt.py:263-295, :391-402)."""
+    algs = ["er", "ba", "sbm", "path", "star", "complete"]
+    for task in ("cycle_check", "shortest_path"):
+        tree = gtok.synth.graph_token_tree(167, seed=1234, task=task, algorithms=algs, splits=("train",))
+        with tempfile.TemporaryDirectory() as tmp:
+            gtok.synth.write_tree(tmp, tree)
+            ex = gdl.load_examples_multi_algorithm(tmp, task, algs, "train", seed=0)
+        vocab, _ = gdl.build_vocab_from_texts([e["text"] for e in ex], max_tokens=600)
+        td = gdl.TokenDataset(ex, vocab, 600)
+        tag = "config1_" + task
+        arrays2[tag + "_texts"] = np.frombuffer("\n".join(e["text"] for e in ex).encode(), np.uint8)
+        meta2[tag + "_labels"] = [e["label"] for e in ex]
+        meta2[tag + "_queries"] = [[e.get("query_u"), e.get("query_v")] for e in ex]
+        meta2[tag + "_vocab"] = list(vocab.items())
+        ids = pad2d([s.tolist() for s in td.seqs])
+        assert ids.max() < 32768
+        arrays2[tag + "_ids"] = ids.astype(np.int16)
+        arrays2[tag + "_len"] = np.array([s.numel() for s in td.seqs], np.int32)
+        arrays2[tag + "_y"] = np.array([int(t) for t in td.labels], np.int32)
+        X, A, Y = gdl.collate([td[i] for i in range(128)], vocab["<pad>"])
+        arrays2[tag + "_collate_X"], arrays2[tag + "_collate_A"], arrays2[tag + "_collate_Y"] = \
+            X.numpy().astype(np.int16), A.numpy(), Y.numpy().astype(np.int32)
+
+
 if __name__ == "__main__":
     zinc_section(); synth_section(); agtt_section(); loader_section(); vocab_section()
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **arrays)
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as f:
         json.dump(meta, f)
+    agds_section(); config1_section()
+    np.savez_compressed(os.path.join(HERE, "reference_vectors_r2.npz"), **arrays2)
+    with open(os.path.join(HERE, "reference_vectors_r2.json"), "w") as f:
+        json.dump(meta2, f)
+    print("round 2:", len(arrays2), "arrays and", len(meta2), "json entries;",
+          os.path.getsize(os.path.join(HERE, "reference_vectors_r2.npz")) // 1024, "KiB npz,",
+          os.path.getsize(os.path.join(HERE, "reference_vectors_r2.json")) // 1024, "KiB json")
     print("wrote", len(arrays), "arrays and", len(meta), "json entries;",
           os.path.getsize(os.path.join(HERE, "reference_vectors.npz")) // 1024, "KiB npz,",
           os.path.getsize(os.path.join(HERE, "reference_vectors.json")) // 1024, "KiB json")

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import PygLike, golden, golden_zinc_coo, gtok, unpad, zinc_data_list
+from _util import PygLike, config1_examples, golden, golden2, golden_zinc_coo, gtok, unpad, zinc_data_list
 
 pytestmark = pytest.mark.gpu
 gdl = gtok.graph_data_loader
@@ -136,3 +136,101 @@ def test_agtt_end_to_end_with_the_gpu_tokenizer():
     # single-item call site (tokenizer(data)): a valid SENT of that molecule
     one = tok(datas[3])
     assert one.dtype == torch.long and one[0] == 0 and one[-1] == 4
+
+
+def _collate_with(pad):
+    def f(b):
+        return gdl.collate(b, pad)
+    return f
+
+
+@pytest.mark.parametrize("workers", [2, 0])
+def test_token_dataset_through_dataloader_workers(workers):
+    """The reference call site (trainer/train_ibtt.py:395-402, configs/ibtt_*.yaml num_workers: 2): the dataset is
+    built in the parent (GPU launch + one copy back), worker PROCESSES then index it and run the reference's
+    collate.  First batch == the reference's golden collate, every batch == collate over the golden rows."""
+    from torch.utils.data import DataLoader
+    arr, meta = golden()
+    cases = [("zinc_L1024", dict(meta["zinc_L1024_vocab"]), None, 1024, "<pad>")]
+    for task in ("cycle_check", "shortest_path"):
+        cases.append(("synth_" + task, dict(meta[f"synth_{task}_vocab"]), meta[f"synth_{task}_examples"], 600, "<pad>"))
+    for tag, vocab, ex, max_len, padtok in cases:
+        if ex is None:
+            ds = gdl.ZINCTokenizationDataset(split="train", max_len=max_len, zinc_dataset=zinc_data_list(golden_zinc_coo()))
+            ex = [ds[i] for i in range(len(ds))]
+            ids_key, len_key = f"{tag}_ids", f"{tag}_len"
+        else:
+            ids_key, len_key = f"{tag}_L{max_len}_ids", f"{tag}_L{max_len}_len"
+        td = gdl.TokenDataset(ex, vocab, max_len)
+        pad = vocab[padtok]
+        dl = DataLoader(td, batch_size=16, shuffle=False, num_workers=workers, collate_fn=_collate_with(pad))
+        want_rows = unpad(arr[ids_key], arr[len_key])
+        seen = 0
+        for b, (X, A, Y) in enumerate(dl):
+            rows = want_rows[seen:seen + X.shape[0]]
+            L = max(len(r) for r in rows)
+            assert X.dtype == torch.long and A.dtype == torch.bool and Y.dtype == torch.long and X.shape[1] == L
+            for i, r in enumerate(rows):
+                assert X[i, :len(r)].tolist() == r and (X[i, len(r):] == pad).all()
+                assert A[i].tolist() == [True] * len(r) + [False] * (L - len(r))
+            if b == 0:
+                assert np.array_equal(X.numpy(), arr[tag + "_collate_X"]) and np.array_equal(A.numpy(), arr[tag + "_collate_A"])
+                assert np.array_equal(Y.numpy(), arr[tag + "_collate_Y"])
+            seen += X.shape[0]
+        assert seen == len(td) == len(want_rows)
+
+
+def test_token_dataset_pickles_without_device_members():
+    """Spawned DataLoader workers get a pickled copy: it must carry the CPU rows and no device tensor."""
+    import pickle
+    arr, meta = golden()
+    ex = meta["synth_cycle_check_examples"]
+    td = gdl.TokenDataset(ex, dict(meta["synth_cycle_check_vocab"]), 600)
+    cp = pickle.loads(pickle.dumps(td))
+    assert cp.ids is None and cp.lens is None and len(cp) == len(td)
+    assert all(torch.equal(a, b) and not a.is_cuda for a, b in zip(cp.seqs, td.seqs))
+    with pytest.raises(gtok.GtokError):
+        next(cp.device_batches(4))
+
+
+def test_agtt_items_through_dataloader_no_workers():
+    """trainer/train_agtt.py:599-607 (configs/agtt_*.yaml num_workers: 0): DataLoader + collate_fn over the
+    GPU-tokenized items == collate_fn over the items fetched directly for the same epoch."""
+    from torch.utils.data import DataLoader
+    datas = zinc_data_list(golden_zinc_coo())
+    src = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=datas)
+    tok = gtok.Graph2TrailTokenizer(dataset_names=[], max_length=1024, truncation_length=1024, labeled_graph=True, undirected=True)
+    tok.set_num_nodes(max(d.num_nodes for d in src)); tok.set_num_node_and_edge_types(*gdl.get_zinc_num_types())
+    a = gtok.agtt.TokenizedGraphDataset(src, tok, task="zinc", remap_to_fixed_vocab=True, device=DEV)
+    b = gtok.agtt.TokenizedGraphDataset(src, tok, task="zinc", remap_to_fixed_vocab=True, device=DEV)
+    direct = [b[i] for i in range(len(b))]
+    seen = 0
+    for X, A, Y, dl in DataLoader(a, batch_size=16, shuffle=False, num_workers=0, collate_fn=gtok.agtt.collate_fn):
+        Xw, Aw, Yw, _ = gtok.agtt.collate_fn(direct[seen:seen + X.shape[0]])
+        assert torch.equal(X, Xw) and torch.equal(A, Aw) and torch.equal(Y, Yw) and len(dl) == X.shape[0]
+        seen += X.shape[0]
+    assert seen == len(a)
+    # worker processes would have to launch kernels: refused with a clear message instead of a HIP re-init failure
+    with pytest.raises(Exception, match="num_workers"):
+        next(iter(DataLoader(a, batch_size=4, num_workers=1, collate_fn=gtok.agtt.collate_fn)))
+
+
+@pytest.mark.parametrize("task", ["cycle_check", "shortest_path"])
+def test_config1_token_dataset_equals_reference(task):
+    """BASELINE config 1 (1,002 graph-token records per task) through the product: the reference
+    serves this configuration on the CPU; the product has no CPU path and serves it with the same kernels
+    (DESIGN.md section 2).  TokenDataset rows, labels, first 128-row batch via DataLoader(num_workers=2) and via
+    device_batches == the reference's."""
+    from torch.utils.data import DataLoader
+    arr, meta = golden2()
+    tag = "config1_" + task
+    vocab = dict(meta[tag + "_vocab"])
+    td = gdl.TokenDataset(config1_examples(task), vocab, 600)
+    want = unpad(arr[tag + "_ids"].astype(np.int64), arr[tag + "_len"])
+    assert [s.tolist() for s in td.seqs] == want
+    assert [int(y) for y in td.labels] == arr[tag + "_y"].tolist()
+    X, A, Y = next(iter(DataLoader(td, batch_size=128, shuffle=False, num_workers=2, collate_fn=_collate_with(vocab["<pad>"]))))
+    assert np.array_equal(X.numpy(), arr[tag + "_collate_X"].astype(np.int64)) and np.array_equal(A.numpy(), arr[tag + "_collate_A"])
+    assert np.array_equal(Y.numpy(), arr[tag + "_collate_Y"].astype(np.int64))
+    Xd, Ad, Yd = next(td.device_batches(128))
+    assert torch.equal(Xd.cpu(), X) and torch.equal(Ad.cpu(), A) and torch.equal(Yd.cpu(), Y)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import ROOT, edge_case_graphs, golden, golden_zinc_coo, gtok, zinc_data_list
+from _util import ROOT, config1_examples, edge_case_graphs, golden, golden2, golden_zinc_coo, gtok, zinc_data_list
 
 gdl = gtok.graph_data_loader
 
@@ -106,6 +106,75 @@ def test_load_examples_matches_reference(tmp_path):
         (d / name).write_text(body)
     for kw, want in zip(meta["loader_misc_calls"], meta["loader_misc_out"]):
         assert gdl.load_examples(str(d / "*.json"), **kw) == want, kw
+
+
+_AGDS_SCRIPT = r"""
+import importlib, json, sys
+sys.path.insert(0, sys.argv[1])
+gtok = importlib.import_module("glearning-benchmark_amd")
+D = gtok.graph_data_loader.GraphTokenDatasetForAutoGraph
+cases = json.load(open(sys.argv[3]))
+out = []
+for kw in cases:
+    ds = D(sys.argv[2], **kw)
+    out.append(dict(processed_dir=ds.processed_dir, raw_dir=ds.raw_dir, items=[
+        dict(edge_index=d.edge_index.tolist(), edge_index_shape=list(d.edge_index.shape), y=d.y.tolist(), y_dtype=str(d.y.dtype),
+             num_nodes=int(d.num_nodes), query_u=getattr(d, "query_u", None), query_v=getattr(d, "query_v", None)) for d in ds]))
+json.dump(out, open(sys.argv[4], "w"))
+"""
+
+
+def test_graph_token_dataset_for_autograph_matches_reference(tmp_path):
+    """GraphTokenDatasetForAutoGraph.process() (reference :259-408) item for item: file sampling per algorithm,
+    num_pairs_per_graph sampling, val -> test fallback, INF / unlabeled / empty records skipped, query fields, the
+    processed-cache key.  The per-algorithm sampling seed is `seed + hash(algo) % 10000` in the reference, so the
+    mirror runs in a child interpreter with the PYTHONHASHSEED the fixture was generated under (0)."""
+    import subprocess
+    import sys
+    _, meta = golden2()
+    root = tmp_path / "graph-token"
+    gtok.synth.write_tree(str(root), meta["agds_tree"])
+    cases = tmp_path / "cases.json"; out = tmp_path / "out.json"
+    cases.write_text(json.dumps([c["kwargs"] for c in meta["agds_cases"]]))
+    env = dict(os.environ, PYTHONHASHSEED="0", PYTHONDONTWRITEBYTECODE="1")
+    for attempt in ("processed from JSON", "served from the processed/ cache"):
+        subprocess.run([sys.executable, "-c", _AGDS_SCRIPT, ROOT, str(root), str(cases), str(out)], check=True, env=env,
+                       stdout=subprocess.DEVNULL)
+        got = json.loads(out.read_text())
+        assert len(got) == len(meta["agds_cases"])
+        for g, want in zip(got, meta["agds_cases"]):
+            assert os.path.relpath(g["processed_dir"], str(root)) == want["processed_dir"], attempt
+            assert os.path.relpath(g["raw_dir"], str(root)) == want["raw_dir"]
+            assert g["items"] == want["items"], (attempt, want["kwargs"])
+            assert os.path.exists(os.path.join(g["processed_dir"], "data.pt"))
+    assert sum(len(c["items"]) for c in meta["agds_cases"]) > 100
+    D = gdl.GraphTokenDatasetForAutoGraph
+    with pytest.raises(RuntimeError) as e:
+        D(str(root), task="cycle_check", algorithm=["nope"], split="train")
+    assert str(e.value) == meta["agds_missing_error"]
+    # a data.pt that is not ours (the reference's PyG pickle) is neither read nor overwritten
+    ds = D(str(root), task="cycle_check", algorithm=["er", "ba", "path"], split="train")
+    path = ds.processed_paths[0]
+    with open(path, "wb") as f:
+        f.write(b"not a gtok cache")
+    ds2 = D(str(root), task="cycle_check", algorithm=["er", "ba", "path"], split="train")
+    assert len(ds2) == len(ds) and open(path, "rb").read() == b"not a gtok cache"
+    b = ds2.graph_batch()
+    assert b.num_graphs == len(ds2) and int(b.node_ptr[-1]) == sum(d.num_nodes for d in ds2)
+
+
+@pytest.mark.parametrize("task", ["cycle_check", "shortest_path"])
+def test_config1_corpus_host_side(task, tmp_path):
+    """BASELINE config 1 at 1k records: our generator's tree -> the mirror's loader gives the example dicts the
+    reference's loader gave (texts, labels, queries), and the frequency-ordered vocab is the reference's."""
+    arr, meta = golden2()
+    algs = ["er", "ba", "sbm", "path", "star", "complete"]
+    gtok.synth.write_tree(str(tmp_path), gtok.synth.graph_token_tree(167, seed=1234, task=task, algorithms=algs, splits=("train",)))
+    ex = gdl.load_examples_multi_algorithm(str(tmp_path), task, algs, "train", seed=0)
+    want = config1_examples(task)
+    assert len(ex) == 1002 and ex == want
+    v, _ = gdl.build_vocab_from_texts([e["text"] for e in ex], max_tokens=600)
+    assert list(v.items()) == [tuple(p) for p in meta[f"config1_{task}_vocab"]]
 
 
 def test_host_collates_match_reference():

@@ -3,7 +3,7 @@ plus the reference-visible invariants of the SENT spec (the only thing that can 
 import numpy as np
 import pytest
 
-from _util import both, edge_case_graphs, golden, golden_zinc_coo, gtok, orc, unpad
+from _util import both, config1_examples, edge_case_graphs, golden, golden2, golden_zinc_coo, gtok, orc, unpad
 
 
 def test_philox_known_answers():
@@ -42,6 +42,23 @@ def test_text_to_ids_matches_reference(task, vname, max_len):
     assert ln.tolist() == want_len.tolist()
     assert unpad(ids, ln) == unpad(arr[f"{tag}{vname}_L{max_len}_ids"], want_len)
     assert [int(e["label"]) for e in kept] == arr[f"{tag}{vname}_L{max_len}_y"].tolist()
+
+
+@pytest.mark.parametrize("task", ["cycle_check", "shortest_path"])
+def test_config1_text_to_ids_matches_reference(task):
+    """BASELINE config 1 at the size SURVEY.md section 8d names (1,002 records per task): oracle == reference TokenDataset,
+    and the oracle's collate of the first 128 rows == the reference's collate."""
+    arr, meta = golden2()
+    tag = "config1_" + task
+    vocab = dict(meta[tag + "_vocab"])
+    kept = [e for e in config1_examples(task) if e["label"] is not None]
+    want_len = arr[tag + "_len"]
+    ids, ln = orc.text_to_ids([e["text"] for e in kept], vocab, 600, int(want_len.max()), nthreads=4)
+    assert ln.tolist() == want_len.tolist() and len(kept) == want_len.size
+    assert np.array_equal(np.where(np.arange(ids.shape[1])[None, :] < ln[:, None], ids, -1), arr[tag + "_ids"].astype(np.int64))
+    assert [int(e["label"]) for e in kept] == arr[tag + "_y"].tolist()
+    X, A, _ = orc.collate(ids, ln, np.arange(128), vocab["<pad>"], int(ln[:128].max()))
+    assert np.array_equal(X, arr[tag + "_collate_X"].astype(np.int64)) and np.array_equal(A.astype(bool), arr[tag + "_collate_A"])
 
 
 def test_zinc_text_path_equals_graph_path():
