@@ -29,6 +29,7 @@ class GtokCsr(ctypes.Structure):
         ("eorder", ctypes.c_void_p), ("nattr", ctypes.c_void_p),
         ("eattr", ctypes.c_void_p),
         ("chunk_nodes", ctypes.c_int32), ("chunk_edges", ctypes.c_int32),
+        ("max_degree", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 

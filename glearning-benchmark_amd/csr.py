@@ -58,6 +58,7 @@ class GraphBatch:
     flags: int = 0                    # GTOK_CSR_*: properties verified on the host for the whole batch
     chunk_nodes: int = 0              # max over 64-graph groups of sum N_g / sum E_g (LDS sizing of the
     chunk_edges: int = 0              # lane-per-graph kernel); 0 = unknown
+    max_degree: int = 0               # longest CSR row (an upper bound is fine); 0 = unknown
 
     @property
     def device(self) -> torch.device:
@@ -75,13 +76,13 @@ class GraphBatch:
         mv = lambda t: None if t is None else t.to(device, non_blocking=True)
         return GraphBatch(self.num_graphs, self.max_nodes, self.max_edges, mv(self.node_ptr), mv(self.edge_ptr),
                           mv(self.rowptr), mv(self.col), mv(self.eorder), mv(self.nattr), mv(self.eattr),
-                          self.flags, self.chunk_nodes, self.chunk_edges)
+                          self.flags, self.chunk_nodes, self.chunk_edges, self.max_degree)
 
     def c_struct(self) -> GtokCsr:
         p = lambda t: None if t is None else t.data_ptr()
         return GtokCsr(self.num_graphs, self.max_nodes, self.max_edges, self.flags, p(self.node_ptr), p(self.edge_ptr),
                        p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr),
-                       self.chunk_nodes, self.chunk_edges)
+                       self.chunk_nodes, self.chunk_edges, self.max_degree, 0)
 
     def node_counts(self) -> torch.Tensor:
         return self.node_ptr[1:] - self.node_ptr[:-1]
@@ -109,7 +110,7 @@ class GraphBatch:
         return GraphBatch(hi - lo, int(nc.max()) if hi > lo else 0, int(ec.max()) if hi > lo else 0,
                           (self.node_ptr[lo:hi + 1] - n0).clone(), (self.edge_ptr[lo:hi + 1] - e0).clone(),
                           sl(self.rowptr, n0 + lo, n1 + hi), sl(self.col, e0, e1), sl(self.eorder, e0, e1),
-                          sl(self.nattr, n0, n1), sl(self.eattr, e0, e1), self.flags, cn, ce)
+                          sl(self.nattr, n0, n1), sl(self.eattr, e0, e1), self.flags, cn, ce, self.max_degree)
 
     # ------------------------------------------------------------------ builders
     @staticmethod
@@ -162,7 +163,7 @@ class GraphBatch:
         flags = CSR_SIMPLE_SYMMETRIC if (check_symmetric and E and _simple_symmetric(gid_e, src, dst, max_nodes)) else 0
         return GraphBatch(G, max_nodes, int(edge_counts.max()) if G else 0,
                           t(node_ptr.astype(np.int32)), t(edge_ptr), t(rowptr), t(col), t(eorder), t(nattr), t(eattr),
-                          flags, _chunk_max(node_counts), _chunk_max(edge_counts))
+                          flags, _chunk_max(node_counts), _chunk_max(edge_counts), int(cnt.max()) if N else 0)
 
     @staticmethod
     def from_coo_device(node_counts, edge_counts, src, dst, x=None, edge_attr=None, device="cuda",
@@ -230,7 +231,7 @@ class GraphBatch:
             pad = (-c.numel()) % 64
             return int(torch.nn.functional.pad(c, (0, pad)).reshape(-1, 64).sum(1).max())
         return GraphBatch(G, max_nodes, int(ec.max()) if G else 0, node_ptr.to(torch.int32), edge_ptr, rowptr, col, eorder,
-                          nattr, eattr, flags, chunk_max(nc), chunk_max(ec))
+                          nattr, eattr, flags, chunk_max(nc), chunk_max(ec), int(cnt.max()) if N else 0)
 
     @staticmethod
     def from_data_list(data_list: Sequence, labeled: Optional[bool] = None) -> "GraphBatch":

@@ -79,19 +79,22 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.cap_e = g->chunk_edges > 0 ? g->chunk_edges : 64 * maxe;
     a.cap_r = a.cap_n + 64;
     int off = 0;
-    a.off_rp = off; off += align_up(a.cap_r + 4, 16);
-    a.off_col = off; off += align_up(a.cap_e + 4, 16);   // +4: clamped look-ahead reads of an empty last row
+    a.off_rp = off; off += align_up(a.cap_r + 8, 16);
+    a.off_col = off; off += align_up(a.cap_e + 8, 16);   // +8: a row's first four entries are read as an aligned dword pair
     a.off_eat = a.off_nat = off;
     if (p->labeled) {
-      a.off_eat = off; off += align_up(a.cap_e + 4, 16);
-      a.off_nat = off; off += align_up(a.cap_n, 16);
+      a.off_eat = off; off += align_up(a.cap_e + 8, 16);
+      a.off_nat = off; off += align_up(a.cap_n + 8, 16);
+    } else {
+      a.off_nat = off; off += align_up(a.cap_n + 8, 16);  // unlabelled: the node -> visit index table alone
     }
-    a.off_vidx = off; off += maxn * 64;
-    a.off_rem = off; off += maxn * 64;
     a.lds = align_up(off, 16);
     if (a.lds > 64 * 1024) return GTOK_E_TOO_LARGE;
+    // counter planes: degree < 2^P; an unknown max_degree is covered by P = 6 (a node of a simple graph with <= 64 nodes has < 64 neighbours)
+    const bool p3 = g->max_degree > 0 && g->max_degree <= 7;
     typedef void (*K)(const SentLaneArgs);
-    K kern = p->labeled ? (K)sent_lane_kernel<true> : (K)sent_lane_kernel<false>;
+    K kern = p->labeled ? (p3 ? (K)sent_lane_kernel<true, 3> : (K)sent_lane_kernel<true, 6>)
+                        : (p3 ? (K)sent_lane_kernel<false, 3> : (K)sent_lane_kernel<false, 6>);
     int dev = 0, ncu = 256, occ = 1;
     if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -105,8 +108,6 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.units = (g->num_graphs + 63) / 64;
     int nb = ncu * occ;
     if (nb > a.units) nb = a.units;
-    a.queue = take_queue_slot(dev);
-    if (!a.queue) return GTOK_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64), (size_t)a.lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
   }

@@ -92,6 +92,8 @@ typedef struct gtok_csr {
   const uint8_t *eattr;
   int32_t chunk_nodes; /* max over 64-graph groups [64i, 64i+64) of sum N_g; 0 = unknown (64*max_nodes assumed) */
   int32_t chunk_edges; /* same for sum E_g                                                                      */
+  int32_t max_degree;  /* longest CSR row of the batch (upper bound accepted); 0 = unknown                       */
+  int32_t reserved;    /* must be 0                                                                              */
 } gtok_csr;
 
 /* LUT layout for gtok_ibtt_zinc (int32 vocab ids; an absent token holds pad_id
