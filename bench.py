@@ -115,7 +115,7 @@ def main():
     safe_ld = gtok.ops.sent_safe_ld(batch, zinc, max_len)
     if args.ld == "tight":
         _, ln0 = gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=0, ld=safe_ld, **kw)
-        ld = min(safe_ld, (int(ln0.max().item()) * 5 // 4 + 8 + 3) // 4 * 4)
+        ld = min(safe_ld, (int(ln0.max().item()) * 5 // 4 + 8 + 15) // 16 * 16)   # rows start on 64-byte boundaries
         ld = gtok.dist.all_reduce_max_int(ld, dev)
     else:
         ld = gtok.dist.all_reduce_max_int(safe_ld, dev)

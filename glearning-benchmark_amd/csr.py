@@ -59,6 +59,8 @@ class GraphBatch:
     chunk_nodes: int = 0              # max over 64-graph groups of sum N_g / sum E_g (LDS sizing of the
     chunk_edges: int = 0              # lane-per-graph kernel); 0 = unknown
     max_degree: int = 0               # longest CSR row (an upper bound is fine); 0 = unknown
+    rowptr8: Optional[torch.Tensor] = None   # uint8 mirrors of rowptr / col (device batches of small graphs:
+    col8: Optional[torch.Tensor] = None      # ops.pack8, once per resident batch)
 
     @property
     def device(self) -> torch.device:
@@ -76,13 +78,13 @@ class GraphBatch:
         mv = lambda t: None if t is None else t.to(device, non_blocking=True)
         return GraphBatch(self.num_graphs, self.max_nodes, self.max_edges, mv(self.node_ptr), mv(self.edge_ptr),
                           mv(self.rowptr), mv(self.col), mv(self.eorder), mv(self.nattr), mv(self.eattr),
-                          self.flags, self.chunk_nodes, self.chunk_edges, self.max_degree)
+                          self.flags, self.chunk_nodes, self.chunk_edges, self.max_degree, mv(self.rowptr8), mv(self.col8))
 
     def c_struct(self) -> GtokCsr:
         p = lambda t: None if t is None else t.data_ptr()
         return GtokCsr(self.num_graphs, self.max_nodes, self.max_edges, self.flags, p(self.node_ptr), p(self.edge_ptr),
                        p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr),
-                       self.chunk_nodes, self.chunk_edges, self.max_degree, 0)
+                       self.chunk_nodes, self.chunk_edges, self.max_degree, 0, p(self.rowptr8), p(self.col8))
 
     def node_counts(self) -> torch.Tensor:
         return self.node_ptr[1:] - self.node_ptr[:-1]

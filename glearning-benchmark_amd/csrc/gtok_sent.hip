@@ -79,7 +79,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.cap_e = g->chunk_edges > 0 ? g->chunk_edges : 64 * maxe;
     a.cap_r = a.cap_n + 64;
     int off = 0;
-    a.off_rp = off; off += align_up(a.cap_r + 8, 16);
+    a.off_rp = off; off += align_up(a.cap_r + 16, 16);  // + 16: the counter set-up reads whole dwords around a lane's row pointers
     a.off_col = off; off += align_up(a.cap_e + 8, 16);   // +8: a row's first four entries are read as an aligned dword pair
     a.off_eat = a.off_nat = off;
     if (p->labeled) {
@@ -91,10 +91,14 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.lds = align_up(off, 16);
     if (a.lds > 64 * 1024) return GTOK_E_TOO_LARGE;
     // counter planes: degree < 2^P; an unknown max_degree is covered by P = 6 (a node of a simple graph with <= 64 nodes has < 64 neighbours)
-    const bool p3 = g->max_degree > 0 && g->max_degree <= 7;
+    const bool p3 = g->max_degree > 0 && g->max_degree <= 15;
     typedef void (*K)(const SentLaneArgs);
-    K kern = p->labeled ? (p3 ? (K)sent_lane_kernel<true, 3> : (K)sent_lane_kernel<true, 6>)
-                        : (p3 ? (K)sent_lane_kernel<false, 3> : (K)sent_lane_kernel<false, 6>);
+    const bool pk = g->rowptr8 && g->col8;
+#define GTOK_LANE_K(LAB, REMAP)                                                                                       \
+  (pk ? (p3 ? (K)sent_lane_kernel<LAB, 4, REMAP, true> : (K)sent_lane_kernel<LAB, 6, REMAP, true>)                    \
+      : (p3 ? (K)sent_lane_kernel<LAB, 4, REMAP, false> : (K)sent_lane_kernel<LAB, 6, REMAP, false>))
+    K kern = !p->labeled ? GTOK_LANE_K(false, false) : p->remap_zinc ? GTOK_LANE_K(true, true) : GTOK_LANE_K(true, false);
+#undef GTOK_LANE_K
     int dev = 0, ncu = 256, occ = 1;
     if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -198,6 +202,33 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     if (!a.queue) return GTOK_E_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// byte-packed mirror of rowptr / col (include/gtok.h: gtok_csr_pack8)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) csr_pack8_kernel(const int32_t *__restrict__ src, int64_t n, uint8_t *__restrict__ dst) {
+  const int64_t nv = n >> 2, step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nv; t += step) {
+    const I32x4 v = reinterpret_cast<const I32x4 *>(src)[t];
+    const uint32_t w = ((uint32_t)v.x & 255u) | (((uint32_t)v.y & 255u) << 8) | (((uint32_t)v.z & 255u) << 16) | ((uint32_t)v.w << 24);
+    __builtin_memcpy(dst + 4 * t, &w, 4);
+  }
+  if (blockIdx.x == 0 && (int64_t)threadIdx.x < (n & 3)) dst[(nv << 2) + threadIdx.x] = (uint8_t)src[(nv << 2) + threadIdx.x];
+}
+
+extern "C" int gtok_csr_pack8(const gtok_csr *g, int64_t num_rowptr, int64_t num_col, uint8_t *rowptr8, uint8_t *col8, void *stream) {
+  if (!g || num_rowptr < 0 || num_col < 0) return GTOK_E_INVAL;
+  if (g->max_edges > 255 || g->max_nodes > 256) return GTOK_E_TOO_LARGE;
+  if ((num_rowptr && (!g->rowptr || !rowptr8)) || (num_col && (!g->col || !col8))) return GTOK_E_INVAL;
+  auto run = [&](const int32_t *src, int64_t n, uint8_t *dst) {
+    if (n == 0) return;
+    const int64_t nb = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(csr_pack8_kernel, dim3((unsigned)(nb < 1 ? 1 : nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, src, n, dst);
+  };
+  run(g->rowptr, num_rowptr, rowptr8);
+  run(g->col, num_col, col8);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 

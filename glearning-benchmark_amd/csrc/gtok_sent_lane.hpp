@@ -27,6 +27,10 @@
 
 namespace gtok {
 
+#ifndef GTOK_LANE_SECTOR_GROUPS
+#define GTOK_LANE_SECTOR_GROUPS 2
+#endif
+
 struct __attribute__((aligned(4))) U32x2a4 { uint32_t lo, hi; };   // two dwords at a 4-byte aligned LDS address: ds_read2_b32
 
 // k-th (0-based) set bit of w, per lane, k < popcount(w): branch-free halving on popcounts.  (A clear-lowest-bit
@@ -42,6 +46,41 @@ __device__ __forceinline__ int kth_bit64(uint64_t w, int k) {
   return base + ((k >= (int)(x & 1u)) ? 1 : 0);
 }
 
+// 16-byte-vector staging of a byte array into LDS: lane_load16 issues the first U vectors of the lane, lane_commit16
+// writes them (then whatever lies beyond U * 64 vectors, and the last < 16 bytes) - `src` has the array's element
+// alignment only, the LDS destination is 16-byte aligned
+template <int U>
+__device__ __forceinline__ void lane_load16(const uint8_t *__restrict__ src, int count, int lane, U8x16 (&r)[U]) {
+  const int nv = count >> 4;
+  const U8x16 *v = reinterpret_cast<const U8x16 *>(src);
+#pragma unroll
+  for (int j = 0; j < U; ++j) { const int t = lane + j * kWave; r[j] = t < nv ? v[t] : U8x16{0, 0, 0, 0}; }
+}
+template <int U>
+__device__ __forceinline__ void lane_commit16(const uint8_t *__restrict__ src, int count, int lane, const U8x16 (&r)[U], uint8_t *dst) {
+  const int nv = count >> 4;
+  const U8x16 *v = reinterpret_cast<const U8x16 *>(src);
+  U8x16a *d = reinterpret_cast<U8x16a *>(dst);
+#pragma unroll
+  for (int j = 0; j < U; ++j) { const int t = lane + j * kWave; if (t < nv) d[t] = U8x16a{r[j].a, r[j].b, r[j].c, r[j].d}; }
+  _Pragma("clang loop vectorize(disable) unroll(disable)")
+  for (int t = lane + U * kWave; t < nv; t += kWave) { const U8x16 x = v[t]; d[t] = U8x16a{x.a, x.b, x.c, x.d}; }
+  if (lane < (count & 15)) dst[(nv << 4) + lane] = src[(nv << 4) + lane];
+}
+
+// Padding store.  (-DGTOK_SC1_PAD_STORES: `sc1` stores, written through and dropped from the XCD's L2 - tried to keep
+// the padding, 56 % of a ZINC slab, from pushing half-written token lines out of L2: the counted write traffic did not
+// move (359 vs 353 MB) and the walks got slower behind the write-through stores, 0.120 vs 0.1175 ms.)
+__device__ __forceinline__ void store_pad16(int32_t *p, int pad) {
+#ifndef GTOK_SC1_PAD_STORES
+  *reinterpret_cast<I32x4 *>(p) = I32x4{pad, pad, pad, pad};
+#else
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i v = {pad, pad, pad, pad};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
 struct SentLaneArgs {
   gtok_csr g;
   gtok_sent_params p;
@@ -55,7 +94,9 @@ struct SentLaneArgs {
   int units;                               // 64-graph units in the batch
 };
 
-template <bool LAB, int P>
+// PK: the batch carries the byte-packed rowptr / col mirror (gtok_csr.rowptr8 / col8): a unit is staged with 12
+// 16-byte loads per lane, all in flight at once, and no packing instructions
+template <bool LAB, int P, bool REMAP, bool PK>
 __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -65,8 +106,13 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
   const int idx_off = GTOK_SENT_IDX_OFFSET;
   const int node_off = idx_off + a.p.max_num_nodes;
   const int edge_off = node_off + a.p.num_node_types;
-  const uint32_t k0 = (uint32_t)a.p.seed, k1 = (uint32_t)(a.p.seed >> 32), epoch = (uint32_t)a.p.epoch;
-  const bool remap = a.p.remap_zinc != 0;   // folded into the emission constants (host guarantees maxn <= max_num_nodes)
+  // the Philox key lives in VECTOR registers: as scalars the compiler precomputes the ten round keys of both halves
+  // (20 SGPRs, spilled, read back with v_readlane in every block); as vectors a round costs two v_add
+  uint32_t k0, k1;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(k0) : "s"((uint32_t)a.p.seed));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(k1) : "s"((uint32_t)(a.p.seed >> 32)));
+  const uint32_t epoch = (uint32_t)a.p.epoch;
+  constexpr bool remap = REMAP;             // folded into the emission constants (host guarantees maxn <= max_num_nodes)
   const int pos_base = remap ? 22 : idx_off;
   const uint64_t T_RESET = remap ? 2 : GTOK_SENT_RESET, T_LADJ = remap ? 2 : GTOK_SENT_LADJ;
   const uint64_t T_RADJ = remap ? 2 : GTOK_SENT_RADJ, T_EOS = remap ? 1 : GTOK_SENT_EOS;
@@ -104,13 +150,8 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
 #pragma unroll
     for (int j = 0; j < UR; ++j) { const int t = lane + j * kWave; r.rv[j] = t < nrv ? rpv[t] : I32x4{0, 0, 0, 0}; }
     if (LAB) {
-      const int nev = (int)min(h.E1 - h.E0, (int64_t)cap_e) >> 4, nnv = min(h.N1 - h.N0, cap_n) >> 4;
-      const U8x16 *ecv = reinterpret_cast<const U8x16 *>(a.g.eattr + h.E0);
-      const U8x16 *ncv = reinterpret_cast<const U8x16 *>(a.g.nattr + h.N0);
-#pragma unroll
-      for (int j = 0; j < UE; ++j) { const int t = lane + j * kWave; r.ev[j] = t < nev ? ecv[t] : U8x16{0, 0, 0, 0}; }
-#pragma unroll
-      for (int j = 0; j < UN; ++j) { const int t = lane + j * kWave; r.nv[j] = t < nnv ? ncv[t] : U8x16{0, 0, 0, 0}; }
+      lane_load16<UE>(a.g.eattr + h.E0, (int)min(h.E1 - h.E0, (int64_t)cap_e), lane, r.ev);
+      lane_load16<UN>(a.g.nattr + h.N0, min(h.N1 - h.N0, cap_n), lane, r.nv);
     }
   };
   auto commit_a = [&](const Hdr &h, const RegsA &r) __attribute__((always_inline)) {
@@ -121,22 +162,31 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
     const int nrv = cr >> 2;
 #pragma unroll
     for (int j = 0; j < UR; ++j) { const int t = lane + j * kWave; if (t < nrv) srp4[t] = pack4(r.rv[j]); }
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
     for (int t = lane + UR * kWave; t < nrv; t += kWave) srp4[t] = pack4(rpv[t]);
     if (lane < (cr & 3)) srp[(nrv << 2) + lane] = (uint8_t)rpc[(nrv << 2) + lane];
     if (LAB) {
-      const int ce = (int)min(h.E1 - h.E0, (int64_t)cap_e), cn = min(h.N1 - h.N0, cap_n);
-      const uint8_t *__restrict__ ec = a.g.eattr + h.E0, *__restrict__ nc = a.g.nattr + h.N0;
-      const U8x16 *ecv = reinterpret_cast<const U8x16 *>(ec), *ncv = reinterpret_cast<const U8x16 *>(nc);
-      U8x16a *seat16 = reinterpret_cast<U8x16a *>(seat), *snat16 = reinterpret_cast<U8x16a *>(snat);
-      const int nev = ce >> 4, nnv = cn >> 4;
-#pragma unroll
-      for (int j = 0; j < UE; ++j) { const int t = lane + j * kWave; if (t < nev) seat16[t] = U8x16a{r.ev[j].a, r.ev[j].b, r.ev[j].c, r.ev[j].d}; }
-#pragma unroll
-      for (int j = 0; j < UN; ++j) { const int t = lane + j * kWave; if (t < nnv) snat16[t] = U8x16a{r.nv[j].a, r.nv[j].b, r.nv[j].c, r.nv[j].d}; }
-      for (int t = lane + UE * kWave; t < nev; t += kWave) { const U8x16 x = ecv[t]; seat16[t] = U8x16a{x.a, x.b, x.c, x.d}; }
-      for (int t = lane + UN * kWave; t < nnv; t += kWave) { const U8x16 x = ncv[t]; snat16[t] = U8x16a{x.a, x.b, x.c, x.d}; }
-      if (lane < (ce & 15)) seat[(nev << 4) + lane] = ec[(nev << 4) + lane];
-      if (lane < (cn & 15)) snat[(nnv << 4) + lane] = nc[(nnv << 4) + lane];
+      lane_commit16<UE>(a.g.eattr + h.E0, (int)min(h.E1 - h.E0, (int64_t)cap_e), lane, r.ev, seat);
+      lane_commit16<UN>(a.g.nattr + h.N0, min(h.N1 - h.N0, cap_n), lane, r.nv, snat);
+    }
+  };
+  // packed mirror: everything is bytes
+  constexpr int PR = 2, PC = 4;
+  struct RegsP { U8x16 rv[PR], cv[PC], ev[UE], nv[UN]; };
+  auto load_p = [&](const Hdr &h, RegsP &r) __attribute__((always_inline)) {
+    lane_load16<PR>(a.g.rowptr8 + h.N0 + h.g0, min((h.N1 - h.N0) + (h.gl - h.g0), cap_r), lane, r.rv);
+    lane_load16<PC>(a.g.col8 + h.E0, (int)min(h.E1 - h.E0, (int64_t)cap_e), lane, r.cv);
+    if (LAB) {
+      lane_load16<UE>(a.g.eattr + h.E0, (int)min(h.E1 - h.E0, (int64_t)cap_e), lane, r.ev);
+      lane_load16<UN>(a.g.nattr + h.N0, min(h.N1 - h.N0, cap_n), lane, r.nv);
+    }
+  };
+  auto commit_p = [&](const Hdr &h, const RegsP &r) __attribute__((always_inline)) {
+    lane_commit16<PR>(a.g.rowptr8 + h.N0 + h.g0, min((h.N1 - h.N0) + (h.gl - h.g0), cap_r), lane, r.rv, srp);
+    lane_commit16<PC>(a.g.col8 + h.E0, (int)min(h.E1 - h.E0, (int64_t)cap_e), lane, r.cv, scol);
+    if (LAB) {
+      lane_commit16<UE>(a.g.eattr + h.E0, (int)min(h.E1 - h.E0, (int64_t)cap_e), lane, r.ev, seat);
+      lane_commit16<UN>(a.g.nattr + h.N0, min(h.N1 - h.N0, cap_n), lane, r.nv, snat);
     }
   };
   auto stage_b = [&](const Hdr &h) __attribute__((always_inline)) {
@@ -150,6 +200,7 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
     for (int j = 0; j < UC; ++j) { const int t = lane + j * kWave; cv[j] = t < ncv ? ccv[t] : I32x4{0, 0, 0, 0}; }
 #pragma unroll
     for (int j = 0; j < UC; ++j) { const int t = lane + j * kWave; if (t < ncv) scol4[t] = pack4(cv[j]); }
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
     for (int t = lane + UC * kWave; t < ncv; t += kWave) scol4[t] = pack4(ccv[t]);
     if (lane < (ce & 3)) scol[(ncv << 2) + lane] = (uint8_t)cc[(ncv << 2) + lane];
   };
@@ -157,25 +208,91 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
   // Units are dealt round-robin (a unit's time is the longest of its 64 walks: they are all alike); with 16
   // resident waves per CU a ZINC-full launch gives every wave exactly one unit.
   const int stride = (int)gridDim.x;
-  int unit = virtual_block();
-  if (unit >= a.units) return;
-  Hdr h = header(unit);
-  {
-    RegsA ra;
-    load_a(h, ra);
-    commit_a(h, ra);
-    stage_b(h);
-  }
-  for (;;) {
+  int lw = 0, done_g0 = -1;                 // pad start of this lane's finished row / first graph of the finished unit
+  // pad the tails of a finished unit's 64 rows: four rows per pass, 16 lanes x 16-byte stores on each
+  auto pad_rows = [&]() __attribute__((always_inline)) {
+    const int q = lane & 15;
+    for (int it = 0; it < 16; ++it) {
+      const int r = it * 4 + (lane >> 4);
+      const int lr = __builtin_amdgcn_ds_bpermute(r << 2, lw);
+      if (done_g0 + it * 4 >= G) break;
+      if (done_g0 + r < G) {
+        int32_t *__restrict__ rowp = a.out + (int64_t)(done_g0 + r) * ld + lr;
+        const int nrem = ld - lr, nvec = nrem >> 2;
+        _Pragma("clang loop vectorize(disable) unroll(disable)")
+        for (int t = q; t < nvec; t += 16) store_pad16(rowp + 4 * t, pad);
+        if (q < (nrem & 3)) rowp[(nvec << 2) + q] = pad;
+      }
+    }
+  };
+#ifdef GTOK_PHASE_TIMING   // profiling build only: cycle stamps per phase, left in the last 8 columns of the unit's first row
+  uint64_t ts[5] = {0, 0, 0, 0, 0};
+  uint32_t rt0 = 0, iters = 0;
+  auto stamps_out = [&]() __attribute__((always_inline)) {
+    if (lane == 0 && ld >= 16 && done_g0 >= 0) {
+      int32_t *row = a.out + (int64_t)done_g0 * ld + ld - 8;
+      row[0] = (int32_t)(ts[1] - ts[0]); row[1] = (int32_t)(ts[2] - ts[1]); row[2] = (int32_t)(ts[3] - ts[2]);
+      row[3] = (int32_t)(ts[4] - ts[3]); row[4] = (int32_t)rt0; row[5] = (int32_t)__builtin_amdgcn_s_memrealtime();
+      row[6] = (int32_t)iters; row[7] = (int32_t)blockIdx.x;
+    }
+  };
+#endif
+  for (int unit = virtual_block(); unit < a.units; unit += stride) {
+    // ---- stage this unit; the loads of phase A go out ahead of the previous unit's padding stores
+#ifdef GTOK_PHASE_TIMING
+    const uint64_t ts0_new = __builtin_amdgcn_s_memtime();
+    const uint32_t rt0_new = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+    const Hdr h = header(unit);
+    auto between = [&]() __attribute__((always_inline)) {   // behind the loads, ahead of the LDS writes
+      if (done_g0 >= 0) pad_rows();
+#ifdef GTOK_PHASE_TIMING
+      stamps_out();
+      ts[0] = ts0_new; rt0 = rt0_new; iters = 0;
+#endif
+      __builtin_amdgcn_wave_barrier();
+    };
+    if (PK) {
+      RegsP rp;
+      load_p(h, rp);
+      between();
+      commit_p(h, rp);
+    } else {
+      {
+        RegsA ra;
+        load_a(h, ra);
+        between();
+        commit_a(h, ra);
+      }
+      stage_b(h);
+    }
     wave_sync();
+#ifdef GTOK_PHASE_TIMING
+    ts[1] = __builtin_amdgcn_s_memtime();
+#endif
     const int g = h.g0 + lane;
     const bool valid = h.valid;
     const int n = h.n, e = h.e;
     const int rbase = (h.nb0 - h.N0) + lane, cbase = (int)(h.e0 - h.E0), nbase = h.nb0 - h.N0;
 
+#ifndef GTOK_LANE_NO_PRIO
+    // A unit runs as long as its longest walk, and a launch as long as its slowest unit (one unit per wave): units
+    // that hold one of the batch's largest graphs - the likely stragglers, walk length grows with the node count -
+    // get a higher issue priority than the waves they share a SIMD with, which have slack.
+    {
+      int mx = n;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+      const int behind = a.maxn - uni(mx);
+      if (behind <= 1) __builtin_amdgcn_s_setprio(3);
+      else if (behind <= 3) __builtin_amdgcn_s_setprio(2);
+      else if (behind <= 5) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     // A node's row: bounds, the set of its neighbours, and the first four neighbour ids / edge types as packed
     // bytes (molecules rarely have more; longer rows continue in byte loops).
-    struct Row { uint64_t mask; uint32_t nb4, et4; int rs, deg; };
+    struct Row { uint64_t mask; uint32_t nb4, et4, bm; int rs, deg; };   // bm: byte mask of the valid entries among the first four
     auto load_row = [&](int v) __attribute__((always_inline)) -> Row {
       Row r;
       r.rs = srp[rbase + v];
@@ -188,22 +305,24 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
         const U32x2a4 t = *reinterpret_cast<const U32x2a4 *>(seat + (o & ~3));
         r.et4 = __builtin_amdgcn_alignbyte(t.hi, t.lo, (uint32_t)(o & 3));
       }
-      uint64_t m = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m |= j < r.deg ? 1ull << ((r.nb4 >> (8 * j)) & 63u) : 0ull;
+      r.bm = r.deg >= 4 ? 0xFFFFFFFFu : ((1u << (8 * r.deg)) - 1u);
+      // entries past the row's end are replaced by its first entry (duplicates are harmless in a set): no per-entry select.
+      // v_lshlrev_b64 takes the low 6 bits of its shift operand, so the upper bytes need no masking.
+      const uint32_t nv = __builtin_amdgcn_perm(r.nb4, r.nb4, 0x03020100u & r.bm);
+      uint64_t m = (1ull << (nv & 63u)) | (1ull << ((nv >> 8) & 63u)) | (1ull << ((nv >> 16) & 63u)) | (1ull << (nv >> 24 & 63u));
+      m = r.deg > 0 ? m : 0ull;
       for (int k = 4; k < r.deg; ++k) m |= 1ull << (scol[o + k] & 63u);
       r.mask = m;
       return r;
     };
     // edge type of the listed entry row -> y (y is listed: symmetric adjacency).  Zero-byte search over the four
     // packed ids (the lowest flag of the classic (x - 0x01..) & ~x & 0x80.. test is exact), byte loop beyond.
-    auto find_et = [&](const Row &r, int y) __attribute__((always_inline)) -> int {
-      const uint32_t x = r.nb4 ^ ((uint32_t)y * 0x01010101u);
-      uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;
-      z &= r.deg >= 4 ? 0xFFFFFFFFu : ((1u << (8 * r.deg)) - 1u);
-      int et = 0;
+    auto find_et = [&](const Row &r, uint32_t y) __attribute__((always_inline)) -> uint32_t {
+      const uint32_t x = r.nb4 ^ (y * 0x01010101u);
+      const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u & r.bm;
+      uint32_t et = 0;
       if (z) {
-        et = (int)((r.et4 >> (__builtin_ctz(z) - 7)) & 255u);
+        et = (r.et4 >> (__builtin_ctz(z) - 7)) & 255u;
       } else {
         const int o = cbase + r.rs;
         for (int k = 4; k < r.deg; ++k) if (scol[o + k] == (uint8_t)y) et = seat[o + k];
@@ -215,34 +334,73 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
     uint64_t c[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) c[p] = 0;
-    {
-      int lo = n > 0 ? (int)srp[rbase] : 0;
-      for (int u = 0; u < n; ++u) {
-        const int hi = min((int)srp[rbase + u + 1], e);
-        const uint32_t dg = (uint32_t)max(hi - lo, 0);
-        lo = hi;
+    if (n > 0) {
+      // four nodes per step, from aligned dwords of the lane's row pointers: the byte-wise differences of a
+      // non-decreasing byte string need no borrows, so one 32-bit subtraction yields four degrees; bit p of the four
+      // is gathered into a nibble of plane p.  (Bits of nodes >= n are garbage and never looked at: `live` is masked
+      // by `vis`, decrements only touch neighbours.)
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(srp + (rbase & ~3));
+      const uint32_t sh = (uint32_t)(rbase & 3);
+      uint32_t d0 = w[0], d1 = w[1];
+      uint32_t cur4 = __builtin_amdgcn_alignbyte(d1, d0, sh);              // row pointers 0..3
+      const int steps = (n + 3) >> 2;
+#pragma unroll 4
+      for (int i = 0; i < steps; ++i) {
+        const uint32_t d2 = w[i + 2];
+        const uint32_t nxt4 = __builtin_amdgcn_alignbyte(d2, d1, sh);        // row pointers 4i+4 .. 4i+7
+        const uint32_t dg4 = __builtin_amdgcn_alignbyte(nxt4, cur4, 1u) - cur4;   // degrees of nodes 4i .. 4i+3
 #pragma unroll
-        for (int p = 0; p < P; ++p) c[p] |= (uint64_t)((dg >> p) & 1u) << u;
+        for (int p = 0; p < P; ++p) {
+          const uint32_t x = (dg4 >> p) & 0x01010101u;
+          const uint32_t nib = (x | (x >> 7) | (x >> 14) | (x >> 21)) & 15u;
+          c[p] |= (uint64_t)nib << ((4 * i) & 63);
+        }
+        d1 = d2; cur4 = nxt4;
       }
     }
 
+#ifdef GTOK_PHASE_TIMING
+    ts[2] = __builtin_amdgcn_s_memtime();
+#endif
     // ---- walk (per lane; mirrors oracle_sent step for step)
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
     const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
     int32_t *__restrict__ orow = a.out + (int64_t)g * ld;
     uint64_t vis = 0, live = 0, wlo = 0;
     int nvis = 0, pos = 0, fl = 0, d = 0, cur = 0;
-    uint64_t plo = 0, phi = 0;
 
-    // token window: tokens fl .. pos-1 of the row sit in wlo, 16 bits each (pos - fl <= 3 between appends)
+    // token window: tokens fl .. pos-1 of the row sit in wlo, 16 bits each (pos - fl <= 3 between appends).  A full
+    // window (4 tokens) joins the groups of its 16-token SECTOR (pg0..pg2: 64 bytes of the row); the sector leaves with
+    // four back-to-back 16-byte stores, so every 64-byte piece of a row reaches the L2 complete and within one burst.
+    // (One 16-byte store per window left each row line half written for ~15 us at a time, and the open lines of all
+    // resident lanes - 32 MB - are the whole L2: 2.8 bytes were counted at the L2's memory side per token byte.)
+    constexpr int SG = GTOK_LANE_SECTOR_GROUPS;   // windows per store burst: 4 = 64-byte sectors, 2 = 32 bytes, 1 = every window on its own
+    uint64_t pg[SG > 1 ? SG - 1 : 1];
+#pragma unroll
+    for (int j = 0; j < SG - 1; ++j) pg[j] = 0;
+    auto tok_of = [](uint64_t w, int i) __attribute__((always_inline)) -> int { return (int)((w >> (i << 4)) & 0xFFFFu); };
+    auto put4 = [&](int at, uint64_t w) __attribute__((always_inline)) {
+      *reinterpret_cast<I32x4 *>(orow + at) = I32x4{tok_of(w, 0), tok_of(w, 1), tok_of(w, 2), (int)(w >> 48)};
+    };
+    auto group_of = [&](int j, uint64_t w) __attribute__((always_inline)) -> uint64_t {   // group j of the open burst (j = SG-1: w)
+      uint64_t r = w;
+#pragma unroll
+      for (int k = 0; k < SG - 1; ++k) r = j == k ? pg[k] : r;
+      return r;
+    };
     auto flush = [&](uint64_t w) __attribute__((always_inline)) {
-      const I32x4 v{(int)(w & 0xFFFFu), (int)((w >> 16) & 0xFFFFu), (int)((w >> 32) & 0xFFFFu), (int)(w >> 48)};
-      if (fl + 4 <= cap) {
-        *reinterpret_cast<I32x4 *>(orow + fl) = v;
-      } else {                                   // the row's cut (max_len or a narrow slab) falls inside this group
-        if (fl + 0 < cap) orow[fl + 0] = v.x;
-        if (fl + 1 < cap) orow[fl + 1] = v.y;
-        if (fl + 2 < cap) orow[fl + 2] = v.z;
+      const int gi = (fl >> 2) & (SG - 1);
+#pragma unroll
+      for (int k = 0; k < SG - 1; ++k) pg[k] = gi == k ? w : pg[k];
+      if (gi == SG - 1) {
+        const int sb = fl - 4 * (SG - 1);
+        if (fl + 4 <= cap) {
+#pragma unroll
+          for (int k = 0; k < SG - 1; ++k) put4(sb + 4 * k, pg[k]);
+          put4(fl, w);
+        } else {                                 // the row's cut (max_len or a narrow slab) falls inside this burst
+          for (int j = 0; j < 4 * SG && sb + j < cap; ++j) orow[sb + j] = tok_of(group_of(j >> 2, w), j & 3);
+        }
       }
     };
     auto append = [&](uint64_t val, int cnt) __attribute__((always_inline)) {   // cnt <= 4 tokens, lowest first
@@ -255,16 +413,18 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
     // decision d uses word d&3 of Philox block d>>2; the block is kept as two packed 64-bit values and the word
     // is extracted with mask arithmetic (a select chain over the captured words makes the compiler select
     // ADDRESSES and park them in scratch: two memory round trips per draw)
+    // decision d uses word d&3 of Philox block d>>2.  All lanes of a unit start together and draw once per step, so
+    // d is the same in every active lane: the block is refreshed by the whole wave every fourth step and the word is
+    // picked with wave-uniform selects (per-lane selection cost a 64-bit mask-and-shift sequence per draw).
+    uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
     auto below = [&](uint32_t nchoices) __attribute__((always_inline)) -> uint32_t {
-      const int w = d & 3;
+      const int w = uni(d) & 3;
       if (w == 0) {
         uint32_t o[4];
         philox4x32_10((uint32_t)(d >> 2), epoch, gid_lo, gid_hi, k0, k1, o);
-        plo = ((uint64_t)o[1] << 32) | o[0];
-        phi = ((uint64_t)o[3] << 32) | o[2];
+        pw0 = o[0]; pw1 = o[1]; pw2 = o[2]; pw3 = o[3];
       }
-      const uint64_t m = 0ull - (uint64_t)((w >> 1) & 1);
-      const uint32_t x = (uint32_t)(((plo & ~m) | (phi & m)) >> ((w & 1) << 5));
+      const uint32_t x = w == 0 ? pw0 : (w == 1 ? pw1 : (w == 2 ? pw2 : pw3));
       ++d;
       return __umulhi(x, nchoices);
     };
@@ -278,6 +438,9 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
         // and the token group are written ONCE and the step's kind only selects operands.  (With one copy per
         // kind, a wave whose lanes are in different kinds - nearly every step - runs every copy.)
         while (pos < lim) {
+#ifdef GTOK_PHASE_TIMING
+          ++iters;
+#endif
           const uint64_t row = rc.mask & ~vis;
           // 0: extend the trail over an uncovered edge (always towards an unvisited node); 1: dead end, restart from
           // a visited node that still owns uncovered edges; 2: another component or an isolated node
@@ -285,29 +448,28 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
           if (kind == 2 && nvis >= n) break;
           const uint64_t set = kind == 0 ? row : (kind == 1 ? live : (~vis & nodes));
           const int pick = kth_bit64(set, (int)below((uint32_t)__popcll(set)));
-          int et = 0;
-          if (LAB && kind == 0) et = find_et(rc, pick);       // type of the listed entry cur -> pick
+          uint32_t et = 0;
+          if (LAB && kind == 0) et = find_et(rc, (uint32_t)pick);   // type of the listed entry cur -> pick
           const Row rn = load_row(pick);
-          const int xb = snat[nbase + pick];                   // node type (first visit) or visit index (kind 1)
+          const uint32_t xb = snat[nbase + pick];              // node type (first visit) or visit index (kind 1)
           const bool first = kind != 1;
-          const int my = nvis;
+          const uint32_t my = (uint32_t)nvis;
           if (first) snat[nbase + pick] = (uint8_t)my;         // from now on this byte is the node's visit index
-          // ---- the step's token group: [edge type | RESET] position [node type]
+          // ---- the step's token group: [edge type | RESET] position [node type], 16 bits per token
           {
-            const uint64_t tpos = (uint64_t)(pos_base + (first ? my : xb));
-            uint64_t ta = T_RESET, val;
+            const uint32_t tpos = (uint32_t)pos_base + (first ? my : xb);
+            uint32_t ta = (uint32_t)T_RESET;
             bool has_a = kind == 1 || (kind == 2 && nvis > 0);   // (the walk's first node is a component start without RESET)
+            uint32_t lo = tpos, hi = 0;                          // token pair, then the third token
             int cnt = 1;
             if (LAB) {
-              if (kind == 0) { ta = (uint64_t)(remap ? remap_edge_type(et, edge_off) : edge_off + et); has_a = true; }
-              const uint64_t ty = (uint64_t)(remap ? remap_node_type(xb, node_off, a.p.num_node_types) : node_off + xb);
-              val = first ? (tpos | (ty << 16)) : tpos;
+              if (kind == 0) { ta = remap ? remap_edge_type_u(et, (uint32_t)edge_off) : (uint32_t)edge_off + et; has_a = true; }
+              const uint32_t ty = remap ? remap_node_type_u(xb, (uint32_t)node_off, (uint32_t)a.p.num_node_types) : (uint32_t)node_off + xb;
+              lo |= first ? ty << 16 : 0u;
               cnt += first;
-            } else {
-              val = tpos;
             }
-            if (has_a) { val = ta | (val << 16); ++cnt; }
-            append(val, cnt);
+            if (has_a) { hi = lo >> 16; lo = ta | (lo << 16); ++cnt; }
+            append(((uint64_t)hi << 32) | lo, cnt);
           }
           // ---- first visit: neighbours lose an unvisited neighbour; already visited neighbours other than the
           // trail's predecessor are this node's bracket
@@ -333,14 +495,15 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
                 if (vx < bv) { bv = vx; bu = u; }
               } while (t);
               M &= ~(1ull << bu);
-              uint64_t val = (uint64_t)(pos_base + bv);
+              uint32_t lo = (uint32_t)(pos_base + bv), hi = 0;
               int cnt = 1;
               if (LAB) {
-                const int at = find_et(rn, bu);
-                val = (uint64_t)(remap ? remap_edge_type(at, edge_off) : edge_off + at) | (val << 16);
+                const uint32_t at = find_et(rn, (uint32_t)bu);
+                lo = (remap ? remap_edge_type_u(at, (uint32_t)edge_off) : (uint32_t)edge_off + at) | (lo << 16);
                 cnt = 2;
               }
-              if (head) { val = T_LADJ | (val << 16); ++cnt; head = false; }
+              if (head) { hi = lo >> 16; lo = (uint32_t)T_LADJ | (lo << 16); ++cnt; head = false; }
+              uint64_t val = ((uint64_t)hi << 32) | lo;
               if (!M) { val |= T_RADJ << (cnt << 4); ++cnt; }
               append(val, cnt);
             } while (M);
@@ -351,6 +514,9 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
       }
       append(T_EOS, 1);
     }
+#ifdef GTOK_PHASE_TIMING
+    ts[3] = __builtin_amdgcn_s_memtime();
+#endif
     // ---- end of the row: what is still in the window, the query tail (trainer/train_agtt.py:257-267: after the
     // trail, original node ids, not remapped), and pad up to the next multiple of 4
     const int len = min(pos, lim);
@@ -360,48 +526,51 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
       q0 = idx_off + h.nfull; q1 = idx_off + a.p.query[2 * (int64_t)g]; q2 = idx_off + a.p.query[2 * (int64_t)g + 1];
       tot = len + 3;
     }
+    int padfrom = 0;                             // where the cooperative padding of this lane's row starts
     if (valid) {
       a.out_len[g] = tot;
-      const int stop = min(ld, (tot + 3) & ~3);
-      for (int i = min(fl, len); i < stop; ++i) {
-        int v = pad;
-        if (i < len) {
-          if (i < fl) continue;                  // already written by a window flush
-          v = (int)((wlo >> ((i - fl) << 4)) & 0xFFFFu);
-        } else if (i < tot) {
-          v = i == len ? q0 : (i == len + 1 ? q1 : q2);
+      const int sb = fl & ~(4 * SG - 1);         // [sb, fl): groups of the open burst, [fl, pos): the window
+      if (!a.p.query && pos <= cap && (ld & 3) == 0) {
+        // common case (row not cut, no query tail): the open burst, the window and the padding up to the next 16-token
+        // boundary leave as one run of 16-byte stores - the row's last 64-byte sector is written whole as well
+        const int s16 = fl & ~15;
+        padfrom = min(ld, (len + 15) & ~15);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int at = s16 + 4 * k;
+          if (at >= sb && at < padfrom) {
+            const uint64_t w = at == fl ? wlo : (at > fl ? 0ull : group_of((at - sb) >> 2, 0));
+            I32x4 v;
+            v.x = at + 0 < len ? tok_of(w, 0) : pad; v.y = at + 1 < len ? tok_of(w, 1) : pad;
+            v.z = at + 2 < len ? tok_of(w, 2) : pad; v.w = at + 3 < len ? tok_of(w, 3) : pad;
+            *reinterpret_cast<I32x4 *>(orow + at) = v;
+          }
         }
-        orow[i] = v;
+      } else {
+        padfrom = min(ld, (tot + 3) & ~3);
+        for (int i = min(sb, len); i < padfrom; ++i) {
+          int v = pad;
+          if (i < len) {
+            if (i < sb) continue;                // already written by a burst
+            v = tok_of(i >= fl ? wlo : group_of((i - sb) >> 2, 0), i & 3);
+          } else if (i < tot) {
+            v = i == len ? q0 : (i == len + 1 ? q1 : q2);
+          }
+          orow[i] = v;
+        }
       }
     }
 
-    // ---- next unit: the loads of its phase A go out ahead of this unit's padding stores
-    const int lw = valid ? min(ld, (tot + 3) & ~3) : 0, done_g0 = h.g0;
-    const int next = unit + stride;
-    const bool more = next < a.units;
-    RegsA ra;
-    if (more) { h = header(next); load_a(h, ra); }
-    // ---- pad the tails of the finished unit's 64 rows: four rows per pass, 16 lanes x 16-byte stores on each
-    {
-      const int q = lane & 15;
-      for (int it = 0; it < 16; ++it) {
-        const int r = it * 4 + (lane >> 4);
-        const int lr = __builtin_amdgcn_ds_bpermute(r << 2, lw);
-        if (done_g0 + it * 4 >= G) break;
-        if (done_g0 + r < G) {
-          int32_t *__restrict__ rowp = a.out + (int64_t)(done_g0 + r) * ld + lr;
-          const int nrem = ld - lr, nvec = nrem >> 2;
-          for (int t = q; t < nvec; t += 16) reinterpret_cast<I32x4 *>(rowp)[t] = I32x4{pad, pad, pad, pad};
-          if (q < (nrem & 3)) rowp[(nvec << 2) + q] = pad;
-        }
-      }
-    }
-    if (!more) break;
-    unit = next;
-    __builtin_amdgcn_wave_barrier();
-    commit_a(h, ra);
-    stage_b(h);
+    lw = padfrom;
+    done_g0 = h.g0;
+#ifdef GTOK_PHASE_TIMING
+    ts[4] = __builtin_amdgcn_s_memtime();
+#endif
   }
+  if (done_g0 >= 0) pad_rows();
+#ifdef GTOK_PHASE_TIMING
+  stamps_out();
+#endif
 }
 
 }  // namespace gtok

@@ -68,6 +68,16 @@ __device__ __forceinline__ int remap_node_type(int x, int node_off, int ntypes) 
 // ... and to edge-type tokens (t = edge_off + at >= edge_off): bond 17+at if at < 4 else 22+t
 __device__ __forceinline__ int remap_edge_type(int at, int edge_off) { return at < 4 ? 17 + at : 22 + edge_off + at; }
 
+// unsigned forms (token fields are packed with 32-bit operations; a signed int would be sign-extended first)
+__device__ __forceinline__ uint32_t remap_node_type_u(uint32_t x, uint32_t node_off, uint32_t ntypes) {
+  const uint32_t b = x - ntypes;
+  uint32_t r = 22u + node_off + x;
+  r = (x < ntypes && x < 9u) ? 8u + x : r;
+  r = (x >= ntypes && b < 4u) ? 17u + b : r;
+  return r;
+}
+__device__ __forceinline__ uint32_t remap_edge_type_u(uint32_t at, uint32_t edge_off) { return at < 4u ? 17u + at : 22u + edge_off + at; }
+
 // How much a single walk iteration can append past `lim`: edge + position + type + LADJ + 64 x 2 + RADJ,
 // plus RESET/position and EOS, plus the 63 junk slots an unpredicated store touches.  The token buffer is sized min(lim, bound) + kSentSlack, so no store in the
 // walk needs a bounds check.

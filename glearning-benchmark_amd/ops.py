@@ -5,6 +5,7 @@ kernels are enqueued on.  Every function raises if libgtok.so is missing or
 the tensors are not on a GPU — there is no CPU path in the product.
 """
 import ctypes
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -105,7 +106,29 @@ def sent_safe_ld(batch: GraphBatch, labeled: bool, max_len: int, with_query: boo
     """Width no SENT row of this batch can exceed (length bound)."""
     n, e = batch.max_nodes, batch.max_edges
     bound = (2 + 7 * n + 2 * e) if labeled else (2 + 5 * n + e)
-    return _round4(min(max_len, bound) + (3 if with_query else 0))
+    # a multiple of 16 ids: every row then starts on a 64-byte boundary and the kernels' 64-byte store bursts are whole
+    return (min(max_len, bound) + (3 if with_query else 0) + 15) // 16 * 16
+
+
+def pack8(batch: GraphBatch) -> bool:
+    """Give a device batch of small graphs its byte-packed rowptr / col mirror (gtok_csr_pack8; once per batch,
+    kept on the batch object).  Returns whether the batch has one now.  A layout step like the CSR build: the
+    lane-per-graph SENT kernel reads the mirror instead of the int32 arrays."""
+    if batch.rowptr8 is not None:
+        return True
+    if os.environ.get("GTOK_NO_PACK8") == "1":      # tests: the lane kernel's int32 staging path (C-ABI callers without a mirror)
+        return False
+    if batch.col.device.type != "cuda" or batch.num_graphs == 0 or batch.max_edges > 255 or batch.max_nodes > 64 \
+            or not (batch.flags & _lib.CSR_SIMPLE_SYMMETRIC):
+        return False
+    dev = batch.device
+    r8 = torch.empty(batch.rowptr.numel() + 16, dtype=torch.uint8, device=dev)   # + slack: 16-byte vector loads of the
+    c8 = torch.empty(batch.col.numel() + 16, dtype=torch.uint8, device=dev)      # last chunk may run past the end
+    cs = batch.c_struct()
+    check(lib().gtok_csr_pack8(ctypes.byref(cs), batch.rowptr.numel(), batch.col.numel(), r8.data_ptr(), c8.data_ptr(),
+                               _stream(dev)), "gtok_csr_pack8")
+    batch.rowptr8, batch.col8 = r8, c8
+    return True
 
 
 def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: int = 0, labeled: bool = False,
@@ -122,6 +145,7 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
     if ld is None:
         ld = sent_safe_ld(batch, labeled, max_len, query is not None)
     ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
+    pack8(batch)
     p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc),
                        pad_id, 0, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
                        None if query is None else query.data_ptr())

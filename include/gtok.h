@@ -23,6 +23,7 @@
  *                      (gather rows of a batch, pad to the batch max, bool mask)
  *   gtok_parse_graph_text  graph_token_dataset_autograph.py:14-158 (text -> edges, query, label)
  *   gtok_find_token    the `<q>` search of trainer/train_ibtt.py:88-103 on a collated batch
+ *   gtok_csr_pack8     (no reference counterpart) byte-packed mirror of the CSR index arrays of small-graph batches
  *   gtok_vocab_stats_synth  the corpus pass of build_vocab_from_texts
  *                      (data_loader.py:451-463) for graph-token corpora held as
  *                      CSR: per node-id token, occurrence count and first position
@@ -94,6 +95,11 @@ typedef struct gtok_csr {
   int32_t chunk_edges; /* same for sum E_g                                                                      */
   int32_t max_degree;  /* longest CSR row of the batch (upper bound accepted); 0 = unknown                       */
   int32_t reserved;    /* must be 0                                                                              */
+  /* Byte-packed mirror of rowptr / col for batches of small graphs (max_edges <= 255, max_nodes <= 256), written
+   * once per resident batch by gtok_csr_pack8 (same indexing as the int32 arrays); NULL = absent.  The
+   * lane-per-graph SENT kernel stages its 64-graph chunks from these (a quarter of the index bytes).            */
+  const uint8_t *rowptr8;
+  const uint8_t *col8;
 } gtok_csr;
 
 /* LUT layout for gtok_ibtt_zinc (int32 vocab ids; an absent token holds pad_id
@@ -112,6 +118,11 @@ typedef struct gtok_csr {
 #define GTOK_ZLUT_ATOM0 7
 #define GTOK_ZLUT_BOND0 17
 #define GTOK_ZLUT_NODE0 22
+
+/* rowptr8[i] = (uint8_t)rowptr[i], col8[i] = (uint8_t)col[i] for the whole batch (sum N + G and sum E elements).
+ * GTOK_E_TOO_LARGE when max_edges > 255 or max_nodes > 256 (values would not fit).  No reference counterpart: a
+ * data-layout step, done once when a batch becomes resident, like the CSR build itself.                       */
+int gtok_csr_pack8(const gtok_csr *g, int64_t num_rowptr, int64_t num_col, uint8_t *rowptr8, uint8_t *col8, void *stream);
 
 /* IBTT molecular serialiser -> ids.
  * lut_len = 22 + number of node-index entries (must cover max_nodes).      */

@@ -1,6 +1,10 @@
 """Per-phase cycle counts of sent_lane_kernel on the ZINC-shaped corpus.  Needs a library built with
--DGTOK_PHASE_TIMING (profiling build: the last 4 columns of every unit's first row hold s_memtime deltas for
-staging / rem[] init / walk / tail padding).  Never ship that build."""
+-DGTOK_PHASE_TIMING and loaded through GTOK_LIB (profiling build: the last 8 columns of every unit's first row hold
+s_memtime deltas for staging / counter init / walk / row end, the wave's start and end on the 100 MHz real-time
+clock, the walk's iteration count and the workgroup id).  Never ship that build.
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DGTOK_PHASE_TIMING -Iinclude \
+        -o glearning-benchmark_amd/csrc/libgtok_prof.so glearning-benchmark_amd/csrc/gtok_sent.hip glearning-benchmark_amd/csrc/gtok_ibtt.hip
+    GTOK_LIB=glearning-benchmark_amd/csrc/libgtok_prof.so python profiles/tools/phase_timing_lane.py"""
 import importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,15 +20,18 @@ kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
 for k in range(3):
     ids, ln = gtok.ops.sent(b, 37, 1024, 0, k, ld=ld, **kw)
 torch.cuda.synchronize()
-assert int(ln.max()) <= ld - 4
-ph = ids[::64, -4:].double()
-names = ["staging", "rem init", "walk", "tail padding"]
-tot = ph.sum()
+assert int(ln.max()) <= ld - 8
+ph = ids[::64, -8:].cpu().numpy().astype(np.int64)
+names = ["staging", "counter init", "walk", "row end"]
+tot = ph[:, :4].sum()
 for i, nme in enumerate(names):
-    print(f"{nme:14s} mean {float(ph[:, i].mean()):10.0f} cycles  max {float(ph[:, i].max()):10.0f}  share {float(ph[:, i].sum() / tot):.3f}")
-print("mean cycles per unit", float(ph.sum(1).mean()))
-nmax = torch.from_numpy(np.pad(d["node_counts"], (0, (-G) % 64)).reshape(-1, 64).max(1)).double()
-w = ph[:, 2].cpu()
-for lo, hi in ((0, 30), (30, 33), (33, 36), (36, 99)):
-    m = (nmax >= lo) & (nmax < hi)
-    if m.any(): print(f"units with max nodes in [{lo},{hi}): {int(m.sum()):5d}  mean walk cycles {float(w[m].mean()):9.0f}")
+    print(f"{nme:14s} mean {ph[:, i].mean():10.0f} cycles  max {ph[:, i].max():10.0f}  share {ph[:, i].sum() / tot:.3f}")
+print("mean cycles per unit", ph[:, :4].sum(1).mean(), " iterations mean", ph[:, 6].mean(), "max", ph[:, 6].max(),
+      " walk cycles per iteration", ph[:, 2].sum() / ph[:, 6].sum())
+rt0 = (ph[:, 4] & 0xFFFFFFFF); rt1 = (ph[:, 5] & 0xFFFFFFFF)
+base = rt0.min()
+s0, s1 = (rt0 - base) / 100.0, (rt1 - base) / 100.0          # us on the 100 MHz clock
+q = lambda a: " ".join(f"{np.percentile(a, p):7.1f}" for p in (0, 10, 50, 90, 100))
+print("wave start us (min p10 p50 p90 max):", q(s0))
+print("wave end   us (min p10 p50 p90 max):", q(s1))
+print("wave life  us (min p10 p50 p90 max):", q(s1 - s0))

@@ -11,7 +11,7 @@ for labeled in (True, False):
     host = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"],
                                     d["x"] if labeled else None, d["edge_attr"] if labeled else None)
     b = host.to(dev)
-    ld = 200 if labeled else 120
+    ld = 208 if labeled else 128
     ids = torch.empty((G, ld), dtype=torch.int32, device=dev); ln = torch.empty(G, dtype=torch.int32, device=dev)
     kw = dict(labeled=labeled, num_node_types=9 if labeled else 0, num_edge_types=4 if labeled else 0, remap_zinc=labeled)
     for _ in range(3):

@@ -167,11 +167,21 @@ def test_collate():
         assert np.array_equal(X.cpu().numpy(), rX) and np.array_equal(A.cpu().numpy(), rA)
 
 
-@pytest.mark.parametrize("pin", ["lane", "reg", "lds"])
+def _pin_sent(monkeypatch, pin):
+    """GTOK_SENT_KERNEL pin; "lane-int32" = the lane kernel staging from the int32 CSR (no byte-packed mirror)."""
+    monkeypatch.setenv("GTOK_SENT_KERNEL", pin.split("-")[0])
+    if pin == "lane-int32":
+        monkeypatch.setenv("GTOK_NO_PACK8", "1")
+    else:
+        monkeypatch.delenv("GTOK_NO_PACK8", raising=False)
+
+
+@pytest.mark.parametrize("pin", ["lane", "lane-int32", "reg", "lds"])
 def test_sent_every_kernel_same_tokens(pin, monkeypatch):
-    """Three kernels implement the one SENT spec (lane-per-graph, register-resident wave-per-graph, LDS bit
-    matrix); GTOK_SENT_KERNEL pins one per call.  Each must reproduce the oracle on graphs they all accept."""
-    monkeypatch.setenv("GTOK_SENT_KERNEL", pin)
+    """Three kernels implement the one SENT spec (lane-per-graph - staged from the byte-packed mirror or from the
+    int32 CSR -, register-resident wave-per-graph, LDS bit matrix); GTOK_SENT_KERNEL pins one per call.  Each must
+    reproduce the oracle on graphs they all accept."""
+    _pin_sent(monkeypatch, pin)
     cases = [(gtok.synth.zinc_like(3000, seed=61), True, 37, dict(remap_zinc=True, num_node_types=9, num_edge_types=4)),
              (gtok.synth.zinc_like(800, seed=62, coalesced=False), True, 37, dict(num_node_types=28, num_edge_types=5)),
              (gtok.synth.zinc_like(1500, seed=63), False, 40, {}),
@@ -417,9 +427,9 @@ def test_sent_at_the_size_boundaries_of_the_kernels(top, monkeypatch):
     d = _rings_with_chords(sizes, chords, seed=top)
     batch, coo = both(d)
     assert batch.flags & 1
-    pins = ["lane", "reg", "lds"] if top <= 64 else ["lds"]
+    pins = ["lane", "lane-int32", "reg", "lds"] if top <= 64 else ["lds"]
     for pin in pins:
-        monkeypatch.setenv("GTOK_SENT_KERNEL", pin)
+        _pin_sent(monkeypatch, pin)
         for labeled in (True, False):
             b2, c2 = both(d, labeled)
             kw = dict(labeled=labeled, num_node_types=28 if labeled else 0, num_edge_types=5 if labeled else 0)
