@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--graphs", type=int, default=None, help="graphs per rank (default: the workload's size)")
     ap.add_argument("--ld", default="tight", choices=["tight", "safe"],
                     help="slab width: measured max length + margin (verified after the run) or the a-priori bound")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank tokenizes its own ZINC-full-sized corpus (headline; no data-path collective). "
+                         "strong: one corpus block-sharded over the ranks + all-gather (BASELINE config 4) becomes the headline; "
+                         "multi-rank runs report it beside the weak line either way")
     ap.add_argument("--cpu-sample", type=int, default=None, help="graphs in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ibtt", action="store_true")
@@ -275,19 +279,60 @@ def main():
 
     # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
     if multi:
-        gtok.dist.gather_tokens(ids, lens[-1], world * G, 5)
+        gtok.dist.gather_tokens(ids, lens[-1], world * G, 5, force=True)
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            gtok.dist.gather_tokens(ids, lens[-1], world * G, 5)
+            gtok.dist.gather_tokens(ids, lens[-1], world * G, 5, force=True)
         torch.cuda.synchronize(); dist.barrier()
         ag = (time.perf_counter() - t0) / reps
         agt = torch.tensor([ag], dtype=torch.float64, device=dev)
         dist.all_reduce(agt, op=dist.ReduceOp.MAX)
         recv = (world - 1) * G * (ld + 1) * 4
         out["allgather"] = dict(ms=round(float(agt.item()) * 1e3, 3), bytes_received_per_gpu=recv,
-                                GBps_per_gpu=round(recv / float(agt.item()) / 1e9, 2))
+                                bytes_gathered_per_gpu=world * G * (ld + 1) * 4,
+                                GBps_per_gpu=round(world * G * (ld + 1) * 4 / float(agt.item()) / 1e9, 2))
+
+    # BASELINE config 4 as configured: ONE ZINC-full corpus block-sharded over the ranks (strong scaling), each rank
+    # tokenizes its block with graph_base = the block's first global index, one all-gather reassembles the padded slab
+    # on every rank.  Reported beside the weak-scaling line above (the driver computes efficiency from `value`).
+    if multi and zinc and (args.scaling == "strong" or os.environ.get("GTOK_BENCH_STRONG", "1") == "1"):
+        Gt = args.graphs or wl["graphs"]
+        dc = gtok.synth.zinc_like(Gt, seed=1000)                      # the same corpus on every rank
+        whole = gtok.GraphBatch.from_coo_device(dc["node_counts"], dc["edge_counts"], dc["src"], dc["dst"], dc["x"], dc["edge_attr"], device=dev)
+        mine, lo, hi = gtok.dist.shard_of(whole, rank, world)
+        del whole
+        gtok.ops.pack8(mine)
+        kws = dict(kw, graph_base=lo)
+        sids = torch.empty((hi - lo, ld), dtype=torch.int32, device=dev)
+        sln = torch.empty((hi - lo,), dtype=torch.int32, device=dev)
+
+        def sstep(k, gather):
+            gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(sids, sln), **kws)
+            if gather:
+                return gtok.dist.gather_tokens(sids, sln, Gt, 5, force=True)
+        res = {}
+        for gather in (False, True):
+            for w in range(args.warmup):
+                sstep(w, gather)
+            swall, _ = timed_loop(lambda k: sstep(args.warmup + k, gather), args.steps, True)
+            tm = torch.tensor([swall], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            res[gather] = float(tm.item())
+        if int(sln.max().item()) > ld:
+            raise SystemExit("strong-scaling leg: slab too narrow")
+        out["strong_scaling"] = dict(
+            workload=f"one {Gt}-graph corpus block-sharded x{world} (graphs_per_gpu {hi - lo}), kernel {gtok.ops.sent_kernel_name(mine, max_nodes, max_len, labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True)}",
+            tokenize_graphs_per_sec=round(Gt * args.steps / res[False], 1), tokenize_ms_per_step=round(res[False] / args.steps * 1e3, 4),
+            tokenize_and_allgather_graphs_per_sec=round(Gt * args.steps / res[True], 1),
+            tokenize_and_allgather_ms_per_step=round(res[True] / args.steps * 1e3, 4),
+            gathered_slab_bytes=int(Gt) * (ld + 1) * 4)
+        if args.scaling == "strong":      # make the configured workload the headline of this run
+            out.update(value=out["strong_scaling"]["tokenize_and_allgather_graphs_per_sec"], scaling="strong",
+                       ms_per_step=out["strong_scaling"]["tokenize_and_allgather_ms_per_step"])
+            out["config"]["parallelism"] = f"one corpus block-sharded x{world} + RCCL all-gather of the padded slab"
+            out["config"]["graphs_per_gpu"] = hi - lo
 
     # CPU baseline: the oracle (a port, not the reference's Python) on a bounded sample, rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -101,18 +101,24 @@ class GraphBatch:
         return b
 
     def shard(self, lo: int, hi: int) -> "GraphBatch":
-        """Graphs [lo, hi) as their own batch (contiguous block sharding, host tensors only)."""
-        assert self.col.device.type == "cpu"
+        """Graphs [lo, hi) as their own batch (contiguous block sharding); works on host and device batches and
+        stays on the batch's device.  Tokenize it with graph_base=lo to get the rows the whole batch would give."""
         n0, n1 = int(self.node_ptr[lo]), int(self.node_ptr[hi])
         e0, e1 = int(self.edge_ptr[lo]), int(self.edge_ptr[hi])
         sl = lambda t, a, b: None if t is None else t[a:b].clone()
         nc = (self.node_ptr[lo + 1:hi + 1] - self.node_ptr[lo:hi])
         ec = (self.edge_ptr[lo + 1:hi + 1] - self.edge_ptr[lo:hi])
-        cn, ce = _chunk_max(nc.numpy()), _chunk_max(ec.numpy())
+
+        def chunk_max(c):
+            if c.numel() == 0:
+                return 0
+            pad = (-c.numel()) % 64
+            return int(torch.nn.functional.pad(c.to(torch.int64), (0, pad)).reshape(-1, 64).sum(1).max())
         return GraphBatch(hi - lo, int(nc.max()) if hi > lo else 0, int(ec.max()) if hi > lo else 0,
                           (self.node_ptr[lo:hi + 1] - n0).clone(), (self.edge_ptr[lo:hi + 1] - e0).clone(),
                           sl(self.rowptr, n0 + lo, n1 + hi), sl(self.col, e0, e1), sl(self.eorder, e0, e1),
-                          sl(self.nattr, n0, n1), sl(self.eattr, e0, e1), self.flags, cn, ce, self.max_degree)
+                          sl(self.nattr, n0, n1), sl(self.eattr, e0, e1), self.flags, chunk_max(nc), chunk_max(ec),
+                          self.max_degree)
 
     # ------------------------------------------------------------------ builders
     @staticmethod

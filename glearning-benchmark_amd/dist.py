@@ -27,12 +27,23 @@ def all_reduce_max_int(value: int, device) -> int:
     return int(t.item())
 
 
-def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: int):
+def shard_of(batch, rank: int = None, world: int = None):
+    """(this rank's block of `batch` as its own GraphBatch, lo, hi): tokenize it with graph_base=lo."""
+    if world is None:
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if rank is None:
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    lo, hi = block_bounds(batch.num_graphs, world)[rank]
+    return batch.shard(lo, hi), lo, hi
+
+
+def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: int, force: bool = False):
     """All-gather the per-rank [G_local, ld] slabs + lengths into the full [G, ld] slab on every rank.
 
     Ranks hold blocks from block_bounds(); the last blocks may be short, so every rank pads its
-    block to ceil(G/P) rows first (one fixed-size all_gather_into_tensor, no size exchange)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    block to ceil(G/P) rows first (one fixed-size all_gather_into_tensor, no size exchange).
+    force: issue the collective even in a one-rank group (rehearsal of the N>1 path on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return ids, ln
     world = dist.get_world_size()
     per = -(-num_graphs // world)

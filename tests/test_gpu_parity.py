@@ -1,6 +1,7 @@
 """GPU parity: every HIP entry point, called through the C ABI, against the CPU oracle — bit-exact
 (integer work).  Sizes are what the oracle finishes in seconds; corpus-scale properties live in
 test_gpu_properties.py."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -603,3 +604,43 @@ def test_sent_decode_kernel_equals_the_oracle_decoder():
     for k in ("num_nodes", "num_edges", "status"):
         assert np.array_equal(got[k].cpu().numpy(), want[k]), k
     assert (want["status"] != 0).mean() > 0.3
+
+
+def test_shard_on_device_then_gather_over_rccl_equals_unsharded():
+    """BASELINE config 4 on one GPU: a device-resident corpus is block-sharded ON the device (GraphBatch.shard),
+    each block tokenized with graph_base = its first global index, and the blocks are reassembled by
+    dist.gather_tokens - run through a real one-rank `nccl` (RCCL) group with force=True, so the collective the
+    multi-GPU runs rely on has executed on hardware.  Result == the unsharded slab == the oracle."""
+    import socket
+    import torch.distributed as tdist
+    d = gtok.synth.zinc_like(30000, seed=91)          # above the lane kernel's threshold: both kernels get exercised
+    batch, coo = both(d)
+    dev_batch = batch.to(DEV)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ld = gtok.ops.sent_safe_ld(batch, True, 1024)
+    whole_ids, whole_ln = gtok.ops.sent(dev_batch, 37, 1024, 21, 3, ld=ld, **kw)
+    ref, rln = orc.sent(coo, 37, 1024, 21, 3, ld=ld, nthreads=8, **kw)
+    _cmp(whole_ids, whole_ln, ref, rln, "unsharded")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        # one rank: its block is the whole corpus, the gather is a real (single-rank) RCCL all_gather_into_tensor
+        mine, lo, hi = gtok.dist.shard_of(dev_batch)
+        assert (lo, hi) == (0, 30000) and mine.col.is_cuda
+        ids, ln = gtok.ops.sent(mine, 37, 1024, 21, 3, ld=ld, graph_base=lo, **kw)
+        g_ids, g_ln = gtok.dist.gather_tokens(ids, ln, 30000, 5, force=True)
+        assert g_ids.data_ptr() != ids.data_ptr()           # went through the collective, not the early return
+        assert torch.equal(g_ids, whole_ids) and torch.equal(g_ln, whole_ln)
+        # the 4-rank layout rehearsed on one device: every rank's block tokenized on its own, blocks laid out as the
+        # gather lays them out (padded to ceil(G/P) rows)
+        world, per = 4, -(-30000 // 4)
+        parts_i, parts_l = [], []
+        for r in range(world):
+            blk, lo, hi = gtok.dist.shard_of(dev_batch, r, world)
+            assert blk.col.is_cuda and blk.num_graphs == hi - lo
+            i_r, l_r = gtok.ops.sent(blk, 37, 1024, 21, 3, ld=ld, graph_base=lo, **kw)
+            parts_i.append(i_r); parts_l.append(l_r)
+        assert torch.equal(torch.cat(parts_i), whole_ids) and torch.equal(torch.cat(parts_l), whole_ln)
+    finally:
+        tdist.destroy_process_group()
