@@ -126,27 +126,90 @@ struct Tickets {
   }
 };
 
-// Ticket counters of the dynamically scheduled kernels: a per-device ring of slots (kQueues counters + one
-// retired-wave counter each), zeroed once when the device is first used.  A launch takes the next slot and its last wave re-arms it, so a
-// slot is clean again when its launch has drained; kSlots launches may be in flight at once (any streams).
-// The first call on a device allocates (not capturable in a hipGraph: warm up once before capturing).
-inline int *take_queue_slot(int dev) {
-  constexpr int kSlots = 256, kMaxDev = 64, kSlotInts = (2 * kQueues + 1) * kQueueStride;
-  static std::mutex mu;
-  static int *ring[kMaxDev] = {};
-  static std::atomic<unsigned> seq{0};
-  if (dev < 0 || dev >= kMaxDev) return nullptr;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!ring[dev]) {
-      int *p = nullptr;
-      if (hipMalloc(reinterpret_cast<void **>(&p), kSlots * kSlotInts * sizeof(int)) != hipSuccess) return nullptr;
-      if (hipMemset(p, 0, kSlots * kSlotInts * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
-      ring[dev] = p;
-    }
+// Ticket counters of the dynamically scheduled kernels: a per-device ring of slots (kQueues counters + the retire
+// counters each), zeroed once when the device is first used.  A launch takes the next slot and its last wave re-arms
+// it, so a slot is clean again when its launch has drained.  A slot is only handed out again once the launch that
+// used it last has FINISHED: every slot carries a HIP event recorded behind its launch, and take_queue_slot waits for
+// that event when the ring has wrapped onto a launch still in flight (256+ launches queued without a
+// synchronisation) - two live launches never share counters.  Launches issued while the stream is being CAPTURED
+// into a hipGraph get a slot of their own from a reserved pool that is never recycled (a replay must find the
+// counters it was captured with, and event queries are not capturable): at most kGraphSlots captured launches per
+// device.  The first call on a device allocates (not capturable: warm up once before capturing).
+struct QueueSlot {
+  int *counters = nullptr;
+  int index = -1;       // ring index, -1: reserved (captured) slot - nothing to record
+  int dev = 0;
+};
+constexpr int kSlots = 256, kGraphSlots = 64, kMaxDev = 64, kSlotInts = (2 * kQueues + 1) * kQueueStride;
+struct QueueRing {
+  std::mutex mu;
+  int *mem[kMaxDev] = {};
+  hipEvent_t ev[kMaxDev][kSlots] = {};
+  bool used[kMaxDev][kSlots] = {};
+  unsigned seq[kMaxDev] = {};
+  int graph_taken[kMaxDev] = {};
+};
+inline QueueRing &queue_ring() { static QueueRing r; return r; }
+
+inline QueueSlot take_queue_slot(int dev, hipStream_t stream) {
+  QueueSlot out;
+  if (dev < 0 || dev >= kMaxDev) return out;
+  QueueRing &r = queue_ring();
+  std::lock_guard<std::mutex> lock(r.mu);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  if (!r.mem[dev]) {
+    if (cap != hipStreamCaptureStatusNone) return out;                    // cannot allocate inside a capture
+    int *p = nullptr;
+    const size_t bytes = (size_t)(kSlots + kGraphSlots) * kSlotInts * sizeof(int);
+    if (hipMalloc(reinterpret_cast<void **>(&p), bytes) != hipSuccess) return out;
+    if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return out; }
+    r.mem[dev] = p;
   }
-  return ring[dev] + (size_t)kSlotInts * (seq.fetch_add(1, std::memory_order_relaxed) % kSlots);
+  out.dev = dev;
+  if (cap != hipStreamCaptureStatusNone) {
+    if (r.graph_taken[dev] >= kGraphSlots) return out;
+    out.counters = r.mem[dev] + (size_t)kSlotInts * (kSlots + r.graph_taken[dev]++);
+    return out;
+  }
+  const int i = (int)(r.seq[dev]++ % kSlots);
+  if (r.used[dev][i]) {
+    if (hipEventQuery(r.ev[dev][i]) != hipSuccess) {      // still in flight (or unknown): wait for that launch
+      (void)hipGetLastError();
+      if (hipEventSynchronize(r.ev[dev][i]) != hipSuccess) { (void)hipGetLastError(); return out; }
+    }
+  } else if (!r.ev[dev][i]) {
+    if (hipEventCreateWithFlags(&r.ev[dev][i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return out; }
+  }
+  out.counters = r.mem[dev] + (size_t)kSlotInts * i;
+  out.index = i;
+  return out;
 }
+// behind the launch that uses the slot, on the launch's stream
+inline void mark_queue_slot(const QueueSlot &q, hipStream_t stream) {
+  if (q.index < 0 || !q.counters) return;
+  QueueRing &r = queue_ring();
+  std::lock_guard<std::mutex> lock(r.mu);
+  r.used[q.dev][q.index] = hipEventRecord(r.ev[q.dev][q.index], stream) == hipSuccess;
+}
+
+// The device a launch belongs to is the STREAM's, not the calling thread's current device (a batch on cuda:1 launched
+// while cuda:0 is current would otherwise get cuda:0's counters and occupancy): DeviceScope makes it current for the
+// duration of the call and restores the caller's device afterwards.  ok() is false when no device could be determined.
+struct DeviceScope {
+  int dev = -1, prev = -1;
+  explicit DeviceScope(hipStream_t stream) {
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; return; }
+    dev = prev;
+    if (stream) {
+      int sd = -1;
+      if (hipStreamGetDevice(stream, &sd) == hipSuccess && sd >= 0) dev = sd; else (void)hipGetLastError();
+    }
+    if (dev != prev && hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+  }
+  ~DeviceScope() { if (prev >= 0 && dev >= 0 && dev != prev) (void)hipSetDevice(prev); }
+  bool ok() const { return dev >= 0; }
+};
 __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }

@@ -1237,6 +1237,8 @@ extern "C" const char *gtok_ibtt_zinc_kernel_name(const gtok_csr *g) {
 extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut_len, int32_t max_len,
                               int32_t pad_id, int32_t *out_ids, int32_t ld, int32_t *out_len,
                               void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (!g || g->num_graphs < 0 || max_len < 0 || ld <= 0) return GTOK_E_INVAL;
   if (g->num_graphs == 0) return GTOK_OK;   // an empty batch is a no-op
   if (!csr_ok(g) || !lut || lut_len < GTOK_ZLUT_NODE0 || !out_ids || !out_len) return GTOK_E_INVAL;
@@ -1303,10 +1305,12 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
         z.units = (g->num_graphs + 63) / 64;
         int nb = ncu * occ;
         if (nb > z.units) nb = z.units;
-        z.queue = gtok::take_queue_slot(dev);
+        const gtok::QueueSlot slot = gtok::take_queue_slot(dev, (hipStream_t)stream);
+        z.queue = slot.counters;
         if (!z.queue) return GTOK_E_LAUNCH;
         z.out = out_ids; z.ld = ld; z.out_len = out_len;
         hipLaunchKernelGGL(ibtt_zinc_lane_kernel, dim3(nb), dim3(64), (size_t)z.lds, (hipStream_t)stream, z);
+        gtok::mark_queue_slot(slot, (hipStream_t)stream);
         return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
       }
     }
@@ -1347,6 +1351,8 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
 extern "C" int gtok_ibtt_synth(const gtok_csr *g, const int32_t *lut, int32_t lut_len,
                                const int32_t *query, int32_t max_len, int32_t pad_id,
                                int32_t *out_ids, int32_t ld, int32_t *out_len, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (!g || g->num_graphs < 0 || max_len < 0 || ld <= 0) return GTOK_E_INVAL;
   if (g->num_graphs == 0) return GTOK_OK;
   if (!csr_ok(g) || !lut || lut_len < GTOK_SLUT_NODE0 || !out_ids || !out_len) return GTOK_E_INVAL;
@@ -1379,6 +1385,8 @@ extern "C" int gtok_ibtt_synth(const gtok_csr *g, const int32_t *lut, int32_t lu
 
 extern "C" int gtok_vocab_stats_synth(const gtok_csr *g, const int32_t *query_nodes, int64_t graph_base,
                                       int32_t num_ids, int64_t *count, int64_t *first, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (!g || g->num_graphs < 0 || num_ids <= 0) return GTOK_E_INVAL;
   if (g->num_graphs == 0) return GTOK_OK;
   if (!csr_ok(g) || !count || !first) return GTOK_E_INVAL;
@@ -1399,6 +1407,8 @@ extern "C" int gtok_vocab_stats_synth(const gtok_csr *g, const int32_t *query_no
 extern "C" int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts,
                                 const gtok_vocab_table *vocab, int32_t strip_label, int32_t max_len,
                                 int32_t *out_ids, int32_t ld, int32_t *out_len, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (!vocab || num_texts < 0 || max_len < 0 || ld <= 0) return GTOK_E_INVAL;
   if (vocab->capacity <= 0 || (vocab->capacity & (vocab->capacity - 1)) || !vocab->key_off ||
       !vocab->key_len || !vocab->id || !vocab->key_bytes)
@@ -1435,6 +1445,8 @@ extern "C" int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr, i
 extern "C" int gtok_remap_zinc(const int32_t *in_ids, int32_t *out_ids, int32_t ld, const int32_t *len,
                                int32_t num_rows, int32_t idx_offset, int32_t node_idx_offset,
                                int32_t edge_idx_offset, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (!in_ids || !out_ids || !len || ld <= 0 || num_rows < 0) return GTOK_E_INVAL;
   if (num_rows == 0) return GTOK_OK;
   const int64_t total = (int64_t)num_rows * ld;
@@ -1448,6 +1460,8 @@ extern "C" int gtok_remap_zinc(const int32_t *in_ids, int32_t *out_ids, int32_t 
 extern "C" int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len, const int64_t *index,
                             int32_t batch, int32_t pad_id, int64_t *out_x, uint8_t *out_attn,
                             int32_t out_ld, int32_t *batch_max, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (!ids || !len || !index || ld <= 0 || batch < 0 || out_ld < 0) return GTOK_E_INVAL;
   if (batch == 0) return GTOK_OK;
   if (batch_max)
@@ -1464,6 +1478,8 @@ extern "C" int gtok_parse_graph_text(const uint8_t *bytes, const int64_t *text_p
                                      const int64_t *edge_ptr, int32_t *src, int32_t *dst, int32_t *num_edges,
                                      int32_t *num_nodes, int32_t *query_nodes, int32_t *label, int32_t *status,
                                      void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (num_texts < 0) return GTOK_E_INVAL;
   if (num_texts == 0) return GTOK_OK;
   if (!bytes || !text_ptr || !num_edges || !num_nodes || !query_nodes || !label || !status) return GTOK_E_INVAL;
@@ -1478,6 +1494,8 @@ extern "C" int gtok_parse_graph_text(const uint8_t *bytes, const int64_t *text_p
 }
 
 extern "C" int gtok_find_token(const int64_t *x, int32_t rows, int32_t ld, int64_t token, int32_t *pos, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (rows < 0 || ld < 0) return GTOK_E_INVAL;
   if (rows == 0) return GTOK_OK;
   if (!pos || (ld > 0 && !x)) return GTOK_E_INVAL;

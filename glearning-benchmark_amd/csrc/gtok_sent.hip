@@ -53,6 +53,8 @@ using namespace gtok;
 
 extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids,
                          int32_t ld, int32_t *out_len, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (!g || !p || ld <= 0 || g->num_graphs < 0) return GTOK_E_INVAL;
   if (g->num_graphs == 0) return GTOK_OK;   // an empty batch is a no-op
   if (!out_ids || !out_len) return GTOK_E_INVAL;
@@ -185,6 +187,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
                                                    wpb * 64, lds) != hipSuccess || occ < 1)
     occ = 1;
   a.queue = nullptr;
+  QueueSlot slot;
   int nb;
   if (reg_path) {
     occ = gtok::resident_blocks(occ);
@@ -198,10 +201,12 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.units = g->num_graphs; a.upb = 0;
     nb = ncu * occ;
     if (nb > a.units) nb = a.units;
-    a.queue = take_queue_slot(dev);
+    slot = take_queue_slot(dev, (hipStream_t)stream);
+    a.queue = slot.counters;
     if (!a.queue) return GTOK_E_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
+  mark_queue_slot(slot, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 
@@ -219,6 +224,8 @@ __global__ void __launch_bounds__(256) csr_pack8_kernel(const int32_t *__restric
 }
 
 extern "C" int gtok_csr_pack8(const gtok_csr *g, int64_t num_rowptr, int64_t num_col, uint8_t *rowptr8, uint8_t *col8, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (!g || num_rowptr < 0 || num_col < 0) return GTOK_E_INVAL;
   if (g->max_edges > 255 || g->max_nodes > 256) return GTOK_E_TOO_LARGE;
   if ((num_rowptr && (!g->rowptr || !rowptr8)) || (num_col && (!g->col || !col8))) return GTOK_E_INVAL;
@@ -310,6 +317,8 @@ extern "C" int gtok_sent_decode(const int32_t *ids, int32_t ld, const int32_t *l
                                 int32_t max_num_nodes, int32_t labeled, int32_t num_node_types,
                                 int32_t *num_nodes, int32_t *num_edges, int32_t *edge_a, int32_t *edge_b, int32_t *edge_type,
                                 int32_t edge_cap, int32_t *node_type, int32_t node_cap, int32_t *status, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (num_rows < 0 || ld <= 0 || edge_cap < 0 || node_cap < 0 || max_num_nodes < 0) return GTOK_E_INVAL;
   if (num_rows == 0) return GTOK_OK;
   if (!ids || !len || !num_nodes || !num_edges || !edge_a || !edge_b || !edge_type || !node_type || !status) return GTOK_E_INVAL;

@@ -644,3 +644,53 @@ def test_shard_on_device_then_gather_over_rccl_equals_unsharded():
         assert torch.equal(torch.cat(parts_i), whole_ids) and torch.equal(torch.cat(parts_l), whole_ln)
     finally:
         tdist.destroy_process_group()
+
+
+def test_ticket_ring_never_shares_a_slot_between_live_launches(monkeypatch):
+    """The ring of ticket-counter slots has 256 entries.  700 launches of a ticket-scheduled kernel are queued on
+    two streams WITHOUT any synchronisation in between (each into its own slab), so the ring wraps while early
+    launches are still in flight: the launcher must wait for a slot's previous launch instead of handing the same
+    counters to two live launches (skipped units = rows left unwritten).  Every slab is checked afterwards."""
+    monkeypatch.setenv("GTOK_SENT_KERNEL", "lds")
+    d = gtok.synth.zinc_like(1500, seed=72)
+    batch, coo = both(d, False)
+    b = batch.to(DEV)
+    ld = gtok.ops.sent_safe_ld(batch, False, 1024)
+    ref = {k: orc.sent(coo, 40, 1024, 3, k, ld=ld) for k in (0, 1)}
+    side = torch.cuda.Stream(device=DEV)
+    n = 350
+    outs = [[(torch.full((1500, ld), -7, dtype=torch.int32, device=DEV), torch.full((1500,), -7, dtype=torch.int32, device=DEV))
+             for _ in range(n)] for _ in range(2)]
+    torch.cuda.synchronize()
+    for i in range(n):
+        gtok.ops.sent(b, 40, 1024, 3, 0, ld=ld, out=outs[0][i])
+        with torch.cuda.stream(side):
+            gtok.ops.sent(b, 40, 1024, 3, 1, ld=ld, out=outs[1][i])
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        want_ids = torch.from_numpy(ref[k][0]).to(DEV); want_ln = torch.from_numpy(ref[k][1]).to(DEV)
+        for i in range(n):
+            assert torch.equal(outs[k][i][1], want_ln) and torch.equal(outs[k][i][0], want_ids), (k, i)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_batch_on_another_device_than_the_current_one():
+    """A batch on cuda:1 tokenized while cuda:0 is the current device: the launch takes its device (occupancy, ticket
+    counters) from the stream it is given, not from the calling thread."""
+    torch.cuda.set_device(0)
+    d = gtok.synth.zinc_like(3000, seed=73)
+    batch, coo = both(d)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    for pin in ("lane", "reg", "lds"):
+        os.environ["GTOK_SENT_KERNEL"] = pin
+        try:
+            ids, ln = gtok.ops.sent(batch.to("cuda:1"), 37, 1024, 5, 1, **kw)
+        finally:
+            del os.environ["GTOK_SENT_KERNEL"]
+        assert ids.device == torch.device("cuda:1") and torch.cuda.current_device() == 0
+        ref, rln = orc.sent(coo, 37, 1024, 5, 1, ld=ids.shape[1], **kw)
+        _cmp(ids, ln, ref, rln, f"cuda:1 [{pin}]")
+    vocab = zinc_vocab(40)
+    ids, ln = gtok.ops.ibtt_zinc(batch.to("cuda:1"), gtok.ops.zinc_lut(vocab, 40), 1024, vocab["<pad>"])
+    ref, rln = orc.ibtt_zinc(coo, gtok.ops.zinc_lut(vocab, 40).numpy(), 1024, vocab["<pad>"], ids.shape[1])
+    _cmp(ids, ln, ref, rln, "cuda:1 ibtt")
