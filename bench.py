@@ -153,16 +153,20 @@ def main():
     write_b = 4.0 * tokens_per_step_rank + 4.0 * G
     kern_s = float(np.mean(kern_ms)) * 1e-3
     achieved = (read_b + write_b) / kern_s / 1e9
-    traffic = None
+    kname = gtok.ops.sent_kernel_name(batch, max_nodes, max_len, labeled=zinc, num_node_types=ntypes, num_edge_types=etypes,
+                                      remap_zinc=zinc) + ("<labelled>" if zinc else "<unlabelled>")
+    # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass, and counter
+    # collection perturbs the timing), i.e. from an EARLIER run of this same command: profiles/pmc_traffic.json records
+    # the kernel and the commit it was measured at, and the figure is dropped when the kernel chosen now differs.
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         rec = json.load(open(tpath)).get(f"sent:{args.workload}:{G}:{args.ld}")
-        if rec:
+        if rec and rec.get("kernel_label", kname) == kname:
             traffic = rec["hbm_bytes_per_launch"]
-    kname = gtok.ops.sent_kernel_name(batch, max_nodes, max_len, labeled=zinc, num_node_types=ntypes, num_edge_types=etypes,
-                                      remap_zinc=zinc) + ("<labelled>" if zinc else "<unlabelled>")
+            traffic_source = f"{rec.get('source', 'profiles/pmc_traffic.json')} (rocprofv3 --pmc, measured at commit {rec.get('commit', 'unknown')}, not in this run)"
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(read_b + write_b), kernel_ms=round(kern_s * 1e3, 4),
                     padded_slab_bytes_per_launch=int(4 * G * ld))
 
@@ -213,17 +217,18 @@ def main():
             iname = gtok.lib().gtok_ibtt_zinc_kernel_name(ctypes.byref(_cs)).decode()
         else:
             iname = "ibtt_synth_kernel"
-        itraffic = None
+        itraffic, itraffic_source = None, None
         if os.path.exists(tpath):
             rec = json.load(open(tpath)).get(f"ibtt:{args.workload}:{G}")
-            if rec:
+            if rec and rec.get("kernel_label", iname) == iname:
                 itraffic = rec["hbm_bytes_per_launch"]
+                itraffic_source = f"{rec.get('source', 'profiles/pmc_traffic.json')} (rocprofv3 --pmc, measured at commit {rec.get('commit', 'unknown')}, not in this run)"
         out["ibtt"] = dict(kernel=iname,
                            graphs_per_sec_per_gpu=round(G * args.steps / iwall, 1),
                            tokens_per_sec_per_gpu=round(itok * args.steps / iwall, 1), kernel_ms=round(ik * 1e3, 4),
                            slab_width=ild, avg_tokens_per_graph=round(itok / G, 2),
                            roofline=dict(bound="hbm", achieved=round(ib / ik / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                                         frac=round(ib / ik / 1e9 / HBM_PEAK_GBS, 5), traffic=itraffic,
+                                         frac=round(ib / ik / 1e9 / HBM_PEAK_GBS, 5), traffic=itraffic, traffic_source=itraffic_source,
                                          algorithmic_bytes_per_launch=int(ib),
                                          padded_slab_bytes_per_launch=int(4 * G * ild)))
 
@@ -360,6 +365,19 @@ def main():
                                    sample=f"first {S} graphs of the same corpus, oracle/gtok_oracle.c:oracle_sent "
                                           f"(OpenMP, {cores} threads), {reps} passes",
                                    tokens_per_sec=round(float(rln.sum()) / cpu_s, 1), parity_with_gpu=bool(same))
+        if zinc and not args.no_ibtt:      # the IBTT serialiser's CPU restatement on the same sample
+            lut_h = lut.cpu().numpy()
+            orc.ibtt_zinc(coo.slice(0, min(S, 2000)), lut_h, max_len, vocab["<pad>"], ild, nthreads=cores)
+            reps_i, t0 = 0, time.perf_counter()
+            while reps_i < 3 or time.perf_counter() - t0 < 5.0:
+                iref, irln = orc.ibtt_zinc(coo, lut_h, max_len, vocab["<pad>"], ild, nthreads=cores)
+                reps_i += 1
+            icpu = (time.perf_counter() - t0) / reps_i
+            isame = np.array_equal(iids[:chk].cpu().numpy(), iref[:chk]) and np.array_equal(iln[:chk].cpu().numpy(), irln[:chk])
+            out["ibtt"]["cpu_baseline"] = dict(value=round(S / icpu, 1), unit="graphs/s", cores=cores, kind="port",
+                                               sample=f"first {S} graphs of the same corpus, oracle/gtok_oracle.c:oracle_ibtt_zinc "
+                                                      f"(OpenMP, {cores} threads), {reps_i} passes",
+                                               tokens_per_sec=round(float(irln.sum()) / icpu, 1), parity_with_gpu=bool(isame))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if multi:

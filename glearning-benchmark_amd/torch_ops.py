@@ -83,3 +83,81 @@ def collate(ids: Tensor, lens: Tensor, index: Tensor, pad_id: int, out_ld: int) 
 def _(ids, lens, index, pad_id, out_ld):
     B = index.shape[0]
     return ids.new_empty((B, out_ld), dtype=torch.int64), ids.new_empty((B, out_ld), dtype=torch.bool)
+
+
+class _Table:
+    """ops.VocabTable rebuilt from its tensors (the custom op takes tensors only)."""
+
+    def __init__(self, key_off, key_len, ids, key_bytes, pad_id):
+        self.key_off, self.key_len, self.ids, self.key_bytes = key_off, key_len, ids, key_bytes
+        self.capacity, self.pad_id = int(key_off.numel()), int(pad_id)
+
+    c_struct = _ops.VocabTable.c_struct
+
+
+@torch.library.custom_op("gtok::text_to_ids", mutates_args=(), device_types="cuda")
+def text_to_ids(text_bytes: Tensor, text_ptr: Tensor, key_off: Tensor, key_len: Tensor, key_id: Tensor, key_bytes: Tensor,
+                pad_id: int, max_len: int, strip_label: bool, ld: int) -> Tuple[Tensor, Tensor]:
+    """TokenDataset's text -> ids (data_loader.py:465-484); the vocab travels as the open-addressing table of
+    ops.VocabTable (key_off / key_len / key_id int32 [capacity], key_bytes uint8)."""
+    return _ops.text_to_ids(text_bytes, text_ptr, _Table(key_off, key_len, key_id, key_bytes, pad_id), max_len, strip_label, ld=ld)
+
+
+@text_to_ids.register_fake
+def _(text_bytes, text_ptr, key_off, key_len, key_id, key_bytes, pad_id, max_len, strip_label, ld):
+    G = text_ptr.shape[0] - 1
+    return text_bytes.new_empty((G, ld), dtype=torch.int32), text_bytes.new_empty((G,), dtype=torch.int32)
+
+
+@torch.library.custom_op("gtok::find_token", mutates_args=(), device_types="cuda")
+def find_token(x: Tensor, token: int) -> Tensor:
+    return _ops.find_token(x, token)
+
+
+@find_token.register_fake
+def _(x, token):
+    return x.new_empty((x.shape[0],), dtype=torch.int32)
+
+
+@torch.library.custom_op("gtok::vocab_stats_synth", mutates_args=(), device_types="cuda")
+def vocab_stats_synth(node_ptr: Tensor, edge_ptr: Tensor, rowptr: Tensor, col: Tensor, eorder: Optional[Tensor],
+                      query_nodes: Optional[Tensor], max_nodes: int, max_edges: int, num_ids: int,
+                      graph_base: int) -> Tuple[Tensor, Tensor]:
+    b = _batch(node_ptr, edge_ptr, rowptr, col, eorder, None, None, max_nodes, max_edges)
+    return _ops.vocab_stats_synth(b, num_ids, query_nodes, graph_base)
+
+
+@vocab_stats_synth.register_fake
+def _(node_ptr, edge_ptr, rowptr, col, eorder, query_nodes, max_nodes, max_edges, num_ids, graph_base):
+    return node_ptr.new_empty((num_ids,), dtype=torch.int64), node_ptr.new_empty((num_ids,), dtype=torch.int64)
+
+
+@torch.library.custom_op("gtok::parse_graph_text", mutates_args=(), device_types="cuda")
+def parse_graph_text(text_bytes: Tensor, text_ptr: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """(num_edges, num_nodes, query [G,2], label, status, edge_ptr [G+1], src, dst): ops.parse_graph_texts as a tuple;
+    src / dst have a data-dependent length (sum of the canonical texts' edge counts)."""
+    r = _ops.parse_graph_texts(text_bytes, text_ptr)
+    return (r["num_edges"], r["num_nodes"], r["query"], r["label"], r["status"], r["edge_ptr"], r["src"].clone(), r["dst"].clone())
+
+
+@parse_graph_text.register_fake
+def _(text_bytes, text_ptr):
+    G = text_ptr.shape[0] - 1
+    E = torch.library.get_ctx().new_dynamic_size()
+    i32 = lambda *s: text_bytes.new_empty(s, dtype=torch.int32)
+    return i32(G), i32(G), i32(G, 2), i32(G), i32(G), text_bytes.new_empty((G + 1,), dtype=torch.int64), i32(E), i32(E)
+
+
+@torch.library.custom_op("gtok::sent_decode", mutates_args=(), device_types="cuda")
+def sent_decode(ids: Tensor, lens: Tensor, max_num_nodes: int, labeled: bool, num_node_types: int, edge_cap: int,
+                node_cap: int) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """(num_nodes, num_edges, status, edge_a, edge_b, edge_type, node_type): ops.sent_decode as a tuple."""
+    r = _ops.sent_decode(ids, lens, max_num_nodes, labeled, num_node_types, edge_cap, node_cap)
+    return (r["num_nodes"], r["num_edges"], r["status"], r["edge_a"], r["edge_b"], r["edge_type"], r["node_type"])
+
+
+@sent_decode.register_fake
+def _(ids, lens, max_num_nodes, labeled, num_node_types, edge_cap, node_cap):
+    G = ids.shape[0]
+    i32 = lambda *s: ids.new_empty(s, dtype=torch.int32)
+    return i32(G), i32(G), i32(G), i32(G, edge_cap), i32(G, edge_cap), i32(G, edge_cap), i32(G, node_cap)

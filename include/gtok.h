@@ -267,7 +267,9 @@ int gtok_sent_decode(const int32_t *ids, int32_t ld, const int32_t *len, int32_t
  * GTOK_CSR_SIMPLE_SYMMETRIC and a large batch; "sent_reg_kernel": wave per graph, <= 64 nodes;
  * "sent_lds_kernel<W=..>": wave per graph, up to 512 nodes).  All three emit the same tokens.               */
 const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_params *p);
-/* Same for gtok_ibtt_zinc(): "ibtt_zinc_lane_kernel" (lane per graph) or "ibtt_zinc_kernel" (wave per graph).   */
+/* Same for gtok_ibtt_zinc(): "ibtt_zinc_quad_kernel" (8 or 16 lanes per molecule: GTOK_CSR_SIMPLE_SYMMETRIC
+ * batches in list order - the default for ZINC), "ibtt_zinc_lane_kernel" (lane per graph, GTOK_IBTT_KERNEL=lane
+ * only) or "ibtt_zinc_kernel" (wave per graph: any batch).  All emit the same tokens.                          */
 const char *gtok_ibtt_zinc_kernel_name(const gtok_csr *g);
 
 /* Library/ABI version and build target string ("gfx950").                   */

@@ -219,6 +219,32 @@ def test_torch_custom_ops():
                                          b.max_nodes, b.max_edges, 1024, 2, 240)
     ref2, rln2 = orc.ibtt_zinc(coo, lut.cpu().numpy(), 1024, 2, 240)
     _cmp(ids2, ln2, ref2, rln2, "torch.ops.gtok.ibtt_zinc")
+    # the other five entry points, against the GraphBatch-level wrappers (themselves checked against the oracle elsewhere)
+    texts = ["<bos> 0 1 <e> 1 2 <e> <n> 0 1 2 <q> has_cycle <p> no <eos>", "<bos> 3 4 <e> <n> 3 4 <q> shortest_distance 3 4 <p> len1 <eos>"]
+    tb, tp = gtok.ops.pack_texts(texts)
+    tb, tp = tb.to(DEV), tp.to(DEV)
+    sv = {t: i for i, t in enumerate(["<pad>", "<bos>", "<e>", "<n>", "<q>", "<p>", "<eos>", "yes", "no", "0", "1", "2", "3", "4", "has_cycle"])}
+    tab = gtok.ops.VocabTable(sv, DEV)
+    a1, l1 = torch.ops.gtok.text_to_ids(tb, tp, tab.key_off, tab.key_len, tab.ids, tab.key_bytes, tab.pad_id, 64, True, 64)
+    a0, l0 = gtok.ops.text_to_ids(tb, tp, tab, 64, True, ld=64)
+    assert torch.equal(a1, a0) and torch.equal(l1, l0)
+    r = gtok.ops.parse_graph_texts(tb, tp)
+    t8 = torch.ops.gtok.parse_graph_text(tb, tp)
+    for got, key in zip(t8, ("num_edges", "num_nodes", "query", "label", "status", "edge_ptr", "src", "dst")):
+        assert torch.equal(got, r[key]), key
+    xb = torch.tensor([[1, 9, 4, 4], [7, 7, 7, 7]], dtype=torch.int64, device=DEV)
+    assert torch.ops.gtok.find_token(xb, 4).tolist() == [2, -1]
+    raw, rl = gtok.ops.sent(b, 37, 1024, 3, 1, labeled=True, num_node_types=9, num_edge_types=4)
+    dd = gtok.ops.sent_decode(raw, rl, 37, True, 9, 64, 37)
+    td = torch.ops.gtok.sent_decode(raw, rl, 37, True, 9, 64, 37)
+    for got, key in zip(td, ("num_nodes", "num_edges", "status", "edge_a", "edge_b", "edge_type", "node_type")):
+        assert torch.equal(got, dd[key]), key
+    s = gtok.synth.graph_token_like(200, seed=74, with_text=False)
+    sb, _ = both(s, False)
+    sb = sb.to(DEV)
+    c0, f0 = gtok.ops.vocab_stats_synth(sb, 64)
+    c1, f1 = torch.ops.gtok.vocab_stats_synth(sb.node_ptr, sb.edge_ptr, sb.rowptr, sb.col, sb.eorder, None, sb.max_nodes, sb.max_edges, 64, 0)
+    assert torch.equal(c0, c1) and torch.equal(f0, f1)
     X, A = torch.ops.gtok.collate(ids2, ln2, torch.arange(8, device=DEV), 2, int(ln2[:8].max()))
     assert X.dtype == torch.int64 and A.dtype == torch.bool and X.shape == A.shape
     with pytest.raises((NotImplementedError, RuntimeError)):

@@ -274,8 +274,16 @@ def test_product_has_no_cpu_path():
 
 
 def test_custom_ops_are_registered_cuda_only_and_have_meta_kernels():
-    for name in ("sent", "ibtt_zinc", "ibtt_synth", "remap_zinc", "collate"):
+    for name in ("sent", "ibtt_zinc", "ibtt_synth", "remap_zinc", "collate", "text_to_ids", "find_token",
+                 "vocab_stats_synth", "parse_graph_text", "sent_decode"):
         assert hasattr(torch.ops.gtok, name), name
+    x = torch.zeros((3, 7), dtype=torch.int64)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.gtok.find_token(x, 4)
+    assert torch.ops.gtok.find_token(x.to("meta"), 4).shape == (3,)
+    dec = torch.ops.gtok.sent_decode(torch.zeros((5, 16), dtype=torch.int32, device="meta"),
+                                     torch.zeros(5, dtype=torch.int32, device="meta"), 37, True, 9, 12, 37)
+    assert [tuple(t.shape) for t in dec] == [(5,), (5,), (5,), (5, 12), (5, 12), (5, 12), (5, 37)]
     ids = torch.zeros((4, 8), dtype=torch.int32); ln = torch.full((4,), 8, dtype=torch.int32)
     with pytest.raises((NotImplementedError, RuntimeError)):       # no CPU kernel exists
         torch.ops.gtok.remap_zinc(ids, ln, 6, 43, 52)
