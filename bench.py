@@ -33,6 +33,9 @@ WORKLOADS = {
     # BASELINE config 5 shape (graph_generator.sh families, 10..256 nodes, sparsity 0.1-0.2, max_len 600):
     # 125k graphs = one rank's share of the 1M-graph corpus on 8 GPUs (sampled on the GPU in ~6 s)
     "synth_er": dict(graphs=125000, desc="AGTT unlabelled SENT, Erdos-Renyi graph-token-shaped graphs, 10-256 nodes, max_len 600"),
+    # the same share of config 5 with the full family mix of graph_generator.sh (er/ba/sbm/sfn/path/star/complete, graph i of
+    # family i mod 7): a seventh of the graphs are complete - they hold most of the corpus's entries
+    "synth_mix": dict(graphs=125000, desc="AGTT unlabelled SENT, er/ba/sbm/sfn/path/star/complete graph-token-shaped graphs, 10-256 nodes, max_len 600"),
 }
 
 
@@ -105,7 +108,8 @@ def main():
         d = gtok.synth.zinc_like(G, seed=1000 + rank)
         host = gtok.GraphBatch.from_coo_device(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"], device=dev)
     else:
-        d = gtok.synth.er_batch_device(G, dev, seed=1000 + rank)
+        sample = gtok.synth.mix_batch_device if args.workload == "synth_mix" else gtok.synth.er_batch_device
+        d = sample(G, dev, seed=1000 + rank)
         host = gtok.GraphBatch.from_coo_device(d["node_counts"], d["edge_counts"], d["src"], d["dst"], device=dev)
     batch = host          # CSR built on the device (torch sort / bincount): bit-identical to the host builder, much faster
     torch.cuda.synchronize()

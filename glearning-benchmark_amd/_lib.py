@@ -70,6 +70,7 @@ SYMBOLS = {
     "gtok_parse_graph_text": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gtok_find_token": (_I, [_P, _I, _I, ctypes.c_int64, _P, _P]),
     "gtok_vocab_stats_synth": (_I, [ctypes.POINTER(GtokCsr), _P, ctypes.c_int64, _I, _P, _P, _P]),
+    "gtok_vocab_stats_text": (_I, [_P, _P, _I, ctypes.c_int64, _I, _P, _P, _P, _P, _P, _P]),
     "gtok_csr_pack8": (_I, [ctypes.POINTER(GtokCsr), ctypes.c_int64, ctypes.c_int64, _P, _P, _P]),
     "gtok_sent_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(GtokCsr), ctypes.POINTER(GtokSentParams)]),
     "gtok_ibtt_zinc_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(GtokCsr)]),

@@ -772,6 +772,113 @@ __device__ __forceinline__ bool py_isspace(uint32_t c) {
   return c == 32u || (c >= 9u && c <= 13u) || (c >= 28u && c <= 31u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// corpus pass of build_vocab_from_texts (data_loader.py:451-463) / the ZINC dynamic-token scan
+// (trainer/train_ibtt.py:361-372) over ARBITRARY texts: occurrence count and first position of every
+// distinct whitespace-separated token.  Wave per text; lane = byte; a token's start lane hashes it (two
+// independent 32-bit FNV-1a streams = a 64-bit identity, the token's length is compared as well) and adds it
+// to the wave's own LDS table; the table is merged into the global one once per wave (a hot token such as
+// `<e>` would otherwise be one global atomic per occurrence).  first = byte offset of the token's earliest
+// occurrence in the corpus blob: the blob is the texts in order, so offsets order occurrences exactly as
+// Counter's first-insertion order does, and blob[first : first + len] is the token string itself.
+// ---------------------------------------------------------------------------------------------
+struct VocabTextArgs {
+  const uint8_t *bytes; const int64_t *text_ptr; int num_texts;
+  int64_t base_offset;
+  int capacity;                                    // global table slots (power of two)
+  unsigned long long *key, *count, *first; int32_t *len, *status;
+  int lslots;                                      // per-wave LDS slots (power of two)
+  int units, upb;
+};
+
+__device__ __forceinline__ void vocab_text_global_add(const VocabTextArgs &a, unsigned long long k, unsigned int ln,
+                                                      unsigned long long cnt, unsigned long long fst) {
+  const unsigned int mask = (unsigned int)a.capacity - 1u;
+  unsigned int slot = (unsigned int)(k ^ (k >> 29)) & mask;
+  for (unsigned int probes = 0; probes <= mask; ++probes, slot = (slot + 1) & mask) {
+    unsigned long long old = atomicCAS(a.key + slot, 0ull, k);
+    if (old == 0ull) {                              // claimed an empty slot: publish the length
+      __hip_atomic_store(a.len + slot, (int)ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = k;
+    }
+    if (old == k) {
+      // same 64-bit identity: the lengths must agree too (the claimant's store may not have landed yet: 0 = not yet)
+      int l2 = __hip_atomic_load(a.len + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spin = 0; l2 == 0 && spin < 1000000; ++spin) l2 = __hip_atomic_load(a.len + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (l2 == 0) { atomicOr(a.status, 2); return; }   // never seen in practice: the claimant's length did not arrive
+      if (l2 == (int)ln) {
+        atomicAdd(a.count + slot, cnt);
+        atomicMin(a.first + slot, fst);
+        return;
+      }
+    }
+  }
+  atomicOr(a.status, 1);                            // table full: the caller enlarges it and runs again
+}
+
+__global__ void __launch_bounds__(256) vocab_stats_text_kernel(const VocabTextArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
+  const int S = a.lslots;
+  unsigned char *wb = smem + (size_t)wave * ((size_t)S * 24);
+  unsigned long long *lkey = reinterpret_cast<unsigned long long *>(wb);
+  unsigned long long *lfirst = lkey + S;
+  unsigned int *lcount = reinterpret_cast<unsigned int *>(lfirst + S);
+  unsigned int *llen = lcount + S;
+  for (int i = lane; i < S; i += kWave) { lkey[i] = 0ull; lfirst[i] = ~0ull; lcount[i] = 0u; llen[i] = 0u; }
+  wave_sync();
+  const unsigned int lmask = (unsigned int)S - 1u;
+
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * wpb + wave;
+    if (g >= a.num_texts) break;
+    const int64_t t0 = a.text_ptr[g];
+    const uint8_t *__restrict__ s = a.bytes + t0;
+    const int64_t n = a.text_ptr[g + 1] - t0;
+    bool prev_sp = true;                            // a text starts a token: texts are not separated in the blob
+    for (int64_t b0 = 0; b0 < n; b0 += kWave) {
+      const int64_t i = b0 + lane;
+      const uint32_t c = i < n ? s[i] : 32u;
+      const bool sp = py_isspace(c);
+      const uint64_t spm = __ballot(sp);
+      const bool before = lane == 0 ? prev_sp : ((spm >> (lane - 1)) & 1ull);
+      prev_sp = (spm >> 63) & 1ull;
+      if (!sp && before) {
+        uint32_t h1 = 2166136261u, h2 = 0x9747b28cu;
+        unsigned int ln = 0;
+        for (int64_t j = i; j < n; ++j) {
+          const uint32_t cj = s[j];
+          if (py_isspace(cj)) break;
+          h1 = (h1 ^ cj) * 16777619u;
+          h2 = (h2 ^ (cj + 0x9e3779b9u)) * 0x85ebca6bu; h2 ^= h2 >> 13;
+          ++ln;
+        }
+        unsigned long long k = ((unsigned long long)h2 << 32) | h1;
+        if (k == 0ull) k = 1ull;                    // 0 marks an empty slot
+        const unsigned long long pos = (unsigned long long)(a.base_offset + t0 + i);
+        bool placed = false;
+        unsigned int slot = (unsigned int)(k ^ (k >> 29)) & lmask;
+        for (unsigned int probes = 0; probes < 16u && !placed; ++probes, slot = (slot + 1) & lmask) {
+          unsigned long long old = atomicCAS(lkey + slot, 0ull, k);
+          if (old == 0ull) { atomicExch(llen + slot, ln); old = k; }
+          if (old == k) {
+            unsigned int l2 = __hip_atomic_load(llen + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            for (int spin = 0; l2 == 0u && spin < 100000; ++spin) l2 = __hip_atomic_load(llen + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (l2 == ln) { atomicAdd(lcount + slot, 1u); atomicMin(lfirst + slot, pos); placed = true; }
+          }
+        }
+        if (!placed) vocab_text_global_add(a, k, ln, 1ull, pos);   // crowded neighbourhood of the small table: straight to the global one
+      }
+    }
+  }
+  wave_sync();
+  for (int i = lane; i < S; i += kWave)
+    if (lkey[i] != 0ull) vocab_text_global_add(a, lkey[i], llen[i], (unsigned long long)lcount[i], lfirst[i]);
+}
+
 struct TextArgs {
   const uint8_t *bytes; const int64_t *text_ptr; int num_texts;
   gtok_vocab_table v;
@@ -1401,6 +1508,27 @@ extern "C" int gtok_vocab_stats_synth(const gtok_csr *g, const int32_t *query_no
   const Launch L = plan(reinterpret_cast<const void *>(vocab_stats_synth_kernel), g->num_graphs, wpb, lds);
   a.units = L.units; a.upb = L.upb;
   hipLaunchKernelGGL(vocab_stats_synth_kernel, dim3(L.nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_vocab_stats_text(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts, int64_t base_offset,
+                                     int32_t capacity, uint64_t *key, int64_t *count, int64_t *first, int32_t *len,
+                                     int32_t *status, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (num_texts < 0 || capacity < 16 || (capacity & (capacity - 1)) != 0) return GTOK_E_INVAL;
+  if (num_texts == 0) return GTOK_OK;
+  if (!bytes || !text_ptr || !key || !count || !first || !len || !status) return GTOK_E_INVAL;
+  VocabTextArgs a;
+  a.bytes = bytes; a.text_ptr = text_ptr; a.num_texts = num_texts; a.base_offset = base_offset; a.capacity = capacity;
+  a.key = reinterpret_cast<unsigned long long *>(key); a.count = reinterpret_cast<unsigned long long *>(count);
+  a.first = reinterpret_cast<unsigned long long *>(first); a.len = len; a.status = status;
+  a.lslots = 512;
+  const int wpb = 4;
+  const size_t lds = (size_t)wpb * a.lslots * 24;
+  const Launch L = plan(reinterpret_cast<const void *>(vocab_stats_text_kernel), num_texts, wpb, lds);
+  a.units = L.units; a.upb = L.upb;
+  hipLaunchKernelGGL(vocab_stats_text_kernel, dim3(L.nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 

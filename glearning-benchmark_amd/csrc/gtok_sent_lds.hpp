@@ -82,14 +82,19 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
 #ifdef GTOK_PHASE_TIMING
     const uint64_t ts1 = __builtin_amdgcn_s_memtime();
 #endif
+    // lane = row.  Unlabelled batches read the neighbour ids straight from HBM: 16 loads per lane are in flight per
+    // round trip (4 made the build - a chain of ~1 us round trips, rows of 10-40 entries - 16 % of the kernel's time;
+    // the LDS atomics themselves are ~1000 cycles per graph).  All rows of a graph with <= 64 nodes go out together,
+    // larger graphs in passes of 64 rows.
+    constexpr int BU = LAB ? 4 : 16;
     for (int u = lane; u < n; u += kWave) {
       const int rs = rpg[u], re = rpg[u + 1];
-      for (int k0e = rs; k0e < re; k0e += 4) {   // 4 neighbour reads in flight per round trip
-        int v[4];
+      for (int k0e = rs; k0e < re; k0e += BU) {
+        int v[BU];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = LAB ? (int)colL[min(k0e + j, re - 1)] : colg[min(k0e + j, re - 1)];
+        for (int j = 0; j < BU; ++j) v[j] = LAB ? (int)colL[min(k0e + j, re - 1)] : colg[min(k0e + j, re - 1)];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < BU; ++j) {
           if (k0e + j < re && (unsigned)v[j] < (unsigned)n) {
             atomicOr(reinterpret_cast<unsigned long long *>(&adj[u * W + (v[j] >> 6)]), 1ull << (v[j] & 63));
             atomicOr(reinterpret_cast<unsigned long long *>(&adj[v[j] * W + (u >> 6)]), 1ull << (u & 63));

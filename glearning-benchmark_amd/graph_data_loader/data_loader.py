@@ -225,6 +225,31 @@ def build_vocab_from_texts(texts: List[str], min_freq: int = 1, max_tokens: Opti
     return vocab, {i: t for t, i in vocab.items()}
 
 
+def build_vocab_from_texts_on_device(texts: List[str], min_freq: int = 1, max_tokens: Optional[int] = None, device=None,
+                                     capacity: int = 1 << 16):
+    """build_vocab_from_texts (reference :451-463) with the corpus pass - every token of every text counted, first
+    appearances kept - done by ONE launch over the packed texts (gtok_vocab_stats_text); the host only walks the
+    DISTINCT tokens, already in Counter.most_common order.  Same (vocab, inverse) as build_vocab_from_texts."""
+    if device is None:
+        if not torch.cuda.is_available():
+            raise GtokError("build_vocab_from_texts_on_device needs a GPU; build_vocab_from_texts is the host function")
+        device = torch.device("cuda", torch.cuda.current_device())
+    vocab = {tok: i for i, tok in enumerate(SPECIAL)}
+    if texts:
+        blob, ptr = _ops.pack_texts(texts)
+        blob = blob.to(device)
+        table = _ops.vocab_stats_text(blob, ptr, capacity)
+        for tok, c, _ in _ops.text_stats_entries(table, blob):
+            if tok in vocab:
+                continue
+            if c < min_freq:
+                break
+            vocab[tok] = len(vocab)
+            if max_tokens and len(vocab) >= max_tokens:
+                break
+    return vocab, {i: t for t, i in vocab.items()}
+
+
 def vocab_from_stats(count, first, node_counts, edge_counts, task: Optional[str] = None, label_tokens=None,
                      query_nodes=None, min_freq: int = 1, max_tokens: Optional[int] = None, graph_base: int = 0):
     """build_vocab_from_texts (reference :451-463) for a graph-token corpus that was never rendered as text:

@@ -60,6 +60,30 @@ def extend_vocab_with_dynamic_tokens(base_vocab: Dict[str, int], dynamic_tokens:
     return vocab
 
 
+def build_zinc_vocab_on_device(texts, device=None, capacity: int = 1 << 16) -> Dict[str, int]:
+    """The vocab pass of trainer/train_ibtt.py:361-372 - fixed table + every token of the train / val / test
+    texts that is not in it - with the scan over all texts done by one launch (gtok_vocab_stats_text).  The
+    reference gives the unseen tokens ids in the iteration order of a Python `set` of str, which depends on
+    PYTHONHASHSEED and cannot be reproduced without fixing it; the DETERMINISTIC stand-in used
+    here is first appearance in the corpus (texts in the order given: train, val, test).  Same token set, same id
+    range 22.., a different permutation of the dynamic ids - which is why every tokenizer entry point takes the
+    vocab as an input: a vocab saved by the reference (its checkpoints embed it) is replayed unchanged."""
+    import torch
+    from ._root import root as _root
+    ops = _root().ops
+    vocab, _ = build_fixed_zinc_vocab()
+    texts = list(texts)
+    if not texts:
+        return vocab
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    blob, ptr = ops.pack_texts(texts)
+    blob = blob.to(device)
+    entries = ops.text_stats_entries(ops.vocab_stats_text(blob, ptr, capacity), blob)
+    unseen = sorted((first, tok) for tok, _, first in entries if tok not in vocab)
+    return extend_vocab_with_dynamic_tokens(vocab, [tok for _, tok in unseen])
+
+
 def map_autograph_token_to_fixed_id(autograph_token_id: int, tokenizer_node_idx_offset: int,
                                     tokenizer_edge_idx_offset: int, is_node_type: bool = False,
                                     is_edge_type: bool = False) -> int:

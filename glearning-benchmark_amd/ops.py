@@ -282,6 +282,57 @@ def vocab_stats_synth(batch: GraphBatch, num_ids: int, query_nodes: Optional[tor
     return count, first
 
 
+def vocab_stats_text(text_bytes: torch.Tensor, text_ptr: torch.Tensor, capacity: int = 1 << 16, base_offset: int = 0,
+                     out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """Count and first position of every distinct whitespace-separated token of the texts (gtok_vocab_stats_text): the
+    corpus pass of build_vocab_from_texts (data_loader.py:451-463) and of the ZINC dynamic-token scan
+    (trainer/train_ibtt.py:361-372) on the device.  Returns the open-addressing table as device tensors
+    {key uint64-as-int64, count, first int64, len int32, status int32 [1]} of `capacity` slots; pass it back as `out`
+    to accumulate further shards (base_offset = the shard's byte offset in the whole corpus).  text_stats_entries()
+    turns a finished table into (token, count, first) triples."""
+    _need_gpu(text_bytes, "vocab_stats_text")
+    dev = text_bytes.device
+    text_ptr = text_ptr.to(dev, dtype=torch.int64).contiguous()
+    G = int(text_ptr.numel()) - 1
+    if capacity < 16 or capacity & (capacity - 1):
+        raise ValueError("capacity must be a power of two >= 16")
+    if out is None:
+        out = dict(key=torch.zeros(capacity, dtype=torch.int64, device=dev), count=torch.zeros(capacity, dtype=torch.int64, device=dev),
+                   first=torch.full((capacity,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev),
+                   len=torch.zeros(capacity, dtype=torch.int32, device=dev), status=torch.zeros(1, dtype=torch.int32, device=dev))
+    elif out["key"].numel() != capacity:
+        raise ValueError("out was built for another capacity")
+    _lib.check(_lib.lib().gtok_vocab_stats_text(text_bytes.data_ptr(), text_ptr.data_ptr(), G, int(base_offset), capacity,
+                                                out["key"].data_ptr(), out["count"].data_ptr(), out["first"].data_ptr(),
+                                                out["len"].data_ptr(), out["status"].data_ptr(), _stream(dev)),
+               "gtok_vocab_stats_text")
+    return out
+
+
+def text_stats_entries(table: Dict[str, torch.Tensor], text_bytes: torch.Tensor, base_offset: int = 0):
+    """[(token, count, first)] of a finished gtok_vocab_stats_text table, in Counter.most_common order (count
+    descending, first appearance ascending).  The token strings are read back from the corpus blob at `first`
+    (only the table and one byte range per DISTINCT token cross to the host).  Raises when the table overflowed."""
+    st = int(table["status"].item())
+    if st:
+        raise _lib.GtokError(f"vocab_stats_text: table {'overflowed' if st & 1 else 'was not consistent'} (status {st}): use a larger capacity")
+    used = (table["key"] != 0).nonzero(as_tuple=True)[0]
+    cnt, fst, ln = table["count"][used], table["first"][used], table["len"][used].to(torch.int64)
+    order = torch.argsort(fst)                      # stable secondary key first ...
+    order = order[torch.argsort(cnt[order], descending=True, stable=True)]
+    cnt, fst, ln = cnt[order].cpu().tolist(), fst[order].cpu().tolist(), ln[order].cpu().tolist()
+    # gather the token bytes on the device: one [sum len] buffer instead of a host copy of the corpus
+    lens = torch.tensor(ln, dtype=torch.int64, device=text_bytes.device)
+    starts = torch.tensor(fst, dtype=torch.int64, device=text_bytes.device) - base_offset
+    ptr = torch.zeros(len(ln) + 1, dtype=torch.int64, device=text_bytes.device)
+    torch.cumsum(lens, 0, out=ptr[1:])
+    idx = torch.arange(int(ptr[-1]), device=text_bytes.device)
+    tok = torch.repeat_interleave(torch.arange(len(ln), device=text_bytes.device), lens, output_size=int(ptr[-1]))
+    blob = bytes(text_bytes[starts[tok] + (idx - ptr[tok])].cpu().numpy())
+    p = ptr.cpu().tolist()
+    return [(blob[p[i]:p[i + 1]].decode("utf-8"), cnt[i], fst[i]) for i in range(len(ln))]
+
+
 def _fnv1a(b: bytes) -> int:
     h = 2166136261
     for c in b:

@@ -234,3 +234,71 @@ def write_tree(root: str, tree: Dict[str, list]) -> None:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "w") as f:
             json.dump(recs, f)
+
+
+MIX_FAMILIES = ("er", "ba", "sbm", "sfn", "path", "star", "complete")
+
+
+def mix_batch_device(num_graphs: int, device, seed: int = 0, min_nodes: int = 10, max_nodes: int = 256,
+                     min_sparsity: float = 0.1, max_sparsity: float = 0.2, families: Sequence[str] = MIX_FAMILIES,
+                     chunk: int = 512) -> Dict[str, np.ndarray]:
+    """BASELINE config 5's corpus shape (graph_generator.sh families er / ba / sbm / sfn / complete / star / path,
+    docs/synthetic_data.md:86, 10..max_nodes nodes, sparsity 0.1-0.2), sampled on the GPU with torch: graph i is of
+    family families[i % len(families)], so every contiguous shard holds the whole mix.  One direction per
+    undirected edge (u < v), row-sorted, as graph-token files list them.  Returns host numpy batched COO plus
+    `family` (index into `families`) per graph.  ba / sfn: preferential attachment, m = round(p (n-1) / 2) >= 1 new
+    edges per arriving node, drawn without replacement with probability ~ degree + 1."""
+    import torch
+    gen = torch.Generator(device=device); gen.manual_seed(seed)
+    F = len(families)
+    n = torch.randint(min_nodes, max_nodes + 1, (num_graphs,), generator=gen, device=device)
+    p = torch.rand((num_graphs,), generator=gen, device=device) * (max_sparsity - min_sparsity) + min_sparsity
+    fam = torch.arange(num_graphs, device=device) % F
+    M = max_nodes
+    iu = torch.arange(M, device=device)
+    upper = iu[None, :] > iu[:, None]                                 # [u, v]: u < v
+    fid = {name: k for k, name in enumerate(families)}
+    srcs, dsts, counts = [], [], []
+    for c0 in range(0, num_graphs, chunk):
+        nn, pp, ff = n[c0:c0 + chunk], p[c0:c0 + chunk], fam[c0:c0 + chunk]
+        C = nn.numel()
+        r = torch.rand((C, M, M), generator=gen, device=device)
+        keep = torch.zeros((C, M, M), dtype=torch.bool, device=device)
+        is_ = lambda name: (ff == fid[name])[:, None, None] if name in fid else torch.zeros((C, 1, 1), dtype=torch.bool, device=device)
+        keep |= is_("er") & (r < pp[:, None, None])
+        keep |= is_("complete")
+        keep |= is_("path") & (iu[None, None, :] == iu[None, :, None] + 1)
+        keep |= is_("star") & (iu[None, :, None] == 0)
+        blk = (iu[None, :] * 2) // nn[:, None].clamp(min=1)           # two communities
+        same = blk[:, :, None] == blk[:, None, :]
+        keep |= is_("sbm") & (r < torch.where(same, (2.0 * pp).clamp(max=1.0)[:, None, None], (0.25 * pp)[:, None, None]))
+        pa = torch.zeros(C, dtype=torch.bool, device=device)
+        for name in ("ba", "sfn"):
+            if name in fid:
+                pa |= ff == fid[name]
+        if bool(pa.any()):
+            idx = pa.nonzero(as_tuple=True)[0]
+            na, ma = nn[idx], torch.clamp(torch.round(pp[idx] * (nn[idx] - 1).float() / 2).long(), min=1)
+            A = idx.numel()
+            mmax = int(ma.max())
+            deg = torch.zeros((A, M), device=device)
+            sub = torch.zeros((A, M, M), dtype=torch.bool, device=device)
+            ar = torch.arange(A, device=device)
+            for t in range(1, int(na.max())):
+                w = deg[:, :t] + 1.0
+                k = min(mmax, t)
+                tgt = torch.multinomial(w, k, replacement=False, generator=gen)          # [A, k] nodes < t
+                use = (torch.arange(k, device=device)[None, :] < torch.minimum(ma, torch.tensor(t, device=device))[:, None]) \
+                    & (t < na)[:, None]
+                a_i = ar[:, None].expand(A, k)[use]; s_i = tgt[use]
+                sub[a_i, s_i, t] = True
+                deg[a_i, s_i] += 1.0
+                deg[:, t] += use.sum(1).float()
+            keep[idx] = sub
+        keep &= upper[None] & (iu[None, None, :] < nn[:, None, None])
+        g, u, v = keep.nonzero(as_tuple=True)                         # sorted by (g, u, v)
+        counts.append(torch.bincount(g, minlength=C))
+        srcs.append(u.to(torch.int32)); dsts.append(v.to(torch.int32))
+    cat = lambda l: torch.cat(l).cpu().numpy()
+    return dict(node_counts=n.cpu().numpy().astype(np.int64), edge_counts=cat(counts).astype(np.int64),
+                src=cat(srcs).astype(np.int64), dst=cat(dsts).astype(np.int64), family=fam.cpu().numpy())

@@ -24,6 +24,7 @@
  *   gtok_parse_graph_text  graph_token_dataset_autograph.py:14-158 (text -> edges, query, label)
  *   gtok_find_token    the `<q>` search of trainer/train_ibtt.py:88-103 on a collated batch
  *   gtok_csr_pack8     (no reference counterpart) byte-packed mirror of the CSR index arrays of small-graph batches
+ *   gtok_vocab_stats_text   the corpus pass of build_vocab_from_texts / the ZINC dynamic-token scan over arbitrary texts
  *   gtok_vocab_stats_synth  the corpus pass of build_vocab_from_texts
  *                      (data_loader.py:451-463) for graph-token corpora held as
  *                      CSR: per node-id token, occurrence count and first position
@@ -249,6 +250,20 @@ int gtok_find_token(const int64_t *x, int32_t rows, int32_t ld, int64_t token, i
 int gtok_vocab_stats_synth(const gtok_csr *g, const int32_t *query_nodes,
                            int64_t graph_base, int32_t num_ids, int64_t *count,
                            int64_t *first, void *stream);
+
+/* The same corpus pass over ARBITRARY texts (any grammar: graph-token tasks, the ZINC strings whose unseen
+ * tokens become the dynamic vocab of trainer/train_ibtt.py:361-372): every distinct whitespace-separated token
+ * (str.split() rules) gets one slot of an open-addressing table of `capacity` slots (a power of two):
+ *   key[s]   64-bit identity of the token (two 32-bit hash streams; 0 = empty slot)
+ *   count[s] occurrences            first[s] base_offset + byte offset of the earliest occurrence in `bytes`
+ *   len[s]   token length in bytes  -> the token string is bytes[first - base_offset : .. + len]
+ * The caller zeroes key / count / len and sets first to INT64_MAX; calls ACCUMULATE (shards: pass the shard's
+ * offset in the whole corpus as base_offset so that `first` keeps ordering occurrences corpus-wide).  status
+ * (zeroed by the caller) gets bit 0 when the table overflowed: enlarge and repeat.  Counter.most_common order =
+ * count descending, then `first` ascending.                                                                    */
+int gtok_vocab_stats_text(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts, int64_t base_offset,
+                          int32_t capacity, uint64_t *key, int64_t *count, int64_t *first, int32_t *len,
+                          int32_t *status, void *stream);
 
 /* SENT decoder: un-remapped token rows (gtok_sent with remap_zinc = 0) -> graphs in visit-index space: node
  * k is the k-th node the trail visited.  Per row: num_nodes, num_edges, the edges in stream order - edge_a =

@@ -184,6 +184,25 @@ def vocab_stats_synth(coo: Coo, num_ids, query_nodes=None, graph_base=0):
     return count, first
 
 
+def vocab_stats_text(texts):
+    """[(token, count, first byte offset in the concatenated texts)] in Counter.most_common order - the corpus pass
+    of build_vocab_from_texts (data_loader.py:451-463: Counter.update(t.split()) text by text; most_common = count
+    descending, ties in first-insertion order).  Pure Python: small cases only."""
+    import re
+    from collections import Counter
+    counts, first, base = Counter(), {}, 0
+    for t in texts:
+        toks = t.split()
+        counts.update(toks)
+        # byte offsets of the tokens (ASCII texts: str.split() separators = the bytes py_isspace accepts)
+        pos = [m.start() for m in re.finditer(r"[^ \t\n\r\x0b\x0c\x1c\x1d\x1e\x1f]+", t)]
+        assert len(pos) == len(toks)
+        for tok, p in zip(toks, pos):
+            first.setdefault(tok, base + p)
+        base += len(t.encode())
+    return [(tok, c, first[tok]) for tok, c in counts.most_common()]
+
+
 def remap_zinc(ids, ln, idx_off, node_off, edge_off):
     ids = np.ascontiguousarray(ids, np.int32); ln = _i32(ln)
     out = np.empty_like(ids)

@@ -720,3 +720,92 @@ def test_batch_on_another_device_than_the_current_one():
     ids, ln = gtok.ops.ibtt_zinc(batch.to("cuda:1"), gtok.ops.zinc_lut(vocab, 40), 1024, vocab["<pad>"])
     ref, rln = orc.ibtt_zinc(coo, gtok.ops.zinc_lut(vocab, 40).numpy(), 1024, vocab["<pad>"], ids.shape[1])
     _cmp(ids, ln, ref, rln, "cuda:1 ibtt")
+
+
+def test_config5_family_mix_up_to_256_nodes():
+    """BASELINE config 5's families (er / ba / sbm / sfn / path / star / complete) at 10-256 nodes through the
+    large-graph kernels, plus the extremes the ER-only runs never reach: a 256-node star (one row of 255 entries), the
+    complete graph K256 (32,640 entries), a 256-node path.  SENT (LDS bit-matrix kernel), the IBTT graph-token grammar
+    and the vocab statistics, all bit-exact against the oracle; max_len 600 cuts the long rows (the hot truncation path)."""
+    mix = gtok.synth.mix_batch_device(140, DEV, seed=5)
+    assert sorted(set(mix["family"].tolist())) == list(range(7)) and int(mix["node_counts"].max()) > 200
+    n = 256
+    iu, iv = np.triu_indices(n, 1)
+    extremes = dict(node_counts=np.array([n, n, n, 3]), edge_counts=np.array([n - 1, iu.size, n - 1, 2]),
+                    src=np.concatenate([np.zeros(n - 1, np.int64), iu, np.arange(n - 1), [0, 1]]),
+                    dst=np.concatenate([np.arange(1, n), iv, np.arange(1, n), [1, 2]]))
+    for name, d in (("mix", mix), ("extremes", extremes)):
+        batch, coo = both(d, False)
+        assert 128 < batch.max_nodes <= 256
+        b = batch.to(DEV)
+        for max_len in (600, 100000 if name == "mix" else 70000):
+            ids, ln = gtok.ops.sent(b, 256, max_len, 9, 2)
+            assert gtok.ops.sent_kernel_name(b, 256, max_len).startswith("sent_lds_kernel<W=4>")
+            ref, rln = orc.sent(coo, 256, max_len, 9, 2, ld=ids.shape[1], nthreads=8)
+            _cmp(ids, ln, ref, rln, f"sent {name} max_len={max_len}")
+        vocab = {t: i for i, t in enumerate(["<pad>", "<bos>", "<e>", "<n>", "<q>", "<p>", "<eos>", "yes", "no", "has_cycle"]
+                                            + [str(i) for i in range(256)])}
+        lut = gtok.ops.synth_lut(vocab, 256)
+        q = np.zeros((batch.num_graphs, 4), np.int32); q[:, 0] = 1; q[:, 1] = vocab["has_cycle"]
+        ids, ln = gtok.ops.ibtt_synth(b, lut, torch.from_numpy(q), 600, 0)
+        ref, rln = orc.ibtt_synth(coo, lut.numpy(), q, 600, 0, ids.shape[1])
+        _cmp(ids, ln, ref, rln, f"ibtt_synth {name}")
+        c, f = gtok.ops.vocab_stats_synth(b, 256)
+        rc, rf = orc.vocab_stats_synth(coo, 256)
+        assert np.array_equal(c.cpu().numpy(), rc) and np.array_equal(f.cpu().numpy(), rf), name
+
+
+def test_vocab_from_texts_on_the_device():
+    """the corpus pass of build_vocab_from_texts (data_loader.py:451-463) and of the ZINC dynamic-token
+    scan (trainer/train_ibtt.py:361-372) over arbitrary texts, on the device.  Table entries == the oracle's
+    Counter-based restatement (token, count, first offset) in most_common order; vocab == the reference's (golden) for
+    every min_freq / max_tokens cut; ZINC: same token set as the reference's hash-seed-0 vocab, dynamic ids by first
+    appearance (the deterministic stand-in for the reference's `set` order)."""
+    from _util import config1_examples, golden, golden2
+    gdl = gtok.graph_data_loader
+    arr, meta = golden()
+    for c in meta["vocab_cases"]:                                  # ties, min_freq, max_tokens corner cases
+        v, itos = gdl.build_vocab_from_texts_on_device(c["texts"], min_freq=c["min_freq"], max_tokens=c["max_tokens"], device=DEV)
+        assert list(v.items()) == [tuple(p) for p in c["vocab"]] and itos == {i: t for t, i in v.items()}
+    for task in ("cycle_check", "shortest_path"):
+        texts = [e["text"] for e in config1_examples(task)]        # 1,002 graph-token records
+        blob, ptr = gtok.ops.pack_texts(texts)
+        table = gtok.ops.vocab_stats_text(blob.to(DEV), ptr, 1 << 12)
+        assert gtok.ops.text_stats_entries(table, blob.to(DEV)) == orc.vocab_stats_text(texts)
+        # accumulated over two shards (base_offset = the shard's byte offset) == one pass
+        half = len(texts) // 2
+        b1, p1 = gtok.ops.pack_texts(texts[:half]); b2, p2 = gtok.ops.pack_texts(texts[half:])
+        t2 = gtok.ops.vocab_stats_text(b1.to(DEV), p1, 1 << 12)
+        t2 = gtok.ops.vocab_stats_text(b2.to(DEV), p2, 1 << 12, base_offset=int(p1[-1]), out=t2)
+        assert gtok.ops.text_stats_entries(t2, blob.to(DEV)) == orc.vocab_stats_text(texts)
+        _, m2 = golden2()
+        for mf, mt in ((1, 600), (1, 40), (3, None), (50, 600)):
+            v, _ = gdl.build_vocab_from_texts_on_device(texts, min_freq=mf, max_tokens=mt, device=DEV)
+            want, _ = gdl.build_vocab_from_texts(texts, min_freq=mf, max_tokens=mt)
+            assert list(v.items()) == list(want.items())
+            if (mf, mt) == (1, 600):
+                assert list(v.items()) == [tuple(p) for p in m2[f"config1_{task}_vocab"]]   # the reference's own vocab
+    # a table that is too small says so
+    texts = [e["text"] for e in config1_examples("cycle_check")]
+    blob, ptr = gtok.ops.pack_texts(texts)
+    with pytest.raises(gtok.GtokError):
+        gtok.ops.text_stats_entries(gtok.ops.vocab_stats_text(blob.to(DEV), ptr, 16), blob.to(DEV))
+    # ZINC: fixed table + unseen tokens
+    ztexts = meta["zinc_L1024_texts"]
+    ref_vocab = dict(meta["zinc_L1024_vocab"])                     # the reference's, PYTHONHASHSEED=0 set order
+    v = gdl.build_zinc_vocab_on_device(ztexts, device=DEV)
+    fixed, _ = gdl.build_fixed_zinc_vocab()
+    assert set(v) == set(ref_vocab) and all(v[t] == i for t, i in fixed.items())
+    dyn = [t for t in v if t not in fixed]
+    assert [v[t] for t in dyn] == list(range(22, 22 + len(dyn)))
+    seen = []
+    for t in ztexts:
+        for tok in t.split():
+            if tok not in fixed and tok not in seen:
+                seen.append(tok)
+    assert dyn == seen                                              # first appearance order
+    # and the vocab it gives tokenizes the corpus to the reference's ids up to that permutation of the dynamic ids
+    ex = [{"text": t, "label": 0} for t in ztexts]
+    a = gdl.TokenDataset(ex, v, 1024); b = gdl.TokenDataset(ex, ref_vocab, 1024)
+    perm = {ref_vocab[t]: v[t] for t in v}
+    assert all([perm[int(x)] for x in sb] == sa.tolist() for sa, sb in zip(a.seqs, b.seqs))
