@@ -1,16 +1,18 @@
 #!/bin/bash
 # Collects the per-round evidence on the GPU box: bench JSON lines, rocprofv3 kernel stats, and the separate PMC
 # passes (FETCH_SIZE, WRITE_SIZE, SQ instruction mix, SQ waits) for both workloads.  Usage (from the repo root):
-#   gpurun --timeout 1200 -- 'bash profiles/tools/collect.sh r01'
+#   gpurun --timeout 1200 -- 'bash profiles/tools/collect.sh r02'
 # Everything lands in gpurun_out/collect_<tag>/; profiles/tools/collect_merge.py turns it into profiles/<tag>/.
 set -e -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/collect_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 B="python3 bench.py --steps 20 --warmup 3"
 timeout -k 10 400 $B > $out/bench_zinc_full.json 2> $out/bench_zinc_full.err
 timeout -k 10 400 $B --workload synth_er > $out/bench_synth_er.json 2> $out/bench_synth_er.err
+timeout -k 10 600 $B --workload synth_mix --no-cpu-baseline > $out/bench_synth_mix.json 2> $out/bench_synth_mix.err
+timeout -k 10 400 $B --workload zinc_subset > $out/bench_zinc_subset.json 2> $out/bench_zinc_subset.err
 for wl in zinc_full synth_er; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o s -- $B --workload $wl --no-cpu-baseline > $out/stats_$wl.log 2>&1
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS"; do

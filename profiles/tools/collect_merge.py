@@ -3,10 +3,15 @@ bench JSON lines, per-kernel stats CSVs, one PMC summary per workload, and profi
 (HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE KiB: gfx950 FETCH_SIZE counts half the fetched bytes,
 /opt/skills/guides/MI355X_MICROARCH.md, HBM section)."""
 import collections, csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+import subprocess
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 src, dst = f"gpurun_out/collect_{tag}", f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
 traffic = {}
+for extra in ("synth_mix", "zinc_subset"):
+    if os.path.exists(f"{src}/bench_{extra}.json"):
+        shutil.copy(f"{src}/bench_{extra}.json", f"{dst}/bench_{extra}_final.json")
 for wl in ("zinc_full", "synth_er"):
     shutil.copy(f"{src}/bench_{wl}.json", f"{dst}/bench_{wl}_final.json")
     for f in glob.glob(f"{src}/stats_{wl}/**/*_kernel_stats.csv", recursive=True):
@@ -34,7 +39,8 @@ for wl in ("zinc_full", "synth_er"):
         leg = "sent" if "sent" in k else ("ibtt" if "ibtt" in k else None)
         if leg:
             key = f"{leg}:{wl}:{G}:{mode}" if leg == "sent" else f"{leg}:{wl}:{G}"
+            label = bench["roofline"]["kernel"] if leg == "sent" else bench.get("ibtt", {}).get("kernel")
             traffic[key] = {"hbm_bytes_per_launch": c["hbm_bytes_per_launch"], "kernel": k.replace("void ", ""),
-                            "source": f"{dst}/pmc_summary_{wl}_final.json"}
+                            "kernel_label": label, "commit": commit, "source": f"{dst}/pmc_summary_{wl}_final.json"}
 json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
