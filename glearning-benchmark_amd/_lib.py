@@ -68,6 +68,7 @@ SYMBOLS = {
     "gtok_remap_zinc": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "gtok_collate": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     "gtok_parse_graph_text": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gtok_count_edge_tokens": (_I, [_P, _P, _I, _P, _P]),
     "gtok_find_token": (_I, [_P, _I, _I, ctypes.c_int64, _P, _P]),
     "gtok_vocab_stats_synth": (_I, [ctypes.POINTER(GtokCsr), _P, ctypes.c_int64, _I, _P, _P, _P]),
     "gtok_vocab_stats_text": (_I, [_P, _P, _I, ctypes.c_int64, _I, _P, _P, _P, _P, _P, _P]),

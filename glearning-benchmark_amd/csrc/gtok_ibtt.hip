@@ -1058,6 +1058,44 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
 // corner semantics, int() included, that are not worth a kernel).  Wave per text, 64 bytes per step, lane = byte.
 enum { T_INT = 0, T_BOS, T_E, T_N, T_Q, T_P, T_EOS, T_OTHER };
 constexpr int32_t kNoLabel = INT32_MIN;
+// ---------------------------------------------------------------------------------------------
+// number of `<e>` tokens per text = the number of edges of a text in the canonical graph-token form: the sizing pass
+// of gtok_parse_graph_text without the parse.  Streaming: every lane looks at 16 bytes (plus one byte before and three
+// after, overlapping loads) and tests the 16 positions for  [space|start] < e > [space|end].
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) count_edge_tokens_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ text_ptr,
+                                                                int num_texts, int32_t *__restrict__ num_edges) {
+  const int lane = lane_id();
+  const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave_id();
+  if (g >= num_texts) return;
+  const int64_t t0 = text_ptr[g], n = text_ptr[g + 1] - t0;
+  const uint8_t *__restrict__ s = bytes + t0;
+  int cnt = 0;
+  for (int64_t b0 = (int64_t)lane * 16; b0 < n; b0 += kWave * 16) {
+    uint32_t w[6];                                   // bytes b0-4 .. b0+19; outside the text = space
+    if (b0 >= 4 && b0 + 20 <= n) {
+      const U8x16 x = *reinterpret_cast<const U8x16 *>(s + b0);
+      __builtin_memcpy(&w[0], s + b0 - 4, 4);
+      w[1] = x.a; w[2] = x.b; w[3] = x.c; w[4] = x.d;
+      __builtin_memcpy(&w[5], s + b0 + 16, 4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int64_t i = b0 - 4 + 4 * k + j; v |= ((i >= 0 && i < n) ? (uint32_t)s[i] : 32u) << (8 * j); }
+        w[k] = v;
+      }
+    }
+    auto at = [&](int j) -> uint32_t { return (w[(j + 4) >> 2] >> (8 * ((j + 4) & 3))) & 255u; };   // byte b0 + j, j in -4..19
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      cnt += (at(j) == '<' && at(j + 1) == 'e' && at(j + 2) == '>' && py_isspace(at(j - 1)) && py_isspace(at(j + 3))) ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if (lane == 0) num_edges[g] = cnt;
+}
+
 struct ParseArgs {
   const uint8_t *bytes; const int64_t *text_ptr; int num_texts;
   const int64_t *edge_ptr; int32_t *src, *dst;   // pass 2 only (NULL in pass 1)
@@ -1066,8 +1104,22 @@ struct ParseArgs {
 };
 
 __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a) {
+  // the text travels through a 2 KB LDS ring per wave, 16 bytes per lane and load, the chunk after next in flight while
+  // the current one is split (a byte per lane straight from HBM, one piece ahead, left the waves waiting for memory half
+  // of the time)
+  __shared__ __align__(16) uint8_t ring_all[4][kTextRing];
   const int lane = lane_id();
   const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
+  uint8_t *ring = ring_all[wave];
+  U8x16a *ring16 = reinterpret_cast<U8x16a *>(ring);
+  const int64_t total = a.text_ptr[a.num_texts];
+  auto load16 = [&](int64_t abs) -> U8x16 {   // never touches bytes past the end of the blob
+    if (abs + 16 <= total) return *reinterpret_cast<const U8x16 *>(a.bytes + abs);
+    uint32_t w[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+    for (int b = 0; b < 16; ++b)
+      if (abs + b < total) w[b >> 2] = (w[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | ((uint32_t)a.bytes[abs + b] << (8 * (b & 3)));
+    return U8x16{w[0], w[1], w[2], w[3]};
+  };
   const bool fill = a.edge_ptr != nullptr;
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
@@ -1093,11 +1145,26 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
     bool prev_sp = true;
     // the token that runs into this piece: decimal value so far, length, "digits only so far"
     uint32_t carry_val = 0; int carry_len = 0; bool carry_dig = true;
-    uint32_t cnext = (lane < n) ? s[lane] : 32u;                  // pieces are loaded one ahead
+    const int64_t t0 = a.text_ptr[g];
+    wave_sync();                                                  // the previous text's last reads of the ring are done
+    {
+      const U8x16 x0 = load16(t0 + lane * 16), x1 = load16(t0 + kTextChunk + lane * 16);
+      ring16[lane] = U8x16a{x0.a, x0.b, x0.c, x0.d};
+      ring16[64 + lane] = U8x16a{x1.a, x1.b, x1.c, x1.d};
+    }
+    wave_sync();
+    U8x16 nxt = load16(t0 + kTextRing + lane * 16);               // chunk 2: lands while chunk 0 is split
     for (int64_t b0 = 0; b0 < n; b0 += kWave) {
+      if (b0 && (b0 & (kTextChunk - 1)) == 0) {                   // chunk b0/1024 - 1 is done: its half takes chunk + 1
+        const int64_t cdone = b0 / kTextChunk - 1;
+        wave_sync();
+        ring16[(cdone & 1) * 64 + lane] = U8x16a{nxt.a, nxt.b, nxt.c, nxt.d};
+        wave_sync();
+        nxt = load16(t0 + (cdone + 3) * kTextChunk + lane * 16);
+      }
       const int64_t i = b0 + lane;
-      const uint32_t c = cnext;
-      cnext = (i + kWave < n) ? s[i + kWave] : 32u;
+      const uint32_t c = i < n ? ring[i & (kTextRing - 1)] : 32u;
+      const uint32_t cnext = (i + kWave < n) ? ring[(i + kWave) & (kTextRing - 1)] : 32u;   // (lane 0's value: the byte after this piece)
       const bool sp = py_isspace(c);
       const uint64_t spm = __ballot(sp);
       const bool before = lane == 0 ? prev_sp : ((spm >> (lane - 1)) & 1ull);
@@ -1105,34 +1172,67 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
       const uint64_t sm = __ballot(!sp && before), em = __ballot(!sp && after);   // token starts / ends
       prev_sp = (spm >> 63) & 1ull;
       if ((~spm) == 0) continue;
-      // Integer tokens without a loop per token: x -> 10 x + digit is an affine map, and affine maps compose
-      // associatively, so one segmented scan over the lanes (segments = tokens) leaves every token's value at its
-      // last byte; "all digits" is a mask test over the token's lanes.
+      // Integer tokens without a loop per token.  Node ids have at most three digits: the value of the digits of a token
+      // that lie in this piece, up to this lane, comes from this byte and the two before it (wave shifts).  A longer run
+      // of digits anywhere in the piece (rare) takes the general route: x -> 10 x + digit is an affine map, affine maps
+      // compose associatively, so one segmented scan over the lanes (segments = tokens) leaves every token's value at
+      // its last byte.  "All digits" is a mask test over the token's lanes.
       const uint64_t le = (2ull << lane) - 1ull;
       const int seg_lo = (sm & le) ? 63 - __builtin_clzll(sm & le) : 0;
       const bool cont = !(sm & le);                                 // began in an earlier piece
       const bool isdig = c >= '0' && c <= '9';
       const uint64_t ndm = __ballot(!sp && !isdig);
-      uint32_t m = 10u, h = isdig ? c - '0' : 0u;
-#pragma unroll
-      for (int dsh = 1; dsh < kWave; dsh <<= 1) {
-        const uint32_t pm = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - dsh) << 2, (int)m);
-        const uint32_t ph = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - dsh) << 2, (int)h);
-        if (!sp && lane - dsh >= seg_lo) { h = ph * m + h; m = pm * m; }
-      }
+      // the two bytes before this one (tags are three bytes long)
+      const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x138, 0xf, 0xf, false);    // wave_shr:1
+      const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1, 0x138, 0xf, 0xf, false);
       int len = lane - seg_lo + 1;
       bool alldig = (ndm & le & ~((1ull << seg_lo) - 1ull)) == 0;
+      uint32_t m, h;
+      if (__ballot(!sp && alldig && len > 3) == 0) {
+        const uint32_t d0 = c - '0', d1 = p1 - '0', d2 = p2 - '0';
+        h = isdig ? d0 : 0u;
+        h += len >= 2 ? 10u * d1 : 0u;
+        h += len >= 3 ? 100u * d2 : 0u;
+        m = len >= 3 ? 1000u : (len == 2 ? 100u : 10u);
+      } else {
+        m = 10u; h = isdig ? c - '0' : 0u;
+#pragma unroll
+        for (int dsh = 1; dsh < kWave; dsh <<= 1) {
+          const uint32_t pm = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - dsh) << 2, (int)m);
+          const uint32_t ph = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - dsh) << 2, (int)h);
+          if (!sp && lane - dsh >= seg_lo) { h = ph * m + h; m = pm * m; }
+        }
+      }
       if (cont) { h = carry_val * m + h; len += carry_len; alldig = alldig && carry_dig; }
       const bool open = !((spm >> 63) & 1ull) && !((em >> 63) & 1ull);
-      carry_val = open ? (uint32_t)__builtin_amdgcn_readlane((int)h, 63) : 0u;
-      carry_len = open ? __builtin_amdgcn_readlane(len, 63) : 0;
-      carry_dig = open ? (bool)__builtin_amdgcn_readlane((int)alldig, 63) : true;
-      // the two bytes before this one (tags are three bytes long)
-      const uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 1) << 2, (int)c);
-      const uint32_t p2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 2) << 2, (int)c);
+      carry_val = 0u; carry_len = 0; carry_dig = true;
+      if (open) {
+        carry_val = (uint32_t)__builtin_amdgcn_readlane((int)h, 63);
+        carry_len = __builtin_amdgcn_readlane(len, 63);
+        carry_dig = (bool)__builtin_amdgcn_readlane((int)alldig, 63);
+      }
       if (em == 0) continue;
       const bool start = (em >> lane) & 1ull;                       // (a token END: the structure code below keys on it)
       const int t = count + __popcll(em & lanemask_lt());
+      // ---- the bulk of a text: pieces that lie wholly in the edge zone and hold nothing but integers and <e> tags
+      // (whole inside the piece).  One ballot decides; then only the triple check and the two stores remain.
+      if (tn < 0) {
+        const bool is_e = len == 3 && lane >= 2 && p2 == '<' && p1 == 'e' && c == '>';
+        const bool plain = !start || (alldig && len <= 9) || is_e;
+        if (__ballot(!plain) == 0 && count > 0) {                  // (token 0 must be <bos>: never plain)
+          if (start) {
+            const int r = (t - 1) % 3;
+            if (is_e != (r == 2)) bad = 1;
+            else if (r != 2) {
+              max_end = max(max_end, (int)h);
+              const int64_t k = (t - 1) / 3;
+              if (fill && k < ecap) { if (r == 0) a.src[ebase + k] = (int)h; else a.dst[ebase + k] = (int)h; }
+            }
+          }
+          count += __popcll(em);
+          continue;
+        }
+      }
       int type = T_OTHER, val = (int)h, lab = kNoLabel;
       bool is_sd = false;
       if (start) {
@@ -1599,6 +1699,17 @@ extern "C" int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len, 
     hipLaunchKernelGGL(collate_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, ld, len,
                        index, batch, pad_id, out_x, out_attn, out_ld);
   }
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_count_edge_tokens(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts, int32_t *num_edges,
+                                      void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (num_texts < 0) return GTOK_E_INVAL;
+  if (num_texts == 0) return GTOK_OK;
+  if (!bytes || !text_ptr || !num_edges) return GTOK_E_INVAL;
+  hipLaunchKernelGGL(count_edge_tokens_kernel, dim3((num_texts + 3) / 4), dim3(256), 0, (hipStream_t)stream, bytes, text_ptr, num_texts, num_edges);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 

@@ -230,18 +230,30 @@ def parse_graph_texts(text_bytes: torch.Tensor, text_ptr: torch.Tensor) -> Dict[
     i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
     ne, nn, q, lab, st = i32(G), i32(G), i32(G, 2), i32(G), i32(G)
     L = _lib.lib()
-    _lib.check(L.gtok_parse_graph_text(text_bytes.data_ptr(), text_ptr.data_ptr(), G, None, None, None, ne.data_ptr(),
-                                       nn.data_ptr(), q.data_ptr(), lab.data_ptr(), st.data_ptr(), _stream(dev)),
-               "gtok_parse_graph_text")
     edge_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(torch.where(st == 0, ne, torch.zeros_like(ne)).to(torch.int64), 0, out=edge_ptr[1:])
-    E = int(edge_ptr[-1]) if G else 0
-    src, dst = i32(max(E, 1)), i32(max(E, 1))
-    if G:
-        _lib.check(L.gtok_parse_graph_text(text_bytes.data_ptr(), text_ptr.data_ptr(), G, edge_ptr.data_ptr(), src.data_ptr(),
-                                           dst.data_ptr(), ne.data_ptr(), nn.data_ptr(), q.data_ptr(), lab.data_ptr(),
-                                           st.data_ptr(), _stream(dev)), "gtok_parse_graph_text")
-    return dict(num_edges=ne, num_nodes=nn, query=q, label=lab, status=st, edge_ptr=edge_ptr, src=src[:E], dst=dst[:E])
+    if not G:
+        return dict(num_edges=ne, num_nodes=nn, query=q, label=lab, status=st, edge_ptr=edge_ptr, src=i32(0), dst=i32(0))
+    # sizing: one streaming pass that counts the `<e>` tokens (exact for canonical texts), then ONE parse that fills
+    cnt = i32(G)
+    _lib.check(L.gtok_count_edge_tokens(text_bytes.data_ptr(), text_ptr.data_ptr(), G, cnt.data_ptr(), _stream(dev)),
+               "gtok_count_edge_tokens")
+    torch.cumsum(cnt.to(torch.int64), 0, out=edge_ptr[1:])
+    cap = int(edge_ptr[-1])
+    src, dst = i32(max(cap, 1)), i32(max(cap, 1))
+    _lib.check(L.gtok_parse_graph_text(text_bytes.data_ptr(), text_ptr.data_ptr(), G, edge_ptr.data_ptr(), src.data_ptr(),
+                                       dst.data_ptr(), ne.data_ptr(), nn.data_ptr(), q.data_ptr(), lab.data_ptr(),
+                                       st.data_ptr(), _stream(dev)), "gtok_parse_graph_text")
+    # every canonical text owns exactly its first num_edges slots; normally that is its whole range (one `<e>` token per
+    # edge).  Texts outside the grammar (status != 0) own nothing, and a canonical text may carry a stray `<e>` where the
+    # grammar allows any word (right after <q> / <p>): then the ranges are squeezed.
+    keep = torch.where(st == 0, ne, torch.zeros_like(ne)).to(torch.int64)
+    if bool((keep == cnt.to(torch.int64)).all()):
+        return dict(num_edges=ne, num_nodes=nn, query=q, label=lab, status=st, edge_ptr=edge_ptr, src=src[:cap], dst=dst[:cap])
+    new_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(keep, 0, out=new_ptr[1:])
+    total = int(new_ptr[-1])
+    idx = torch.repeat_interleave(edge_ptr[:-1] - new_ptr[:-1], keep, output_size=total) + torch.arange(total, device=dev)
+    return dict(num_edges=ne, num_nodes=nn, query=q, label=lab, status=st, edge_ptr=new_ptr, src=src[idx], dst=dst[idx])
 
 
 def find_token(x: torch.Tensor, token: int) -> torch.Tensor:
