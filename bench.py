@@ -157,6 +157,13 @@ def main():
     if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
+    # beside the headline: the same steps with GTOK_SENT_NO_PAD (rows written up to their length only - what
+    # TokenizedGraphDataset uses, its readers go through `len`); not the headline because the C ABI's documented output is the padded slab
+    nopad_ms = None
+    if zinc:
+        _, npm = timed_loop(lambda k: gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=args.warmup + k, ld=ld, out=(ids, scratch_len), pad=False, **kw),
+                            args.steps, multi, per_launch_events=False)
+        nopad_ms = float(np.mean(npm))
 
     all_len = torch.stack(lens)
     if int(all_len.max().item()) > ld:
@@ -199,6 +206,9 @@ def main():
                            slab_width=ld, slab_width_mode=args.ld, avg_tokens_per_graph=round(tokens_per_step_rank / G, 2),
                            parallelism=f"graph-sharded x{world}, no data-path collective"),
                roofline=roofline)
+    if nopad_ms is not None:
+        out["unpadded_rows"] = dict(ms_per_step=round(nopad_ms, 4), graphs_per_sec=round(G / nopad_ms * 1e3, 1),
+                                    note="GTOK_SENT_NO_PAD: tokens only, pad tails of the slab not written")
 
     # IBTT serialiser on the same corpus (second half of the metric; outside the timed region)
     if not args.no_ibtt:

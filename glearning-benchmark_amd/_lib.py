@@ -36,6 +36,7 @@ class GtokCsr(ctypes.Structure):
 
 
 CSR_SIMPLE_SYMMETRIC = 1
+SENT_NO_PAD = 1
 
 
 class GtokVocabTable(ctypes.Structure):
@@ -51,7 +52,7 @@ class GtokSentParams(ctypes.Structure):
         ("max_num_nodes", ctypes.c_int32), ("labeled", ctypes.c_int32),
         ("num_node_types", ctypes.c_int32), ("num_edge_types", ctypes.c_int32),
         ("max_len", ctypes.c_int32), ("remap_zinc", ctypes.c_int32),
-        ("pad_id", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("pad_id", ctypes.c_int32), ("flags", ctypes.c_int32),
         ("seed", ctypes.c_uint64), ("epoch", ctypes.c_uint64),
         ("graph_base", ctypes.c_int64), ("query", ctypes.c_void_p),
     ]

@@ -58,8 +58,10 @@ class TokenizedGraphDataset(Dataset):
     def tokenize_epoch(self, epoch: int):
         """(ids int32 [G, ld], len int32 [G]) on the device for `epoch`; also what __getitem__ serves from."""
         batch = self._graphs()
+        # every reader of the slab goes through the lengths (items are cut at len, gtok_collate pads per batch as the
+        # reference's collate_fn does): the pad tails - more than half of a ZINC slab - are not written
         self._ids, self._lens = self.tokenizer.tokenize_batch(batch, epoch=epoch, remap_zinc=self.remap_to_fixed_vocab,
-                                                              query=self._query)
+                                                              query=self._query, pad=False)
         self._epoch, self._ids_h, self._lens_h = epoch, None, None
         self._served = np.zeros(len(self), bool)
         return self._ids, self._lens

@@ -77,13 +77,14 @@ class Graph2TrailTokenizer:
 
     # ---- batched fast path: one launch for a whole split / epoch
     def tokenize_batch(self, batch: "GraphBatch", epoch: int = 0, graph_base: int = 0, remap_zinc: bool = False,
-                       query: Optional[torch.Tensor] = None, ld: Optional[int] = None, out=None):
-        """(ids int32 [G, ld], len int32 [G]) on the device; trail g is a function of (seed, epoch, graph_base+g)."""
+                       query: Optional[torch.Tensor] = None, ld: Optional[int] = None, out=None, pad: bool = True):
+        """(ids int32 [G, ld], len int32 [G]) on the device; trail g is a function of (seed, epoch, graph_base+g).
+        pad=False: rows are only written up to their length (consumers that read through `len`: ops.collate)."""
         if self.max_num_nodes is None:
             raise RuntimeError("call set_num_nodes() first")
         return _ops.sent(batch, self.max_num_nodes, self._max_len(), self.seed, epoch, labeled=self.labeled_graph,
                          num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
-                         remap_zinc=remap_zinc, pad_id=self.pad, graph_base=graph_base, query=query, ld=ld, out=out)
+                         remap_zinc=remap_zinc, pad_id=self.pad, graph_base=graph_base, query=query, ld=ld, out=out, pad=pad)
 
     # ---- reference call site: one Data in, one 1-D LongTensor out, a fresh random trail per call
     def tokenize(self, data) -> torch.Tensor:

@@ -210,7 +210,9 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
   const int stride = (int)gridDim.x;
   int lw = 0, done_g0 = -1;                 // pad start of this lane's finished row / first graph of the finished unit
   // pad the tails of a finished unit's 64 rows: four rows per pass, 16 lanes x 16-byte stores on each
+  const bool no_pad = (a.p.flags & GTOK_SENT_NO_PAD) != 0;
   auto pad_rows = [&]() __attribute__((always_inline)) {
+    if (no_pad) return;
     const int q = lane & 15;
     for (int it = 0; it < 16; ++it) {
       const int r = it * 4 + (lane >> 4);

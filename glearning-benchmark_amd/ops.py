@@ -134,8 +134,10 @@ def pack8(batch: GraphBatch) -> bool:
 def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: int = 0, labeled: bool = False,
          num_node_types: int = 0, num_edge_types: int = 0, remap_zinc: bool = False, pad_id: int = SENT_PAD,
          graph_base: int = 0, query: Optional[torch.Tensor] = None,
-         ld: Optional[int] = None, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """SENT trail walk.  Returns (ids int32 [G, ld], len int32 [G]); len > ld flags a too-narrow slab."""
+         ld: Optional[int] = None, out=None, pad: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """SENT trail walk.  Returns (ids int32 [G, ld], len int32 [G]); len > ld flags a too-narrow slab.
+    pad=False (GTOK_SENT_NO_PAD): rows are only written up to their length - for consumers that go through `len`
+    (ops.collate does); the rest of the slab keeps whatever it held."""
     _need_gpu(batch.col, "sent")
     dev = batch.device
     if query is not None:
@@ -147,7 +149,7 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
     ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
     pack8(batch)
     p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc),
-                       pad_id, 0, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
+                       pad_id, 0 if pad else _lib.SENT_NO_PAD, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
                        None if query is None else query.data_ptr())
     cs = batch.c_struct()
     check(lib().gtok_sent(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)),

@@ -179,6 +179,11 @@ int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr,
 #define GTOK_SENT_PAD 5
 #define GTOK_SENT_IDX_OFFSET 6
 
+/* gtok_sent_params.flags */
+#define GTOK_SENT_NO_PAD 1 /* rows are only guaranteed up to out_len[g] (rounded up to a multiple of 16 ids); the pad tails -
+                              56 % of a ZINC slab - may be left unwritten.  For callers that read rows through out_len
+                              anyway (gtok_collate pads per batch, as both reference collates do).                  */
+
 typedef struct gtok_sent_params {
   int32_t max_num_nodes;  /* tokenizer.set_num_nodes()                      */
   int32_t labeled;        /* labeled_graph: emit node/edge type tokens      */
@@ -187,7 +192,7 @@ typedef struct gtok_sent_params {
   int32_t max_len;        /* max_length == truncation_length                */
   int32_t remap_zinc;     /* fuse TokenizedGraphDataset.remap_zinc_tokens   */
   int32_t pad_id;         /* slab fill (Graph2TrailTokenizer.pad = 5)       */
-  int32_t reserved;
+  int32_t flags;          /* GTOK_SENT_* (0 = the documented output convention) */
   uint64_t seed;          /* Philox key                                     */
   uint64_t epoch;         /* a new trail every epoch                        */
   int64_t graph_base;     /* global index of graph 0 (shard-invariant RNG)  */

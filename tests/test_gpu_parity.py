@@ -811,3 +811,27 @@ def test_vocab_from_texts_on_the_device():
     a = gdl.TokenDataset(ex, v, 1024); b = gdl.TokenDataset(ex, ref_vocab, 1024)
     perm = {ref_vocab[t]: v[t] for t in v}
     assert all([perm[int(x)] for x in sb] == sa.tolist() for sa, sb in zip(a.seqs, b.seqs))
+
+
+def test_sent_without_padding_writes_the_same_rows():
+    """GTOK_SENT_NO_PAD: every row equals the padded run up to its length; what lies beyond is left alone (checked
+    against a sentinel for the rows' far ends), lengths are identical.  TokenizedGraphDataset tokenizes this way."""
+    d = gtok.synth.zinc_like(40000, seed=93)
+    batch, coo = both(d)
+    b = batch.to(DEV)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ld = gtok.ops.sent_safe_ld(batch, True, 1024)
+    ids, ln = gtok.ops.sent(b, 37, 1024, 4, 6, ld=ld, **kw)
+    assert gtok.ops.sent_kernel_name(b, 37, 1024, **kw) == "sent_lane_kernel"
+    raw = torch.full((40000, ld), -9, dtype=torch.int32, device=DEV)
+    ln2 = torch.empty(40000, dtype=torch.int32, device=DEV)
+    gtok.ops.sent(b, 37, 1024, 4, 6, ld=ld, out=(raw, ln2), pad=False, **kw)
+    assert torch.equal(ln, ln2)
+    col = torch.arange(ld, device=DEV)[None, :]
+    inside = col < ln[:, None]
+    assert torch.equal(torch.where(inside, raw, 0), torch.where(inside, ids, 0))
+    far = col >= ((ln[:, None] + 15) // 16) * 16
+    assert bool((raw[far] == -9).all())
+    X, A = gtok.ops.collate(raw, ln2, torch.arange(128, device=DEV), 5, int(ln2[:128].max()))
+    X0, A0 = gtok.ops.collate(ids, ln, torch.arange(128, device=DEV), 5, int(ln[:128].max()))
+    assert torch.equal(X, X0) and torch.equal(A, A0)
