@@ -116,7 +116,14 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
     uint64_t curw = 0;                           // word wl of the set {cur}
     const int rem_n = n - wl * 64;
     const uint64_t validw = rem_n >= 64 ? ~0ull : (rem_n > 0 ? ((1ull << rem_n) - 1ull) : 0ull);
-    int pos = 1, d = 0, nvis = 0, cur = 0;
+    // One scalar unit serves the CU's four SIMDs, and this kernel issues about as many scalar as vector instructions
+    // (4.4 k vs 4.7 k per graph: the scalar pipe, not the vector pipes, is what fills up).  The token cursor only
+    // feeds LDS addresses, so it lives in a VECTOR register (the same value in every lane, seeded from an opaque
+    // zero so that the compiler does not move it back): its arithmetic leaves the scalar pipe.
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    int pos = vz + 1;
+    int d = 0, nvis = 0, cur = 0;
 
     auto below = [&](uint32_t nchoices) -> uint32_t {
       const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)R, d & 63);
@@ -222,7 +229,7 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
     if (n > 0) {
       cur = (int)below((uint32_t)n);
       uint64_t rowc = visit(cur, -1);   // adjacency row of cur, word wl
-      while (pos < lim) {
+      while (uni(pos) < lim) {
         {   // extend the trail over an uncovered edge (always towards an unvisited node)
           const uint64_t cand = rowc & ~vis;
           const int c = __popcll(cand), incl = prefix(c), cnt = total_of(incl);
@@ -286,7 +293,7 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
     const uint64_t ts3 = __builtin_amdgcn_s_memtime();
 #endif
     // ---- row out
-    const int ltrail = min(pos, lim);
+    const int ltrail = min(uni(pos), lim);
     int len = ltrail;
     if (a.p.query) {  // trainer/train_agtt.py:257-267: after the trail, original node ids, not remapped
       if (lane < 3)

@@ -835,3 +835,46 @@ def test_sent_without_padding_writes_the_same_rows():
     X, A = gtok.ops.collate(raw, ln2, torch.arange(128, device=DEV), 5, int(ln2[:128].max()))
     X0, A0 = gtok.ops.collate(ids, ln, torch.arange(128, device=DEV), 5, int(ln[:128].max()))
     assert torch.equal(X, X0) and torch.equal(A, A0)
+
+
+@pytest.mark.parametrize("pin", ["lane", "lane-int32"])
+def test_lane_kernel_many_units_per_wave_and_chunks_beyond_the_staging_registers(pin, monkeypatch):
+    """Two paths of sent_lane_kernel the big corpora never take (ZINC-full gives every wave exactly one unit whose chunk
+    fits the staging registers): (1) a grid smaller than the number of 64-graph units (GTOK_LANE_BLOCKS_PER_CU=1: 256
+    waves for 625 units) - waves loop over units, padding the previous unit's rows behind the next unit's loads;
+    (2) units of dense 60-64-node graphs with ~250 entries each (16 k entries per unit) - the staging tail loops beyond
+    the register-held vectors, counter planes P = 6 (degree up to 63), rows longer than four entries everywhere."""
+    _pin_sent(monkeypatch, pin)
+    monkeypatch.setenv("GTOK_LANE_BLOCKS_PER_CU", "1")
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    d = gtok.synth.zinc_like(40000, seed=95)
+    batch, coo = both(d)
+    for max_len in (1024, 57):
+        ids, ln = gtok.ops.sent(batch.to(DEV), 37, max_len, 8, 3, **kw)
+        ref, rln = orc.sent(coo, 37, max_len, 8, 3, ld=ids.shape[1], nthreads=8, **kw)
+        _cmp(ids, ln, ref, rln, f"many units per wave [{pin}] max_len={max_len}")
+    monkeypatch.delenv("GTOK_LANE_BLOCKS_PER_CU")
+    dense = _rings_with_chords([64, 63, 62, 61, 60, 64, 64, 33] * 25, 60, seed=5)      # 200 graphs, ~3 units, up to 248 entries each
+    # one hub per graph (node 3 tied to every third node): degrees past 15 -> six counter planes, long rows
+    nptr = np.concatenate([[0], np.cumsum(dense["node_counts"])]); eptr = np.concatenate([[0], np.cumsum(dense["edge_counts"])])
+    srcs, dsts, ecs = [], [], []
+    for g, n in enumerate(dense["node_counts"]):
+        pairs = set(zip(dense["src"][eptr[g]:eptr[g + 1]].tolist(), dense["dst"][eptr[g]:eptr[g + 1]].tolist()))
+        pairs = {(a, b) for a, b in pairs if a < b and len(pairs) and (a, b) in pairs}
+        keep = sorted(pairs)[:90]                                   # room for the hub inside the 255-entry limit
+        hub = {(min(3, j), max(3, j)) for j in range(0, int(n), 3) if j != 3}
+        e = np.array(sorted(set(keep) | hub), np.int64).reshape(-1, 2)
+        s_ = np.concatenate([e[:, 0], e[:, 1]]); t_ = np.concatenate([e[:, 1], e[:, 0]])
+        o = np.lexsort((t_, s_))
+        srcs.append(s_[o]); dsts.append(t_[o]); ecs.append(s_.size)
+    dense = dict(dense, edge_counts=np.array(ecs), src=np.concatenate(srcs), dst=np.concatenate(dsts))
+    dense["edge_attr"] = np.minimum(dense["src"], dense["dst"]) % 7
+    assert int(dense["edge_counts"].max()) <= 255
+    for labeled in (True, False):
+        b2, c2 = both(dense, labeled)
+        assert b2.max_degree > 15 and b2.flags & 1
+        kw2 = dict(labeled=labeled, num_node_types=28 if labeled else 0, num_edge_types=5 if labeled else 0)
+        for max_len in (4096, 300):
+            ids, ln = gtok.ops.sent(b2.to(DEV), 64, max_len, 2, 9, **kw2)
+            ref, rln = orc.sent(c2, 64, max_len, 2, 9, ld=ids.shape[1], **kw2)
+            _cmp(ids, ln, ref, rln, f"dense units [{pin}] labeled={labeled} max_len={max_len}")
