@@ -237,8 +237,14 @@ def test_torch_custom_ops():
     raw, rl = gtok.ops.sent(b, 37, 1024, 3, 1, labeled=True, num_node_types=9, num_edge_types=4)
     dd = gtok.ops.sent_decode(raw, rl, 37, True, 9, 64, 37)
     td = torch.ops.gtok.sent_decode(raw, rl, 37, True, 9, 64, 37)
-    for got, key in zip(td, ("num_nodes", "num_edges", "status", "edge_a", "edge_b", "edge_type", "node_type")):
-        assert torch.equal(got, dd[key]), key
+    td = dict(zip(("num_nodes", "num_edges", "status", "edge_a", "edge_b", "edge_type", "node_type"), td))
+    for key in ("num_nodes", "num_edges", "status"):
+        assert torch.equal(td[key], dd[key]), key
+    em = torch.arange(64, device=DEV)[None, :] < dd["num_edges"][:, None]       # slots past the counts are not written
+    nm = torch.arange(37, device=DEV)[None, :] < dd["num_nodes"][:, None]
+    for key in ("edge_a", "edge_b", "edge_type"):
+        assert torch.equal(td[key][em], dd[key][em]), key
+    assert torch.equal(td["node_type"][nm], dd["node_type"][nm])
     s = gtok.synth.graph_token_like(200, seed=74, with_text=False)
     sb, _ = both(s, False)
     sb = sb.to(DEV)
