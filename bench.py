@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None, help="graphs in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ibtt", action="store_true")
+    ap.add_argument("--no-unpadded", action="store_true", help="skip the GTOK_SENT_NO_PAD leg (profiling runs: one launch flavour per kernel name)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,7 +161,7 @@ def main():
     # beside the headline: the same steps with GTOK_SENT_NO_PAD (rows written up to their length only - what
     # TokenizedGraphDataset uses, its readers go through `len`); not the headline because the C ABI's documented output is the padded slab
     nopad_ms = None
-    if zinc:
+    if zinc and not args.no_unpadded:
         _, npm = timed_loop(lambda k: gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=args.warmup + k, ld=ld, out=(ids, scratch_len), pad=False, **kw),
                             args.steps, multi, per_launch_events=False)
         nopad_ms = float(np.mean(npm))
