@@ -884,3 +884,32 @@ def test_lane_kernel_many_units_per_wave_and_chunks_beyond_the_staging_registers
             ids, ln = gtok.ops.sent(b2.to(DEV), 64, max_len, 2, 9, **kw2)
             ref, rln = orc.sent(c2, 64, max_len, 2, 9, ld=ids.shape[1], **kw2)
             _cmp(ids, ln, ref, rln, f"dense units [{pin}] labeled={labeled} max_len={max_len}")
+
+
+@pytest.mark.parametrize("pin", ["lane", "lane-int32", "reg"])
+def test_lane_kernel_row_ends_query_tail_cuts_and_odd_slabs(pin, monkeypatch):
+    """Everything sent_lane_kernel does at the END of a row, on graphs it accepts (symmetric molecules): the query tail
+    (labelled and unlabelled, remapped or not), rows cut by max_len at every phase of the 4-token window and of the
+    store burst, slabs narrower than the rows (len > ld), slab widths that are not multiples of 4 or 16 (element-wise
+    stores instead of the 16-byte ones), and GTOK_SENT_NO_PAD on top.  The reg kernel runs the same matrix."""
+    _pin_sent(monkeypatch, pin)
+    d = gtok.synth.zinc_like(700, seed=97)
+    rng = np.random.default_rng(3)
+    q = np.stack([rng.integers(0, d["node_counts"]), rng.integers(0, d["node_counts"])], 1).astype(np.int32)
+    for labeled, remap in ((True, True), (True, False), (False, False)):
+        batch, coo = both(d, labeled)
+        b = batch.to(DEV)
+        kw = dict(labeled=labeled, num_node_types=9 if labeled else 0, num_edge_types=4 if labeled else 0, remap_zinc=remap)
+        for max_len, ld in ((1024, None), (1024, 64), (1024, 61), (1024, 203), (33, None), (34, 48), (35, 41), (36, 36), (37, 20),
+                            (5, 8), (2, 4), (1, 7), (0, 4), (90, 96), (91, 91)):
+            for query in (None, q):
+                kwq = dict(kw, query=None if query is None else torch.from_numpy(query))
+                ids, ln = gtok.ops.sent(b, 37, max_len, 13, 4, ld=ld, **kwq)
+                ref, rln = orc.sent(coo, 37, max_len, 13, 4, ld=ids.shape[1], query=query, **kw)
+                _cmp(ids, ln, ref, rln, f"[{pin}] labeled={labeled} remap={remap} max_len={max_len} ld={ld} query={query is not None}")
+        # rows without padding: equal inside their lengths
+        raw = torch.full((700, 208), -3, dtype=torch.int32, device=DEV); l2 = torch.empty(700, dtype=torch.int32, device=DEV)
+        gtok.ops.sent(b, 37, 1024, 13, 4, ld=208, out=(raw, l2), pad=False, query=torch.from_numpy(q), **kw)
+        ref, rln = orc.sent(coo, 37, 1024, 13, 4, ld=208, query=q, **kw)
+        inside = np.arange(208)[None, :] < rln[:, None]
+        assert np.array_equal(l2.cpu().numpy(), rln) and np.array_equal(np.where(inside, raw.cpu().numpy(), 0), np.where(inside, ref, 0))
