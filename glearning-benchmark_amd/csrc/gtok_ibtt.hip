@@ -396,7 +396,8 @@ struct ZincQuadArgs {
 // GS = lanes per molecule (16 or 8): 64 / GS molecules per wave.  Eight lanes halve the instructions per molecule
 // (a molecule's ~50 entries fill 7 passes of 8 lanes instead of 4 passes of 16 with a third of the lanes idle) as
 // long as the molecules are small; NP / EP = node / entry passes whose loads travel through the register pipeline.
-template <bool ROWS, int GS>
+// PK: row pointers and neighbour ids come from the batch's byte mirror (gtok_csr.rowptr8 / col8): a quarter of the index bytes
+template <bool ROWS, int GS, bool PK>
 __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a) {
   constexpr int NG = kWave / GS, NP = GS == 16 ? 4 : 6, EP = GS == 16 ? 8 : 12;
   constexpr uint32_t kGroupBits = (1u << GS) - 1u;
@@ -438,17 +439,18 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
     Dat d;
     const int g = (unit < u1 && unit * NG + grp < G) ? unit * NG + grp : 0;   // idle groups read graph 0's first words
     const int32_t *__restrict__ rp = a.g.rowptr + h.nb0 + g;
+    const uint8_t *__restrict__ rp8 = PK ? a.g.rowptr8 + h.nb0 + g : nullptr;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int i = ql + GS * j;
-      d.rs[j] = rp[min(i, h.n)];
-      d.re[j] = rp[min(i + 1, h.n)];
+      d.rs[j] = PK ? (int)rp8[min(i, h.n)] : rp[min(i, h.n)];
+      d.re[j] = PK ? (int)rp8[min(i + 1, h.n)] : rp[min(i + 1, h.n)];
       d.x[j] = ld_na ? (int)a.g.nattr[min(max(h.nb0 + min(i, h.n - 1), 0), Ntot - 1)] : 255;
     }
 #pragma unroll
     for (int j = 0; j < EP; ++j) {
       const int64_t k = min(max(h.e0 + min(ql + GS * j, h.e - 1), (int64_t)0), Etot - 1);
-      d.v[j] = ld_col ? a.g.col[k] : 0;
+      d.v[j] = ld_col ? (PK ? (int)a.g.col8[k] : a.g.col[k]) : 0;
       d.at[j] = ld_ea ? (int)a.g.eattr[k] : 0;
     }
     return d;
@@ -1470,8 +1472,11 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
     if (rows) off += 4 * ng * ld;
     q.lds = off;
     typedef void (*K)(const ZincQuadArgs);
-    K kern = gs == 8 ? (rows ? (K)ibtt_zinc_quad_kernel<true, 8> : (K)ibtt_zinc_quad_kernel<false, 8>)
-                     : (rows ? (K)ibtt_zinc_quad_kernel<true, 16> : (K)ibtt_zinc_quad_kernel<false, 16>);
+    const bool pk = g->rowptr8 && g->col8;
+    K kern = pk ? (gs == 8 ? (rows ? (K)ibtt_zinc_quad_kernel<true, 8, true> : (K)ibtt_zinc_quad_kernel<false, 8, true>)
+                           : (rows ? (K)ibtt_zinc_quad_kernel<true, 16, true> : (K)ibtt_zinc_quad_kernel<false, 16, true>))
+                : (gs == 8 ? (rows ? (K)ibtt_zinc_quad_kernel<true, 8, false> : (K)ibtt_zinc_quad_kernel<false, 8, false>)
+                           : (rows ? (K)ibtt_zinc_quad_kernel<true, 16, false> : (K)ibtt_zinc_quad_kernel<false, 16, false>));
     int dev = 0, ncu = 256, occ = 1;
     if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);

@@ -76,6 +76,7 @@ def ibtt_zinc(batch: GraphBatch, lut: torch.Tensor, max_len: int, pad_id: int,
     if ld is None:
         ld = _round4(min(max_len, 4 + 2 * batch.max_nodes + 4 * batch.max_edges))
     ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
+    pack8(batch)
     cs = batch.c_struct()
     check(lib().gtok_ibtt_zinc(ctypes.byref(cs), lut.data_ptr(), lut.numel(), max_len, pad_id,
                                ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)), "gtok_ibtt_zinc")
