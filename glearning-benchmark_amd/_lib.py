@@ -12,7 +12,7 @@ _ROOT = os.path.dirname(_HERE)
 # GTOK_LIB: load another build of the same ABI (profiling builds of profiles/tools, e.g. -DGTOK_PHASE_TIMING)
 LIB_PATH = os.environ.get("GTOK_LIB") or os.path.join(_HERE, "csrc", "libgtok.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("gtok_sent.hip", "gtok_ibtt.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "gtok_common.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_reg.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_lds.hpp"),
+HEADERS = [os.path.join(_HERE, "csrc", "gtok_common.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_blane.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_reg.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_lds.hpp"),
            os.path.join(_HERE, "csrc", "gtok_sent_lane.hpp"),
            os.path.join(_ROOT, "include", "gtok.h")]
 
@@ -32,6 +32,8 @@ class GtokCsr(ctypes.Structure):
         ("chunk_nodes", ctypes.c_int32), ("chunk_edges", ctypes.c_int32),
         ("max_degree", ctypes.c_int32), ("reserved", ctypes.c_int32),
         ("rowptr8", ctypes.c_void_p), ("col8", ctypes.c_void_p),
+        ("adj_rows", ctypes.c_void_p), ("adj_planes", ctypes.c_void_p), ("lane_order", ctypes.c_void_p),
+        ("adj_words", ctypes.c_int32), ("adj_max_degree", ctypes.c_int32),
     ]
 
 
@@ -73,6 +75,7 @@ SYMBOLS = {
     "gtok_find_token": (_I, [_P, _I, _I, ctypes.c_int64, _P, _P]),
     "gtok_vocab_stats_synth": (_I, [ctypes.POINTER(GtokCsr), _P, ctypes.c_int64, _I, _P, _P, _P]),
     "gtok_vocab_stats_text": (_I, [_P, _P, _I, ctypes.c_int64, _I, _P, _P, _P, _P, _P, _P]),
+    "gtok_csr_adjbits": (_I, [ctypes.POINTER(GtokCsr), _I, _P, _P, _P, _P]),
     "gtok_csr_pack8": (_I, [ctypes.POINTER(GtokCsr), ctypes.c_int64, ctypes.c_int64, _P, _P, _P]),
     "gtok_sent_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(GtokCsr), ctypes.POINTER(GtokSentParams)]),
     "gtok_ibtt_zinc_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(GtokCsr)]),

@@ -61,6 +61,11 @@ class GraphBatch:
     max_degree: int = 0               # longest CSR row (an upper bound is fine); 0 = unknown
     rowptr8: Optional[torch.Tensor] = None   # uint8 mirrors of rowptr / col (device batches of small graphs:
     col8: Optional[torch.Tensor] = None      # ops.pack8, once per resident batch)
+    adj_rows: Optional[torch.Tensor] = None      # adjacency bit-matrix mirror (ops.adjbits, once per resident batch):
+    adj_planes: Optional[torch.Tensor] = None    # int64 [sum N, W] rows, int64 [G, 8, W] degree bit planes,
+    lane_order: Optional[torch.Tensor] = None    # int32 [G] graphs in the order they are dealt to lanes
+    adj_words: int = 0
+    adj_max_degree: int = 0
 
     @property
     def device(self) -> torch.device:
@@ -78,13 +83,15 @@ class GraphBatch:
         mv = lambda t: None if t is None else t.to(device, non_blocking=True)
         return GraphBatch(self.num_graphs, self.max_nodes, self.max_edges, mv(self.node_ptr), mv(self.edge_ptr),
                           mv(self.rowptr), mv(self.col), mv(self.eorder), mv(self.nattr), mv(self.eattr),
-                          self.flags, self.chunk_nodes, self.chunk_edges, self.max_degree, mv(self.rowptr8), mv(self.col8))
+                          self.flags, self.chunk_nodes, self.chunk_edges, self.max_degree, mv(self.rowptr8), mv(self.col8),
+                          mv(self.adj_rows), mv(self.adj_planes), mv(self.lane_order), self.adj_words, self.adj_max_degree)
 
     def c_struct(self) -> GtokCsr:
         p = lambda t: None if t is None else t.data_ptr()
         return GtokCsr(self.num_graphs, self.max_nodes, self.max_edges, self.flags, p(self.node_ptr), p(self.edge_ptr),
                        p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr),
-                       self.chunk_nodes, self.chunk_edges, self.max_degree, 0, p(self.rowptr8), p(self.col8))
+                       self.chunk_nodes, self.chunk_edges, self.max_degree, 0, p(self.rowptr8), p(self.col8),
+                       p(self.adj_rows), p(self.adj_planes), p(self.lane_order), self.adj_words, self.adj_max_degree)
 
     def node_counts(self) -> torch.Tensor:
         return self.node_ptr[1:] - self.node_ptr[:-1]

@@ -20,6 +20,7 @@
 #include "gtok_sent_reg.hpp"
 #include "gtok_sent_lds.hpp"
 #include "gtok_sent_lane.hpp"
+#include "gtok_sent_blane.hpp"
 
 namespace gtok {
 
@@ -29,13 +30,20 @@ constexpr int GTOK_LANE_MIN_GRAPHS = 28000;     // measured crossover on ZINC-sh
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 
-// 0 = lane-per-graph, 1 = register-resident wave-per-graph, 2 = LDS bit matrix.  GTOK_SENT_KERNEL=lane|reg|lds
-// pins a kernel where it is applicable (tests run every path).
+// below this many graphs the bit-matrix lane kernel cannot fill the chip either (measured crossover, 10-256-node graphs)
+constexpr int GTOK_BLANE_MIN_GRAPHS = 4096;
+
+// 0 = lane-per-graph, 1 = register-resident wave-per-graph, 2 = LDS bit matrix, 3 = lane-per-graph over the adjacency
+// bit-matrix mirror.  GTOK_SENT_KERNEL=lane|reg|lds|blane pins a kernel where it is applicable (tests run every path).
 static int choose_sent_kernel(const gtok_csr *g, const gtok_sent_params *p) {
   const int maxn = g->max_nodes > 0 ? g->max_nodes : 1;
   const char *pin = std::getenv("GTOK_SENT_KERNEL");
   const bool pin_lane = pin && pin[0] == 'l' && pin[1] == 'a', pin_reg = pin && pin[0] == 'r';
-  const bool pin_lds = pin && pin[0] == 'l' && pin[1] == 'd';
+  const bool pin_lds = pin && pin[0] == 'l' && pin[1] == 'd', pin_blane = pin && pin[0] == 'b';
+  const int wneed = maxn <= 64 ? 1 : maxn <= 128 ? 2 : 4;
+  const bool blane_ok = !p->labeled && !p->remap_zinc && maxn <= 256 && g->adj_rows && g->adj_planes && g->adj_words == wneed &&
+                        g->adj_max_degree <= 255;
+  if (pin_blane && blane_ok) return 3;
   const bool fold_ok = !p->remap_zinc || g->max_nodes <= p->max_num_nodes;   // remap folded into constants
   const bool lane_ok = maxn <= 64 && g->max_edges <= 255 && (g->flags & GTOK_CSR_SIMPLE_SYMMETRIC) && fold_ok;
   const bool reg_ok = maxn <= 64 && g->max_edges <= 32768 && fold_ok &&
@@ -44,6 +52,7 @@ static int choose_sent_kernel(const gtok_csr *g, const gtok_sent_params *p) {
   if (pin_lane && lane_ok) return 0;
   if (pin_reg && reg_ok) return 1;
   if (lane_ok && !pin_reg && g->num_graphs >= GTOK_LANE_MIN_GRAPHS) return 0;
+  if (blane_ok && !pin_reg && !pin_lane && g->num_graphs >= GTOK_BLANE_MIN_GRAPHS) return 3;
   return reg_ok ? 1 : 2;
 }
 
@@ -73,6 +82,25 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   const int maxe = g->max_edges > 0 ? g->max_edges : 1;
   const int which = choose_sent_kernel(g, p);
   const bool lane_path = which == 0, reg_path = which == 1;
+  if (which == 3) {
+    SentBLaneArgs a;
+    a.g = *g; a.p = *p; a.out = out_ids; a.ld = ld; a.out_len = out_len;
+    a.units = (g->num_graphs + 63) / 64;
+    const bool p4 = g->adj_max_degree <= 15;
+    typedef void (*K)(const SentBLaneArgs);
+    K kern = W == 1 ? (p4 ? (K)sent_blane_kernel<1, 4> : (K)sent_blane_kernel<1, 8>)
+           : W == 2 ? (p4 ? (K)sent_blane_kernel<2, 4> : (K)sent_blane_kernel<2, 8>)
+                    : (p4 ? (K)sent_blane_kernel<4, 4> : (K)sent_blane_kernel<4, 8>);
+    const size_t lds = (size_t)4096 * W;
+    int dev = 0, ncu = 256, occ = 1;
+    if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64, lds) != hipSuccess || occ < 1) occ = 1;
+    int nb = ncu * occ;
+    if (nb > a.units) nb = a.units;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(64), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+  }
   if (lane_path) {
     SentLaneArgs a;
     a.g = *g; a.p = *p; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
@@ -211,6 +239,28 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
 }
 
 // ---------------------------------------------------------------------------------------------
+// adjacency bit-matrix mirror (include/gtok.h: gtok_csr_adjbits)
+// ---------------------------------------------------------------------------------------------
+extern "C" int gtok_csr_adjbits(const gtok_csr *g, int32_t words, uint64_t *rows, uint64_t *planes, int32_t *info, void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (!g || g->num_graphs < 0 || (words != 1 && words != 2 && words != 4)) return GTOK_E_INVAL;
+  if (g->max_nodes > 64 * words) return GTOK_E_TOO_LARGE;
+  if (g->num_graphs == 0) return GTOK_OK;
+  if (!g->node_ptr || !g->edge_ptr || !g->rowptr || (g->max_edges > 0 && !g->col) || !rows || !planes || !info) return GTOK_E_INVAL;
+  AdjBitsArgs a;
+  a.g = *g; a.W = words; a.rows = rows; a.planes = planes; a.info = info;
+  const int wpb = words == 4 ? 2 : 4;                         // 64 W^2 words of LDS per wave: 8 KB at W = 4
+  const size_t lds = (size_t)wpb * 64 * words * words * 8;
+  int nb = (g->num_graphs + wpb - 1) / wpb;
+  if (nb > 256 * 8) nb = 256 * 8;
+  typedef void (*K)(const AdjBitsArgs);
+  K kern = words == 1 ? (K)adj_bits_kernel<1> : words == 2 ? (K)adj_bits_kernel<2> : (K)adj_bits_kernel<4>;
+  hipLaunchKernelGGL(kern, dim3(nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
 // byte-packed mirror of rowptr / col (include/gtok.h: gtok_csr_pack8)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) csr_pack8_kernel(const int32_t *__restrict__ src, int64_t n, uint8_t *__restrict__ dst) {
@@ -335,9 +385,11 @@ extern "C" const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_
   if (!g || !p) return "";
   static const char *lds[] = {"sent_lds_kernel<W=1>", "sent_lds_kernel<W=2>", "sent_lds_kernel<W=4>", "sent_lds_kernel<W=8>"};
   const int maxn = g->max_nodes > 0 ? g->max_nodes : 1;
+  static const char *bl[] = {"sent_blane_kernel<W=1>", "sent_blane_kernel<W=2>", "sent_blane_kernel<W=4>"};
   switch (choose_sent_kernel(g, p)) {
     case 0: return "sent_lane_kernel";
     case 1: return "sent_reg_kernel";
+    case 3: return bl[maxn <= 64 ? 0 : maxn <= 128 ? 1 : 2];
     default: return lds[maxn <= 64 ? 0 : maxn <= 128 ? 1 : maxn <= 256 ? 2 : 3];
   }
 }

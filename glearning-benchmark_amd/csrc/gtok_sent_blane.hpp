@@ -1,0 +1,391 @@
+// gtok_sent_blane.hpp — SENT walk, LANE per graph, for UNLABELLED graphs of up to 256 nodes of any shape (self loops,
+// duplicate or one-directional edge lists), over a resident ADJACENCY BIT-MATRIX mirror of the batch.
+//
+// The wave-per-graph kernels spend ~120 instructions per trail step on ONE graph and are bound by the CU's single scalar
+// pipe; the lane-per-graph kernel of gtok_sent_lane.hpp advances 64 walks per instruction but keeps each graph's CSR in
+// LDS, which stops at molecule size.  Here a graph's adjacency lives in HBM as an immutable bit matrix (rows of W = 1, 2
+// or 4 64-bit words: the symmetric closure of the edge list, built ONCE per resident batch by gtok_csr_adjbits, like the
+// CSR itself), and a lane fetches the one row it needs per step (8 W bytes, the only HBM read of the walk).  Walk state is
+// all registers: the visited set (W words), the row of the current node, and P x W words of bit-sliced counters (plane p
+// = bit p of every node's number of unvisited neighbours; their initial value - the degrees - comes with the mirror), from
+// which `live` (visited nodes that still own an uncovered edge) is formed only when a lane is at a dead end.  The one
+// per-node table, node -> visit index (position tokens of bracket members and restarts), sits in LDS laid out
+// [dword][lane]: lane-private, bank = lane, conflict-free.  A bracket is listed in ascending visit index by passing its
+// members (a W-word set in node space) through a W-word set in visit-index space.  Same spec and token stream as every
+// other SENT kernel, bit-exact against oracle/gtok_oracle.c:oracle_sent.
+//
+// Lanes of a wave need not hold neighbouring graphs: `lane_order` (optional, part of the mirror) lists the graphs in the
+// order they are dealt to lanes, so that a wave's 64 walks have similar lengths (a unit lasts as long as its longest walk).
+#pragma once
+#include "gtok_sent_lane.hpp"
+
+namespace gtok {
+
+struct SentBLaneArgs {
+  gtok_csr g;
+  gtok_sent_params p;
+  int32_t *out;
+  int ld;
+  int32_t *out_len;
+  int units;   // ceil(G / 64)
+};
+
+struct __attribute__((aligned(16))) U64x2 { uint64_t a, b; };
+
+template <int W, int P>
+__global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(const SentBLaneArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];   // node -> visit index, u8 [64 * W / 4 dwords][64 lanes]
+  const int lane = lane_id();
+  uint8_t *vx = smem + lane * 4;
+  auto vx_at = [&](int u) __attribute__((always_inline)) -> uint8_t & { return vx[((u & ~3) << 6) + (u & 3)]; };
+
+  const int lim = a.p.max_len, ld = a.ld, cap = min(lim, ld);
+  const int idx_off = GTOK_SENT_IDX_OFFSET;
+  uint32_t k0, k1;   // Philox key in vector registers (gtok_sent_lane.hpp)
+  asm volatile("v_mov_b32 %0, %1" : "=v"(k0) : "s"((uint32_t)a.p.seed));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(k1) : "s"((uint32_t)(a.p.seed >> 32)));
+  const uint32_t epoch = (uint32_t)a.p.epoch;
+  const uint64_t T_RESET = GTOK_SENT_RESET, T_LADJ = GTOK_SENT_LADJ, T_RADJ = GTOK_SENT_RADJ, T_EOS = GTOK_SENT_EOS;
+  const int G = a.g.num_graphs, pad = a.p.pad_id;
+  const bool no_pad = (a.p.flags & GTOK_SENT_NO_PAD) != 0;
+
+  for (int unit = (int)blockIdx.x; unit < a.units; unit += (int)gridDim.x) {
+    const int slot = unit * 64 + lane;
+    const bool valid = slot < G;
+    const int g = valid ? (a.g.lane_order ? a.g.lane_order[slot] : slot) : 0;
+    int nb0 = 0, nfull = 0;
+    if (valid) { nb0 = a.g.node_ptr[g]; nfull = a.g.node_ptr[g + 1] - nb0; }
+    const int n = min(nfull, 64 * W);
+    const uint64_t *__restrict__ rows = a.g.adj_rows + (size_t)nb0 * W;
+    auto load_row = [&](int v, uint64_t (&r)[W]) __attribute__((always_inline)) {
+      const uint64_t *q = rows + (size_t)v * W;
+      if (W == 1) { r[0] = q[0]; }
+      else {
+#pragma unroll
+        for (int w = 0; w < W; w += 2) { const U64x2 x = *reinterpret_cast<const U64x2 *>(q + w); r[w] = x.a; r[w + 1] = x.b; }
+      }
+    };
+    // counters: plane p, word w
+    uint64_t c[P][W];
+    {
+      const uint64_t *pl = a.g.adj_planes + (size_t)g * 8 * W;
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int w = 0; w < W; ++w) c[p][w] = valid ? pl[p * W + w] : 0ull;
+    }
+    uint64_t validm[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { const int r = n - 64 * w; validm[w] = r >= 64 ? ~0ull : (r > 0 ? ((1ull << r) - 1ull) : 0ull); }
+
+    const uint64_t gid = (uint64_t)(a.p.graph_base + g);
+    const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
+    int32_t *__restrict__ orow = a.out + (int64_t)g * ld;
+    uint64_t vis[W], rowc[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { vis[w] = 0; rowc[w] = 0; }
+    uint64_t wlo = 0;
+    int nvis = 0, pos = 0, fl = 0, d = 0, cur = 0;
+
+    // ---- token window and store bursts: as in gtok_sent_lane.hpp
+    constexpr int SG = GTOK_LANE_SECTOR_GROUPS;
+    uint64_t pg[SG > 1 ? SG - 1 : 1];
+#pragma unroll
+    for (int j = 0; j < SG - 1; ++j) pg[j] = 0;
+    auto tok_of = [](uint64_t w, int i) __attribute__((always_inline)) -> int { return (int)((w >> (i << 4)) & 0xFFFFu); };
+    auto put4 = [&](int at, uint64_t w) __attribute__((always_inline)) {
+      *reinterpret_cast<I32x4 *>(orow + at) = I32x4{tok_of(w, 0), tok_of(w, 1), tok_of(w, 2), (int)(w >> 48)};
+    };
+    auto group_of = [&](int j, uint64_t w) __attribute__((always_inline)) -> uint64_t {
+      uint64_t r = w;
+#pragma unroll
+      for (int k = 0; k < SG - 1; ++k) r = j == k ? pg[k] : r;
+      return r;
+    };
+    auto flush = [&](uint64_t w) __attribute__((always_inline)) {
+      const int gi = (fl >> 2) & (SG - 1);
+#pragma unroll
+      for (int k = 0; k < SG - 1; ++k) pg[k] = gi == k ? w : pg[k];
+      if (gi == SG - 1) {
+        const int sb = fl - 4 * (SG - 1);
+        if (fl + 4 <= cap && (ld & 3) == 0) {
+#pragma unroll
+          for (int k = 0; k < SG - 1; ++k) put4(sb + 4 * k, pg[k]);
+          put4(fl, w);
+        } else {
+          for (int j = 0; j < 4 * SG && sb + j < cap; ++j) orow[sb + j] = tok_of(group_of(j >> 2, w), j & 3);
+        }
+      }
+    };
+    auto append = [&](uint64_t val, int cnt) __attribute__((always_inline)) {   // cnt <= 4 tokens, lowest first
+      const int s = (pos - fl) << 4;
+      wlo |= val << s;
+      const uint64_t over = (val >> (63 - s)) >> 1;
+      pos += cnt;
+      if (pos - fl >= 4) { flush(wlo); wlo = over; fl += 4; }
+    };
+    uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
+    auto below = [&](uint32_t nchoices) __attribute__((always_inline)) -> uint32_t {   // d is the same in every active lane
+      const int w = uni(d) & 3;
+      if (w == 0) {
+        uint32_t o[4];
+        philox4x32_10((uint32_t)(d >> 2), epoch, gid_lo, gid_hi, k0, k1, o);
+        pw0 = o[0]; pw1 = o[1]; pw2 = o[2]; pw3 = o[3];
+      }
+      const uint32_t x = w == 0 ? pw0 : (w == 1 ? pw1 : (w == 2 ? pw2 : pw3));
+      ++d;
+      return __umulhi(x, nchoices);
+    };
+    // k-th member (ascending node id) of a W-word set, k below its size
+    auto kth_of = [&](const uint64_t (&s)[W], int k) __attribute__((always_inline)) -> int {
+      uint64_t word = s[W - 1];
+      int base = 64 * (W - 1), kk = k;
+      bool found = false;
+#pragma unroll
+      for (int w = 0; w < W - 1; ++w) {
+        const int cw = __popcll(s[w]);
+        const bool take = !found && kk < cw;
+        word = take ? s[w] : word;
+        base = take ? 64 * w : base;
+        found = found || take;
+        kk = found ? kk : kk - cw;
+      }
+      return base + kth_bit64(word, kk);
+    };
+    auto count_of = [&](const uint64_t (&s)[W]) __attribute__((always_inline)) -> int {
+      int t = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) t += __popcll(s[w]);
+      return t;
+    };
+    // lowest member of a W-word set (not empty), removed from it
+    auto pop_lowest = [&](uint64_t (&s)[W]) __attribute__((always_inline)) -> int {
+      int u = 0;
+      bool done = false;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const bool here = !done && s[w] != 0;
+        if (here) { u = 64 * w + __builtin_ctzll(s[w]); s[w] &= s[w] - 1; }
+        done = done || here;
+      }
+      return u;
+    };
+
+    if (valid) {
+      append((uint64_t)GTOK_SENT_SOS, 1);
+      if (n > 0) {
+        while (pos < lim) {
+          uint64_t set[W];
+          int cnt = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) { set[w] = rowc[w] & ~vis[w]; cnt += __popcll(set[w]); }
+          int kind = 0;
+          if (cnt == 0) {   // dead end: visited nodes that still own an uncovered edge, else another component / isolated node
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              uint64_t nz = 0;
+#pragma unroll
+              for (int p = 0; p < P; ++p) nz |= c[p][w];
+              set[w] = vis[w] & nz;
+              cnt += __popcll(set[w]);
+            }
+            kind = 1;
+            if (cnt == 0) {
+              kind = 2;
+#pragma unroll
+              for (int w = 0; w < W; ++w) { set[w] = ~vis[w] & validm[w]; cnt += __popcll(set[w]); }
+            }
+          }
+          if (cnt == 0) break;                                  // every node visited, every edge covered
+          const int pick = kth_of(set, (int)below((uint32_t)cnt));
+          uint64_t rn[W];
+          load_row(pick, rn);
+          const bool first = kind != 1;
+          const uint32_t xb = vx_at(pick);                      // visit index of a restart node (kind 1)
+          const uint32_t my = (uint32_t)nvis;
+          if (first) vx_at(pick) = (uint8_t)my;
+          {
+            const uint64_t tpos = (uint64_t)((uint32_t)idx_off + (first ? my : xb));
+            const bool has_a = kind == 1 || (kind == 2 && nvis > 0);   // (the walk's first node is a component start without RESET)
+            append(has_a ? (T_RESET | (tpos << 16)) : tpos, has_a ? 2 : 1);
+          }
+          // ---- first visit: the node's neighbours lose an unvisited neighbour; visited neighbours (itself included: self
+          // loop) other than the trail's predecessor form its bracket
+          uint64_t M[W];
+          bool anym = false;
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            const uint64_t S = first ? rn[w] : 0ull;
+            uint64_t b = S;
+#pragma unroll
+            for (int p = 0; p < P; ++p) { const uint64_t t = c[p][w]; c[p][w] = t ^ b; b &= ~t; }
+            const uint64_t pickbit = (pick >> 6) == w ? 1ull << (pick & 63) : 0ull;
+            const uint64_t predbit = (kind == 0 && (cur >> 6) == w) ? 1ull << (cur & 63) : 0ull;
+            vis[w] |= pickbit;
+            M[w] = S & vis[w] & ~predbit;
+            anym = anym || M[w] != 0;
+          }
+          nvis += first;
+          if (anym) {   // LADJ, members by ascending visit index, RADJ: node space -> visit-index space -> tokens
+            uint64_t T[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) T[w] = 0;
+            bool more = true;
+            do {
+              const int u = pop_lowest(M);
+              const int t = vx_at(u);
+#pragma unroll
+              for (int w = 0; w < W; ++w) T[w] |= (t >> 6) == w ? 1ull << (t & 63) : 0ull;
+              more = false;
+#pragma unroll
+              for (int w = 0; w < W; ++w) more = more || M[w] != 0;
+            } while (more);
+            bool head = true;
+            do {
+              const int t = pop_lowest(T);
+              more = false;
+#pragma unroll
+              for (int w = 0; w < W; ++w) more = more || T[w] != 0;
+              uint64_t val = (uint64_t)(uint32_t)(idx_off + t);
+              int cntt = 1;
+              if (head) { val = T_LADJ | (val << 16); cntt = 2; head = false; }
+              if (!more) { val |= T_RADJ << (cntt << 4); ++cntt; }
+              append(val, cntt);
+            } while (more);
+          }
+#pragma unroll
+          for (int w = 0; w < W; ++w) rowc[w] = rn[w];
+          cur = pick;
+        }
+      }
+      append(T_EOS, 1);
+    }
+    // ---- end of the row (as in gtok_sent_lane.hpp): window, query tail, padding to a 16-token boundary
+    const int len = min(pos, lim);
+    int tot = len;
+    int q0 = 0, q1 = 0, q2 = 0;
+    if (valid && a.p.query) {
+      q0 = idx_off + nfull; q1 = idx_off + a.p.query[2 * (int64_t)g]; q2 = idx_off + a.p.query[2 * (int64_t)g + 1];
+      tot = len + 3;
+    }
+    int padfrom = 0;
+    if (valid) {
+      a.out_len[g] = tot;
+      const int sb = fl & ~(4 * SG - 1);
+      if (!a.p.query && pos <= cap && (ld & 3) == 0) {
+        const int s16 = fl & ~15;
+        padfrom = min(ld, (len + 15) & ~15);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int at = s16 + 4 * k;
+          if (at >= sb && at < padfrom) {
+            const uint64_t w = at == fl ? wlo : (at > fl ? 0ull : group_of((at - sb) >> 2, 0));
+            I32x4 v;
+            v.x = at + 0 < len ? tok_of(w, 0) : pad; v.y = at + 1 < len ? tok_of(w, 1) : pad;
+            v.z = at + 2 < len ? tok_of(w, 2) : pad; v.w = at + 3 < len ? tok_of(w, 3) : pad;
+            *reinterpret_cast<I32x4 *>(orow + at) = v;
+          }
+        }
+      } else {
+        padfrom = min(ld, (tot + 3) & ~3);
+        for (int i = min(sb, len); i < padfrom; ++i) {
+          int v = pad;
+          if (i < len) {
+            if (i < sb) continue;
+            v = tok_of(i >= fl ? wlo : group_of((i - sb) >> 2, 0), i & 3);
+          } else if (i < tot) {
+            v = i == len ? q0 : (i == len + 1 ? q1 : q2);
+          }
+          orow[i] = v;
+        }
+      }
+    }
+    // ---- pad tails: four rows per pass, 16 lanes x 16-byte stores on each (rows of a unit need not be neighbours)
+    if (!no_pad) {
+      const int q = lane & 15;
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 4 + (lane >> 4);
+        const int lr = __builtin_amdgcn_ds_bpermute(r << 2, padfrom);
+        const int gr = __builtin_amdgcn_ds_bpermute(r << 2, valid ? g : -1);
+        if (unit * 64 + it * 4 >= G) break;
+        if (gr >= 0) {
+          int32_t *__restrict__ rowp = a.out + (int64_t)gr * ld + lr;
+          const int nrem = ld - lr, nvec = nrem >> 2;
+          _Pragma("clang loop vectorize(disable) unroll(disable)")
+          for (int t = q; t < nvec; t += 16) store_pad16(rowp + 4 * t, pad);
+          if (q < (nrem & 3)) rowp[(nvec << 2) + q] = pad;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the mirror: adjacency bit matrix (symmetric closure of the listed entries, self loops kept) + degree planes.
+// Wave per graph: the matrix is assembled in LDS with atomic ORs (lane = row, 16 neighbour loads in flight), written
+// out coalesced; node u's degree = popcount of its row, its bit p goes to plane p (one ballot per plane and word).
+// ---------------------------------------------------------------------------------------------
+struct AdjBitsArgs {
+  gtok_csr g;
+  int W;
+  uint64_t *rows, *planes;
+  int32_t *info;   // [0] = largest degree in the symmetric closure (self loop counted): picks the number of counter planes
+};
+
+template <int W>
+__global__ void __launch_bounds__(256) adj_bits_kernel(const AdjBitsArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id(), wave = wave_id(), wpb = (int)(blockDim.x >> 6);
+  uint64_t *adj = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * (64 * W * W);
+  const int G = a.g.num_graphs;
+  for (int g = (int)blockIdx.x * wpb + wave; g < G; g += (int)gridDim.x * wpb) {
+    const int nb0 = sload(a.g.node_ptr, g);
+    const int n = min(sload(a.g.node_ptr, g + 1) - nb0, 64 * W);
+    const int64_t e0 = sload(a.g.edge_ptr, g);
+    const int32_t *__restrict__ rpg = a.g.rowptr + nb0 + g;
+    const int32_t *__restrict__ colg = a.g.col + e0;
+    wave_sync();
+    for (int i = lane; i < n * W; i += kWave) adj[i] = 0;
+    wave_sync();
+    for (int u = lane; u < n; u += kWave) {
+      const int rs = rpg[u], re = rpg[u + 1];
+      for (int k0e = rs; k0e < re; k0e += 16) {
+        int v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = colg[min(k0e + j, re - 1)];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (k0e + j < re && (unsigned)v[j] < (unsigned)n) {
+            atomicOr(reinterpret_cast<unsigned long long *>(&adj[u * W + (v[j] >> 6)]), 1ull << (v[j] & 63));
+            atomicOr(reinterpret_cast<unsigned long long *>(&adj[v[j] * W + (u >> 6)]), 1ull << (u & 63));
+          }
+        }
+      }
+    }
+    wave_sync();
+    uint64_t *__restrict__ dst = a.rows + (size_t)nb0 * W;
+    for (int i = lane; i < n * W; i += kWave) dst[i] = adj[i];
+    uint64_t *__restrict__ pl = a.planes + (size_t)g * 8 * W;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const int u = 64 * w + lane;
+      int deg = 0;
+      if (u < n) {
+#pragma unroll
+        for (int x = 0; x < W; ++x) deg += __popcll(adj[u * W + x]);
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const uint64_t m = __ballot((deg >> p) & 1);
+        if (lane == 0) pl[p * W + w] = m;
+      }
+      int mx = deg;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+      if (lane == 0 && mx > 0) atomicMax(a.info, mx);
+    }
+  }
+}
+
+}  // namespace gtok

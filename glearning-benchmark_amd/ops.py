@@ -111,6 +111,9 @@ def sent_safe_ld(batch: GraphBatch, labeled: bool, max_len: int, with_query: boo
     return (min(max_len, bound) + (3 if with_query else 0) + 15) // 16 * 16
 
 
+ADJBITS_MIN_GRAPHS = 4096     # = GTOK_BLANE_MIN_GRAPHS of gtok_sent.hip: below it gtok_sent never picks the bit-matrix lane kernel
+
+
 def pack8(batch: GraphBatch) -> bool:
     """Give a device batch of small graphs its byte-packed rowptr / col mirror (gtok_csr_pack8; once per batch,
     kept on the batch object).  Returns whether the batch has one now.  A layout step like the CSR build: the
@@ -132,6 +135,37 @@ def pack8(batch: GraphBatch) -> bool:
     return True
 
 
+def adjbits(batch: GraphBatch) -> bool:
+    """Give a device batch of graphs with <= 256 nodes its adjacency bit-matrix mirror (gtok_csr_adjbits; once per
+    batch, kept on the batch object) and the order its graphs are dealt to lanes (longest walks first, so that the 64
+    walks of a wave have similar lengths).  Returns whether the batch has one now.  A layout step like the CSR build:
+    the lane-per-graph SENT kernel for unlabelled graphs reads one row of it per trail step."""
+    if batch.adj_rows is not None:
+        return True
+    if os.environ.get("GTOK_NO_ADJBITS") == "1":
+        return False
+    if batch.col.device.type != "cuda" or batch.num_graphs == 0 or batch.max_nodes > 256:
+        return False
+    dev, G = batch.device, batch.num_graphs
+    W = 1 if batch.max_nodes <= 64 else 2 if batch.max_nodes <= 128 else 4
+    total_nodes = batch.rowptr.numel() - G
+    rows = torch.empty((max(total_nodes, 1), W), dtype=torch.int64, device=dev)
+    planes = torch.empty((G, 8, W), dtype=torch.int64, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    cs = batch.c_struct()
+    check(lib().gtok_csr_adjbits(ctypes.byref(cs), W, rows.data_ptr(), planes.data_ptr(), info.data_ptr(), _stream(dev)),
+          "gtok_csr_adjbits")
+    maxdeg = int(info.item())
+    if maxdeg > 255:          # a 256-node graph with a full row and a self loop: 8 counter planes cannot hold it
+        return False
+    batch.adj_rows, batch.adj_planes, batch.adj_words, batch.adj_max_degree = rows, planes, W, maxdeg
+    if os.environ.get("GTOK_BLANE_ORDER", "1") != "0":
+        # walk length ~ nodes + edges: deal graphs to lanes in descending order of it
+        cost = (batch.edge_ptr[1:] - batch.edge_ptr[:-1]).to(torch.int64) + 2 * (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.int64)
+        batch.lane_order = torch.argsort(cost, descending=True, stable=True).to(torch.int32)
+    return True
+
+
 def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: int = 0, labeled: bool = False,
          num_node_types: int = 0, num_edge_types: int = 0, remap_zinc: bool = False, pad_id: int = SENT_PAD,
          graph_base: int = 0, query: Optional[torch.Tensor] = None,
@@ -149,6 +183,8 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
         ld = sent_safe_ld(batch, labeled, max_len, query is not None)
     ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
     pack8(batch)
+    if not labeled and not remap_zinc and batch.num_graphs >= ADJBITS_MIN_GRAPHS or os.environ.get("GTOK_SENT_KERNEL") == "blane":
+        adjbits(batch)
     p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc),
                        pad_id, 0 if pad else _lib.SENT_NO_PAD, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
                        None if query is None else query.data_ptr())

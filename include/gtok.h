@@ -24,6 +24,7 @@
  *   gtok_parse_graph_text  graph_token_dataset_autograph.py:14-158 (text -> edges, query, label)
  *   gtok_find_token    the `<q>` search of trainer/train_ibtt.py:88-103 on a collated batch
  *   gtok_csr_pack8     (no reference counterpart) byte-packed mirror of the CSR index arrays of small-graph batches
+ *   gtok_csr_adjbits   (no reference counterpart) adjacency bit-matrix mirror of batches of graphs with <= 256 nodes
  *   gtok_vocab_stats_text   the corpus pass of build_vocab_from_texts / the ZINC dynamic-token scan over arbitrary texts
  *   gtok_vocab_stats_synth  the corpus pass of build_vocab_from_texts
  *                      (data_loader.py:451-463) for graph-token corpora held as
@@ -101,6 +102,17 @@ typedef struct gtok_csr {
    * lane-per-graph SENT kernel stages its 64-graph chunks from these (a quarter of the index bytes).            */
   const uint8_t *rowptr8;
   const uint8_t *col8;
+  /* Adjacency bit-matrix mirror for UNLABELLED batches of graphs with <= 256 nodes, written once per resident batch by
+   * gtok_csr_adjbits; NULL = absent.  adj_rows[(node_ptr[g] + u) * adj_words + w] = word w of node u's row in the
+   * symmetric closure of graph g's entries (self loops kept); adj_planes[(g * 8 + p) * adj_words + w] = bit p of the
+   * degrees of nodes 64 w .. 64 w + 63; adj_max_degree = the largest degree (must be <= 255).  lane_order (optional):
+   * the graphs in the order the lane-per-graph kernel deals them to lanes (64 per wave) - a permutation of 0..G-1
+   * grouping walks of similar length; NULL = dataset order.  The SENT walk of such a batch reads one row per step.   */
+  const uint64_t *adj_rows;
+  const uint64_t *adj_planes;
+  const int32_t *lane_order;
+  int32_t adj_words;      /* 1, 2 or 4 = ceil(max_nodes / 64) rounded up to a power of two */
+  int32_t adj_max_degree;
 } gtok_csr;
 
 /* LUT layout for gtok_ibtt_zinc (int32 vocab ids; an absent token holds pad_id
@@ -124,6 +136,12 @@ typedef struct gtok_csr {
  * GTOK_E_TOO_LARGE when max_edges > 255 or max_nodes > 256 (values would not fit).  No reference counterpart: a
  * data-layout step, done once when a batch becomes resident, like the CSR build itself.                       */
 int gtok_csr_pack8(const gtok_csr *g, int64_t num_rowptr, int64_t num_col, uint8_t *rowptr8, uint8_t *col8, void *stream);
+
+/* Adjacency bit-matrix mirror (see gtok_csr.adj_rows): rows = [sum N_g][words] uint64, planes = [G][8][words] uint64,
+ * info = int32[1], zeroed by the caller, receives the largest closure degree.  words = 1, 2 or 4 with 64 * words >=
+ * max_nodes (GTOK_E_TOO_LARGE otherwise).  Works on any edge list (one or both directions, duplicates, self loops).
+ * A data-layout step like gtok_csr_pack8: done once when a batch becomes resident, not per epoch.                    */
+int gtok_csr_adjbits(const gtok_csr *g, int32_t words, uint64_t *rows, uint64_t *planes, int32_t *info, void *stream);
 
 /* IBTT molecular serialiser -> ids.
  * lut_len = 22 + number of node-index entries (must cover max_nodes).      */
@@ -289,9 +307,10 @@ int gtok_sent_decode(const int32_t *ids, int32_t ld, const int32_t *len, int32_t
                      int32_t *edge_type, int32_t edge_cap, int32_t *node_type, int32_t node_cap,
                      int32_t *status, void *stream);
 
-/* Which SENT kernel gtok_sent() will run for this batch ("sent_lane_kernel": lane per graph, needs
- * GTOK_CSR_SIMPLE_SYMMETRIC and a large batch; "sent_reg_kernel": wave per graph, <= 64 nodes;
- * "sent_lds_kernel<W=..>": wave per graph, up to 512 nodes).  All three emit the same tokens.               */
+/* Which SENT kernel gtok_sent() will run for this batch ("sent_lane_kernel": lane per graph over the CSR, needs
+ * GTOK_CSR_SIMPLE_SYMMETRIC, <= 64 nodes and a large batch; "sent_blane_kernel<W=..>": lane per graph over the
+ * adjacency bit-matrix mirror, unlabelled, <= 256 nodes; "sent_reg_kernel": wave per graph, <= 64 nodes;
+ * "sent_lds_kernel<W=..>": wave per graph, up to 512 nodes).  All emit the same tokens.                      */
 const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_params *p);
 /* Same for gtok_ibtt_zinc(): "ibtt_zinc_quad_kernel" (8 or 16 lanes per molecule: GTOK_CSR_SIMPLE_SYMMETRIC
  * batches in list order - the default for ZINC), "ibtt_zinc_lane_kernel" (lane per graph, GTOK_IBTT_KERNEL=lane

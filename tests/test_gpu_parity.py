@@ -913,3 +913,73 @@ def test_lane_kernel_row_ends_query_tail_cuts_and_odd_slabs(pin, monkeypatch):
         ref, rln = orc.sent(coo, 37, 1024, 13, 4, ld=208, query=q, **kw)
         inside = np.arange(208)[None, :] < rln[:, None]
         assert np.array_equal(l2.cpu().numpy(), rln) and np.array_equal(np.where(inside, raw.cpu().numpy(), 0), np.where(inside, ref, 0))
+
+
+@pytest.mark.parametrize("order", ["1", "0"])
+def test_sent_bit_matrix_lane_kernel(order, monkeypatch):
+    """sent_blane_kernel (lane per graph over the adjacency bit-matrix mirror; unlabelled, <= 256 nodes, ANY edge list)
+    against the oracle: molecules, the graph-token families, the hand-made edge cases (self loops, duplicates, one
+    direction only, isolated nodes, empty graphs), every word count W (batches topping out at 64 / 65 / 128 / 129 / 256
+    nodes), 4 and 8 counter planes, the 256-node star / complete graph / path, the query tail, rows cut by max_len at
+    every phase of the token window, odd slab widths, GTOK_SENT_NO_PAD, a non-zero graph_base, and the graphs dealt
+    to lanes in dataset order (order = "0") or longest walk first."""
+    monkeypatch.setenv("GTOK_SENT_KERNEL", "blane")
+    monkeypatch.setenv("GTOK_BLANE_ORDER", order)
+    cases = [("zinc", gtok.synth.zinc_like(1500, seed=63), 40),
+             ("families", gtok.synth.graph_token_like(400, seed=64, with_text=False, algorithms=("er", "ba", "sbm", "path", "star")), 49),
+             ("edge cases", edge_case_graphs(), 8)]
+    for top in (64, 65, 128, 129, 256):
+        cases.append((f"top={top}", _rings_with_chords([top, top - 1, top - 2, 3, 1, 0] * 3 + [top] * 70, 3, seed=top), top))
+    n = 256
+    iu, iv = np.triu_indices(n, 1)
+    cases.append(("extremes", dict(node_counts=np.array([n, n, n, 3]), edge_counts=np.array([n - 1, iu.size, n - 1, 2]),
+                                   src=np.concatenate([np.zeros(n - 1, np.int64), iu, np.arange(n - 1), [0, 1]]),
+                                   dst=np.concatenate([np.arange(1, n), iv, np.arange(1, n), [1, 2]])), 256))
+    for name, d, nn in cases:
+        batch, coo = both(d, False)
+        b = batch.to(DEV)
+        for max_len in (100000, 40):
+            ids, ln = gtok.ops.sent(b, nn, max_len, 17, 5, graph_base=123)
+            assert b.adj_rows is not None and (b.lane_order is not None) == (order == "1")
+            assert gtok.ops.sent_kernel_name(b, nn, max_len).startswith("sent_blane_kernel<W=%d>" % b.adj_words), name
+            ref, rln = orc.sent(coo, nn, max_len, 17, 5, graph_base=123, ld=ids.shape[1], nthreads=8)
+            _cmp(ids, ln, ref, rln, f"blane {name} max_len={max_len}")
+    # row ends: query tail x cuts x slab widths (the matrix of test_lane_kernel_row_ends_query_tail_cuts_and_odd_slabs)
+    d = gtok.synth.zinc_like(700, seed=97)
+    rng = np.random.default_rng(3)
+    q = np.stack([rng.integers(0, d["node_counts"]), rng.integers(0, d["node_counts"])], 1).astype(np.int32)
+    batch, coo = both(d, False)
+    b = batch.to(DEV)
+    for max_len, ld in ((1024, None), (1024, 64), (1024, 61), (1024, 203), (33, None), (34, 48), (35, 41), (36, 36), (37, 20),
+                        (5, 8), (2, 4), (1, 7), (0, 4), (90, 96), (91, 91)):
+        for query in (None, q):
+            ids, ln = gtok.ops.sent(b, 37, max_len, 13, 4, ld=ld, query=None if query is None else torch.from_numpy(query))
+            ref, rln = orc.sent(coo, 37, max_len, 13, 4, ld=ids.shape[1], query=query)
+            _cmp(ids, ln, ref, rln, f"blane max_len={max_len} ld={ld} query={query is not None}")
+    raw = torch.full((700, 208), -3, dtype=torch.int32, device=DEV); l2 = torch.empty(700, dtype=torch.int32, device=DEV)
+    gtok.ops.sent(b, 37, 1024, 13, 4, ld=208, out=(raw, l2), pad=False, query=torch.from_numpy(q))
+    ref, rln = orc.sent(coo, 37, 1024, 13, 4, ld=208, query=q)
+    inside = np.arange(208)[None, :] < rln[:, None]
+    assert np.array_equal(l2.cpu().numpy(), rln) and np.array_equal(np.where(inside, raw.cpu().numpy(), 0), np.where(inside, ref, 0))
+    # K256 plus a self loop: a degree of 256 does not fit 8 counter planes -> no mirror, the LDS kernel takes the batch
+    full = dict(node_counts=np.array([n, 5]), edge_counts=np.array([iu.size + 1, 1]),
+                src=np.concatenate([iu, [7], [0]]), dst=np.concatenate([iv, [7], [1]]))
+    batch, coo = both(full, False)
+    b = batch.to(DEV)
+    ids, ln = gtok.ops.sent(b, 256, 100000, 3, 1)
+    assert b.adj_rows is None and gtok.ops.sent_kernel_name(b, 256, 100000).startswith("sent_lds_kernel")
+    ref, rln = orc.sent(coo, 256, 100000, 3, 1, ld=ids.shape[1])
+    _cmp(ids, ln, ref, rln, "K256 + self loop")
+
+
+def test_config5_sized_batches_take_the_bit_matrix_lane_kernel():
+    """A config-5 sized batch (>= 4096 unlabelled graphs of 10-256 nodes) is tokenized by sent_blane_kernel by default;
+    bit-exact against the oracle, ER and the seven-family mix."""
+    for name, d in (("er", gtok.synth.er_batch_device(6000, DEV, seed=3)), ("mix", gtok.synth.mix_batch_device(6000, DEV, seed=4))):
+        batch, coo = both(d, False)
+        b = batch.to(DEV)
+        for max_len in (100000, 600):
+            ids, ln = gtok.ops.sent(b, 256, max_len, 9, 2)
+            assert gtok.ops.sent_kernel_name(b, 256, max_len).startswith("sent_blane_kernel<W=4>")
+            ref, rln = orc.sent(coo, 256, max_len, 9, 2, ld=ids.shape[1], nthreads=8)
+            _cmp(ids, ln, ref, rln, f"blane default {name} max_len={max_len}")
