@@ -11,7 +11,8 @@
 // which `live` (visited nodes that still own an uncovered edge) is formed only when a lane is at a dead end.  The one
 // per-node table, node -> visit index (position tokens of bracket members and restarts), sits in LDS laid out
 // [dword][lane]: lane-private, bank = lane, conflict-free.  A bracket is listed in ascending visit index by passing its
-// members (a W-word set in node space) through a W-word set in visit-index space.  Same spec and token stream as every
+// members (a set in node space) through a set in visit-index space, both streamed word by word through LDS so that every
+// lane iterates over its own members only.  Same spec and token stream as every
 // other SENT kernel, bit-exact against oracle/gtok_oracle.c:oracle_sent.
 //
 // Lanes of a wave need not hold neighbouring graphs: `lane_order` (optional, part of the mirror) lists the graphs in the
@@ -34,10 +35,14 @@ struct __attribute__((aligned(16))) U64x2 { uint64_t a, b; };
 
 template <int W, int P>
 __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(const SentBLaneArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];   // node -> visit index, u8 [64 * W / 4 dwords][64 lanes]
+  // LDS, all of it lane-private and laid out [dword][lane] (bank = lane): 16 W dwords node -> visit index (u8 each),
+  // 2 W dwords bracket members in node space, 2 W dwords bracket members in visit-index space (zero between brackets)
+  extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   uint8_t *vx = smem + lane * 4;
   auto vx_at = [&](int u) __attribute__((always_inline)) -> uint8_t & { return vx[((u & ~3) << 6) + (u & 3)]; };
+  uint32_t *lw = reinterpret_cast<uint32_t *>(smem) + lane;
+  constexpr int MW0 = 16 * W * 64, TW0 = 18 * W * 64;   // dword offsets of the two word sets
 
   const int lim = a.p.max_len, ld = a.ld, cap = min(lim, ld);
   const int idx_off = GTOK_SENT_IDX_OFFSET;
@@ -84,11 +89,14 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
     uint64_t vis[W], rowc[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) { vis[w] = 0; rowc[w] = 0; }
+#pragma unroll
+    for (int k = 0; k < 2 * W; ++k) lw[TW0 + k * 64] = 0;   // (a row cut by max_len may leave its last bracket half listed)
     uint64_t wlo = 0;
     int nvis = 0, pos = 0, fl = 0, d = 0, cur = 0;
 
-    // ---- token window and store bursts: as in gtok_sent_lane.hpp
-    constexpr int SG = GTOK_LANE_SECTOR_GROUPS;
+    // ---- token window as in gtok_sent_lane.hpp, flushed four tokens (one 16-byte store) at a time: this kernel is bound
+    // by the instructions of its bracket loops, not by its HBM writes
+    constexpr int SG = 1;
     uint64_t pg[SG > 1 ? SG - 1 : 1];
 #pragma unroll
     for (int j = 0; j < SG - 1; ++j) pg[j] = 0;
@@ -123,6 +131,11 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
       const uint64_t over = (val >> (63 - s)) >> 1;
       pos += cnt;
       if (pos - fl >= 4) { flush(wlo); wlo = over; fl += 4; }
+    };
+    auto append1 = [&](uint32_t tok) __attribute__((always_inline)) {
+      wlo |= (uint64_t)tok << ((pos - fl) << 4);
+      ++pos;
+      if (pos - fl == 4) { flush(wlo); wlo = 0; fl += 4; }
     };
     uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
     auto below = [&](uint32_t nchoices) __attribute__((always_inline)) -> uint32_t {   // d is the same in every active lane
@@ -204,10 +217,13 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
           const uint32_t xb = vx_at(pick);                      // visit index of a restart node (kind 1)
           const uint32_t my = (uint32_t)nvis;
           if (first) vx_at(pick) = (uint8_t)my;
+          uint64_t tokv;
+          int tokc;
           {
             const uint64_t tpos = (uint64_t)((uint32_t)idx_off + (first ? my : xb));
             const bool has_a = kind == 1 || (kind == 2 && nvis > 0);   // (the walk's first node is a component start without RESET)
-            append(has_a ? (T_RESET | (tpos << 16)) : tpos, has_a ? 2 : 1);
+            tokv = has_a ? (T_RESET | (tpos << 16)) : tpos;
+            tokc = has_a ? 2 : 1;
           }
           // ---- first visit: the node's neighbours lose an unvisited neighbour; visited neighbours (itself included: self
           // loop) other than the trail's predecessor form its bracket
@@ -226,32 +242,51 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
             anym = anym || M[w] != 0;
           }
           nvis += first;
-          if (anym) {   // LADJ, members by ascending visit index, RADJ: node space -> visit-index space -> tokens
-            uint64_t T[W];
+          if (anym) { tokv |= T_LADJ << (tokc << 4); ++tokc; }
+          append(tokv, tokc);
+          if (anym && pos < lim) {
+            // LADJ, members by ascending visit index, RADJ.  The members (node space) go to LDS as 32-bit words; every lane
+            // streams through ITS non-empty words (a mask of them in a register, the next word fetched while the current one
+            // is consumed), so that a wave runs as many iterations as its largest bracket has members, whatever words they
+            // fall in.  Each member sets its visit index's bit in the second word set, which is then streamed the same way
+            // in ascending order - one token per iteration - and left zeroed.
+            uint32_t nzm = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w) T[w] = 0;
-            bool more = true;
-            do {
-              const int u = pop_lowest(M);
-              const int t = vx_at(u);
-#pragma unroll
-              for (int w = 0; w < W; ++w) T[w] |= (t >> 6) == w ? 1ull << (t & 63) : 0ull;
-              more = false;
-#pragma unroll
-              for (int w = 0; w < W; ++w) more = more || M[w] != 0;
-            } while (more);
-            bool head = true;
-            do {
-              const int t = pop_lowest(T);
-              more = false;
-#pragma unroll
-              for (int w = 0; w < W; ++w) more = more || T[w] != 0;
-              uint64_t val = (uint64_t)(uint32_t)(idx_off + t);
-              int cntt = 1;
-              if (head) { val = T_LADJ | (val << 16); cntt = 2; head = false; }
-              if (!more) { val |= T_RADJ << (cntt << 4); ++cntt; }
-              append(val, cntt);
-            } while (more);
+            for (int w = 0; w < W; ++w) {
+              const uint32_t lo = (uint32_t)M[w], hi = (uint32_t)(M[w] >> 32);
+              lw[MW0 + (2 * w) * 64] = lo;
+              lw[MW0 + (2 * w + 1) * 64] = hi;
+              nzm |= (lo ? 1u << (2 * w) : 0u) | (hi ? 2u << (2 * w) : 0u);
+            }
+            int k = __builtin_ctz(nzm);
+            nzm &= nzm - 1;
+            uint32_t mw = lw[MW0 + k * 64], nw = 0, nzt = 0;
+            int base = k << 5, nbase = 0;
+            if (nzm) { k = __builtin_ctz(nzm); nzm &= nzm - 1; nw = lw[MW0 + k * 64]; nbase = k << 5; }
+            while (mw != 0) {
+              const uint32_t t = vx_at(base + __builtin_ctz(mw));
+              mw &= mw - 1;
+              if (mw == 0) {
+                mw = nw; base = nbase; nw = 0;
+                if (nzm) { k = __builtin_ctz(nzm); nzm &= nzm - 1; nw = lw[MW0 + k * 64]; nbase = k << 5; }
+              }
+              __hip_atomic_fetch_or(&lw[TW0 + (t >> 5) * 64], 1u << (t & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              nzt |= 1u << (t >> 5);
+            }
+            k = __builtin_ctz(nzt);
+            nzt &= nzt - 1;
+            mw = lw[TW0 + k * 64]; lw[TW0 + k * 64] = 0; base = k << 5; nw = 0;
+            if (nzt) { k = __builtin_ctz(nzt); nzt &= nzt - 1; nw = lw[TW0 + k * 64]; lw[TW0 + k * 64] = 0; nbase = k << 5; }
+            while (mw != 0 && pos < lim) {
+              const uint32_t t = (uint32_t)(idx_off + base + __builtin_ctz(mw));
+              mw &= mw - 1;
+              if (mw == 0) {
+                mw = nw; base = nbase; nw = 0;
+                if (nzt) { k = __builtin_ctz(nzt); nzt &= nzt - 1; nw = lw[TW0 + k * 64]; lw[TW0 + k * 64] = 0; nbase = k << 5; }
+              }
+              append1(t);
+            }
+            append1((uint32_t)T_RADJ);
           }
 #pragma unroll
           for (int w = 0; w < W; ++w) rowc[w] = rn[w];
