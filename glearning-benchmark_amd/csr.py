@@ -66,6 +66,7 @@ class GraphBatch:
     lane_order: Optional[torch.Tensor] = None    # int32 [G] graphs in the order they are dealt to lanes
     adj_words: int = 0
     adj_max_degree: int = 0
+    lane_order_len: int = 0                      # the max_len lane_order was made for (ops.sent)
 
     @property
     def device(self) -> torch.device:

@@ -91,7 +91,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     K kern = W == 1 ? (p4 ? (K)sent_blane_kernel<1, 4> : (K)sent_blane_kernel<1, 8>)
            : W == 2 ? (p4 ? (K)sent_blane_kernel<2, 4> : (K)sent_blane_kernel<2, 8>)
                     : (p4 ? (K)sent_blane_kernel<4, 4> : (K)sent_blane_kernel<4, 8>);
-    const size_t lds = (size_t)5120 * W;   // 20 W dwords per lane (gtok_sent_blane.hpp)
+    const size_t lds = (size_t)4608 * W;   // 18 W dwords per lane (gtok_sent_blane.hpp)
     int dev = 0, ncu = 256, occ = 1;
     if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);

@@ -36,13 +36,13 @@ struct __attribute__((aligned(16))) U64x2 { uint64_t a, b; };
 template <int W, int P>
 __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(const SentBLaneArgs a) {
   // LDS, all of it lane-private and laid out [dword][lane] (bank = lane): 16 W dwords node -> visit index (u8 each),
-  // 2 W dwords bracket members in node space, 2 W dwords bracket members in visit-index space (zero between brackets)
+  // 2 W dwords bracket members in visit-index space (zero between brackets)
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   uint8_t *vx = smem + lane * 4;
   auto vx_at = [&](int u) __attribute__((always_inline)) -> uint8_t & { return vx[((u & ~3) << 6) + (u & 3)]; };
   uint32_t *lw = reinterpret_cast<uint32_t *>(smem) + lane;
-  constexpr int MW0 = 16 * W * 64, TW0 = 18 * W * 64;   // dword offsets of the two word sets
+  constexpr int TW0 = 16 * W * 64;   // dword offset of the visit-index set
 
   const int lim = a.p.max_len, ld = a.ld, cap = min(lim, ld);
   const int idx_off = GTOK_SENT_IDX_OFFSET;
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
 #pragma unroll
     for (int w = 0; w < W; ++w) { vis[w] = 0; rowc[w] = 0; }
 #pragma unroll
-    for (int k = 0; k < 2 * W; ++k) lw[TW0 + k * 64] = 0;   // (a row cut by max_len may leave its last bracket half listed)
+    for (int k = 0; k < 2 * W; ++k) lw[TW0 + k * 64] = 0;
     uint64_t wlo = 0;
     int nvis = 0, pos = 0, fl = 0, d = 0, cur = 0;
 
@@ -132,11 +132,6 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
       pos += cnt;
       if (pos - fl >= 4) { flush(wlo); wlo = over; fl += 4; }
     };
-    auto append1 = [&](uint32_t tok) __attribute__((always_inline)) {
-      wlo |= (uint64_t)tok << ((pos - fl) << 4);
-      ++pos;
-      if (pos - fl == 4) { flush(wlo); wlo = 0; fl += 4; }
-    };
     uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
     auto below = [&](uint32_t nchoices) __attribute__((always_inline)) -> uint32_t {   // d is the same in every active lane
       const int w = uni(d) & 3;
@@ -171,126 +166,194 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
       for (int w = 0; w < W; ++w) t += __popcll(s[w]);
       return t;
     };
-    // lowest member of a W-word set (not empty), removed from it
-    auto pop_lowest = [&](uint64_t (&s)[W]) __attribute__((always_inline)) -> int {
-      int u = 0;
-      bool done = false;
+    // ---- a set of 64 W bits (W registers) consumed in ascending order, 32 bits at a time: `nz` = its sub-words that still
+    // hold members beyond the current one.  Every lane moves through ITS non-empty sub-words, so a wave runs as many
+    // iterations as its largest set has members, whatever words they fall in.  The sub-word is picked out of the
+    // registers by a tree of bit-field inserts under masks made from the bits of its index (the masks go through inline
+    // asm: left to itself the compiler turns the tree into a chain of 2 W compares and selects).
+    struct Stream { uint32_t cur, nz; int base; };
+    auto bit_mask = [](int k, int bit) __attribute__((always_inline)) -> uint32_t {   // all ones if bit `bit` of k is set
+      uint32_t m;
+      if (bit == 0) asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(k));
+      else if (bit == 1) asm("v_bfe_i32 %0, %1, 1, 1" : "=v"(m) : "v"(k));
+      else if (bit == 2) asm("v_bfe_i32 %0, %1, 2, 1" : "=v"(m) : "v"(k));
+      else asm("v_bfe_i32 %0, %1, 3, 1" : "=v"(m) : "v"(k));
+      return m;
+    };
+    auto sub_word = [&](const uint64_t (&sw)[W], int k) __attribute__((always_inline)) -> uint32_t {   // k = -1 (none left): 0
+      uint32_t h[2 * W];
 #pragma unroll
-      for (int w = 0; w < W; ++w) {
-        const bool here = !done && s[w] != 0;
-        if (here) { u = 64 * w + __builtin_ctzll(s[w]); s[w] &= s[w] - 1; }
-        done = done || here;
+      for (int w = 0; w < W; ++w) { h[2 * w] = (uint32_t)sw[w]; h[2 * w + 1] = (uint32_t)(sw[w] >> 32); }
+      int level = 0;
+#pragma unroll
+      for (int span = 1; span < 2 * W; span <<= 1, ++level) {
+        const uint32_t m = bit_mask(k, level);
+#pragma unroll
+        for (int j = 0; j + span < 2 * W; j += 2 * span) h[j] = (h[j] & ~m) | (h[j + span] & m);
       }
+      return h[0] & ~bit_mask(k, level);
+    };
+    auto stream_next = [&](Stream &st, const uint64_t (&sw)[W]) __attribute__((always_inline)) {   // (current sub-word used up)
+      const int k = __ffs((int)st.nz) - 1;   // -1 when nz == 0
+      st.nz &= st.nz - 1;
+      st.cur = sub_word(sw, k);
+      st.base = k << 5;
+    };
+    auto stream_pop = [&](Stream &st, const uint64_t (&sw)[W]) __attribute__((always_inline)) -> int {   // st.cur != 0
+      const int u = st.base + __builtin_ctz(st.cur);
+      st.cur &= st.cur - 1;
+      if (st.cur == 0) stream_next(st, sw);
       return u;
     };
 
+#ifdef GTOK_PHASE_TIMING   // profiling build only: cycles per phase, left in the last 8 columns of the row of the unit's lane 0
+    uint64_t pt[5] = {0, 0, 0, 0, 0}, pt_last = __builtin_amdgcn_s_memtime();
+    uint32_t pt_steps = 0, pt_it1 = 0, pt_it2 = 0;
+    const uint32_t pt_rt0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#define GTOK_PT(i) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); pt[i] += now_ - pt_last; pt_last = now_; }
+#else
+#define GTOK_PT(i)
+#endif
     if (valid) {
       append((uint64_t)GTOK_SENT_SOS, 1);
       if (n > 0) {
-        while (pos < lim) {
-          uint64_t set[W];
-          int cnt = 0;
-#pragma unroll
-          for (int w = 0; w < W; ++w) { set[w] = rowc[w] & ~vis[w]; cnt += __popcll(set[w]); }
-          int kind = 0;
-          if (cnt == 0) {   // dead end: visited nodes that still own an uncovered edge, else another component / isolated node
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-              uint64_t nz = 0;
-#pragma unroll
-              for (int p = 0; p < P; ++p) nz |= c[p][w];
-              set[w] = vis[w] & nz;
-              cnt += __popcll(set[w]);
-            }
-            kind = 1;
-            if (cnt == 0) {
-              kind = 2;
-#pragma unroll
-              for (int w = 0; w < W; ++w) { set[w] = ~vis[w] & validm[w]; cnt += __popcll(set[w]); }
-            }
-          }
-          if (cnt == 0) break;                                  // every node visited, every edge covered
-          const int pick = kth_of(set, (int)below((uint32_t)cnt));
-          uint64_t rn[W];
-          load_row(pick, rn);
-          const bool first = kind != 1;
-          const uint32_t xb = vx_at(pick);                      // visit index of a restart node (kind 1)
-          const uint32_t my = (uint32_t)nvis;
-          if (first) vx_at(pick) = (uint8_t)my;
-          uint64_t tokv;
-          int tokc;
-          {
-            const uint64_t tpos = (uint64_t)((uint32_t)idx_off + (first ? my : xb));
-            const bool has_a = kind == 1 || (kind == 2 && nvis > 0);   // (the walk's first node is a component start without RESET)
-            tokv = has_a ? (T_RESET | (tpos << 16)) : tpos;
-            tokc = has_a ? 2 : 1;
-          }
-          // ---- first visit: the node's neighbours lose an unvisited neighbour; visited neighbours (itself included: self
-          // loop) other than the trail's predecessor form its bracket
-          uint64_t M[W];
+        // The loop is software-pipelined: with the row of step k in hand (counters, visited set and bracket members
+        // brought up to date), the node of step k + 1 is chosen and its row requested BEFORE step k's tokens are written
+        // - the choice does not depend on them - so that the one HBM access of a step travels behind the bracket loops.
+        int kind = 0, pick = 0, after = pos;   // `after`: the row's length once the current step's tokens are out
+        uint32_t xb = 0;
+        bool have = false;                      // false in the first pass only (same in every lane: nothing to write yet)
+        for (;;) {
+          uint64_t M[W], tokv = 0;
+          int tokc = 0;
           bool anym = false;
 #pragma unroll
-          for (int w = 0; w < W; ++w) {
-            const uint64_t S = first ? rn[w] : 0ull;
-            uint64_t b = S;
-#pragma unroll
-            for (int p = 0; p < P; ++p) { const uint64_t t = c[p][w]; c[p][w] = t ^ b; b &= ~t; }
-            const uint64_t pickbit = (pick >> 6) == w ? 1ull << (pick & 63) : 0ull;
-            const uint64_t predbit = (kind == 0 && (cur >> 6) == w) ? 1ull << (cur & 63) : 0ull;
-            vis[w] |= pickbit;
-            M[w] = S & vis[w] & ~predbit;
-            anym = anym || M[w] != 0;
-          }
-          nvis += first;
-          if (anym) { tokv |= T_LADJ << (tokc << 4); ++tokc; }
-          append(tokv, tokc);
-          if (anym && pos < lim) {
-            // LADJ, members by ascending visit index, RADJ.  The members (node space) go to LDS as 32-bit words; every lane
-            // streams through ITS non-empty words (a mask of them in a register, the next word fetched while the current one
-            // is consumed), so that a wave runs as many iterations as its largest bracket has members, whatever words they
-            // fall in.  Each member sets its visit index's bit in the second word set, which is then streamed the same way
-            // in ascending order - one token per iteration - and left zeroed.
-            uint32_t nzm = 0;
+          for (int w = 0; w < W; ++w) M[w] = 0;
+          if (have) {
+#ifdef GTOK_PHASE_TIMING
+            ++pt_steps;
+#endif
+            const bool first = kind != 1;
+            const uint32_t my = (uint32_t)nvis;
+            if (first) vx_at(pick) = (uint8_t)my;
+            {
+              const uint64_t tpos = (uint64_t)((uint32_t)idx_off + (first ? my : xb));   // xb: visit index of a restart node
+              const bool has_a = kind == 1 || (kind == 2 && nvis > 0);   // (the walk's first node is a component start without RESET)
+              tokv = has_a ? (T_RESET | (tpos << 16)) : tpos;
+              tokc = has_a ? 2 : 1;
+            }
+            // first visit: the node's neighbours lose an unvisited neighbour; visited neighbours (itself included: self
+            // loop) other than the trail's predecessor form its bracket
+            int nm = 0;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-              const uint32_t lo = (uint32_t)M[w], hi = (uint32_t)(M[w] >> 32);
-              lw[MW0 + (2 * w) * 64] = lo;
-              lw[MW0 + (2 * w + 1) * 64] = hi;
-              nzm |= (lo ? 1u << (2 * w) : 0u) | (hi ? 2u << (2 * w) : 0u);
+              const uint64_t S = first ? rowc[w] : 0ull;
+              uint64_t b = S;
+#pragma unroll
+              for (int p = 0; p < P; ++p) { const uint64_t t = c[p][w]; c[p][w] = t ^ b; b &= ~t; }
+              const uint64_t pickbit = (pick >> 6) == w ? 1ull << (pick & 63) : 0ull;
+              const uint64_t predbit = (kind == 0 && (cur >> 6) == w) ? 1ull << (cur & 63) : 0ull;
+              vis[w] |= pickbit;
+              M[w] = S & vis[w] & ~predbit;
+              nm += __popcll(M[w]);
             }
-            int k = __builtin_ctz(nzm);
-            nzm &= nzm - 1;
-            uint32_t mw = lw[MW0 + k * 64], nw = 0, nzt = 0;
-            int base = k << 5, nbase = 0;
-            if (nzm) { k = __builtin_ctz(nzm); nzm &= nzm - 1; nw = lw[MW0 + k * 64]; nbase = k << 5; }
-            while (mw != 0) {
-              const uint32_t t = vx_at(base + __builtin_ctz(mw));
-              mw &= mw - 1;
-              if (mw == 0) {
-                mw = nw; base = nbase; nw = 0;
-                if (nzm) { k = __builtin_ctz(nzm); nzm &= nzm - 1; nw = lw[MW0 + k * 64]; nbase = k << 5; }
-              }
-              __hip_atomic_fetch_or(&lw[TW0 + (t >> 5) * 64], 1u << (t & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-              nzt |= 1u << (t >> 5);
-            }
-            k = __builtin_ctz(nzt);
-            nzt &= nzt - 1;
-            mw = lw[TW0 + k * 64]; lw[TW0 + k * 64] = 0; base = k << 5; nw = 0;
-            if (nzt) { k = __builtin_ctz(nzt); nzt &= nzt - 1; nw = lw[TW0 + k * 64]; lw[TW0 + k * 64] = 0; nbase = k << 5; }
-            while (mw != 0 && pos < lim) {
-              const uint32_t t = (uint32_t)(idx_off + base + __builtin_ctz(mw));
-              mw &= mw - 1;
-              if (mw == 0) {
-                mw = nw; base = nbase; nw = 0;
-                if (nzt) { k = __builtin_ctz(nzt); nzt &= nzt - 1; nw = lw[TW0 + k * 64]; lw[TW0 + k * 64] = 0; nbase = k << 5; }
-              }
-              append1(t);
-            }
-            append1((uint32_t)T_RADJ);
+            anym = nm != 0;
+            nvis += first;
+            if (anym) { tokv |= T_LADJ << (tokc << 4); ++tokc; }
+            after = pos + tokc + (anym ? nm + 1 : 0);
+            GTOK_PT(1)
           }
+          // ---- the next node: rowc = row of the node the trail stands on (all zero before the first step)
+          bool more = after < lim;
+          int nkind = 0, npick = 0;
+          uint32_t nxb = 0;
+          uint64_t rn[W];
+#pragma unroll
+          for (int w = 0; w < W; ++w) rn[w] = 0;
+          if (more) {
+            uint64_t set[W];
+            int cnt = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { set[w] = rowc[w] & ~vis[w]; cnt += __popcll(set[w]); }
+            if (cnt == 0) {   // dead end: visited nodes that still own an uncovered edge, else another component / isolated node
+#pragma unroll
+              for (int w = 0; w < W; ++w) {
+                uint64_t nz = 0;
+#pragma unroll
+                for (int p = 0; p < P; ++p) nz |= c[p][w];
+                set[w] = vis[w] & nz;
+                cnt += __popcll(set[w]);
+              }
+              nkind = 1;
+              if (cnt == 0) {
+                nkind = 2;
+#pragma unroll
+                for (int w = 0; w < W; ++w) { set[w] = ~vis[w] & validm[w]; cnt += __popcll(set[w]); }
+              }
+            }
+            more = cnt != 0;                                     // else: every node visited, every edge covered
+            if (more) {
+              npick = kth_of(set, (int)below((uint32_t)cnt));
+              load_row(npick, rn);
+              nxb = vx_at(npick);
+            }
+          }
+          GTOK_PT(0)
+          // ---- the current step's tokens
+          if (have) {
+            append(tokv, tokc);
+            if (anym && pos < lim) {
+              // LADJ, members by ascending visit index, RADJ: each member (node space, any order) sets its visit index's
+              // bit in the lane's LDS set (two per iteration: two independent LDS reads in flight) ...
+              Stream sm;
+              sm.nz = 0;
+#pragma unroll
+              for (int w = 0; w < W; ++w)
+                sm.nz |= ((uint32_t)M[w] ? 1u << (2 * w) : 0u) | ((uint32_t)(M[w] >> 32) ? 2u << (2 * w) : 0u);
+              stream_next(sm, M);
+              uint32_t nzt = 0;
+              while (sm.cur != 0) {
+                const int u1 = stream_pop(sm, M);
+                const int u2 = sm.cur != 0 ? stream_pop(sm, M) : u1;
+                const uint32_t t1 = vx_at(u1), t2 = vx_at(u2);
+                __hip_atomic_fetch_or(&lw[TW0 + (t1 >> 5) * 64], 1u << (t1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_or(&lw[TW0 + (t2 >> 5) * 64], 1u << (t2 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                nzt |= (1u << (t1 >> 5)) | (1u << (t2 >> 5));
+#ifdef GTOK_PHASE_TIMING
+                ++pt_it1;
+#endif
+              }
+              GTOK_PT(2)
+              // ... which is then read back whole, zeroed, and listed in ascending order, two tokens per iteration, RADJ
+              // with the last
+              uint64_t T[W];
+#pragma unroll
+              for (int w = 0; w < W; ++w) {
+                const uint32_t lo = lw[TW0 + (2 * w) * 64], hi = lw[TW0 + (2 * w + 1) * 64];
+                T[w] = ((uint64_t)hi << 32) | lo;
+                lw[TW0 + (2 * w) * 64] = 0; lw[TW0 + (2 * w + 1) * 64] = 0;
+              }
+              Stream stt;
+              stt.nz = nzt;
+              stream_next(stt, T);
+              while (stt.cur != 0 && pos < lim) {
+                uint64_t val = (uint64_t)(uint32_t)(idx_off + stream_pop(stt, T));
+                int cntt = 1;
+                if (stt.cur != 0) { val |= (uint64_t)(uint32_t)(idx_off + stream_pop(stt, T)) << 16; cntt = 2; }
+                if (stt.cur == 0) { val |= T_RADJ << (cntt << 4); ++cntt; }
+                append(val, cntt);
+#ifdef GTOK_PHASE_TIMING
+                ++pt_it2;
+#endif
+              }
+              GTOK_PT(3)
+            }
+          }
+          if (!more) break;
+          cur = pick; pick = npick; kind = nkind; xb = nxb;
 #pragma unroll
           for (int w = 0; w < W; ++w) rowc[w] = rn[w];
-          cur = pick;
+          have = true;
         }
       }
       append(T_EOS, 1);
@@ -353,6 +416,15 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
       }
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef GTOK_PHASE_TIMING
+    GTOK_PT(4)
+    if (lane == 0 && ld >= 16) {
+      int32_t *row = a.out + (int64_t)g * ld + ld - 8;
+      row[0] = (int32_t)pt[0]; row[1] = (int32_t)pt[1]; row[2] = (int32_t)pt[2]; row[3] = (int32_t)pt[3]; row[4] = (int32_t)pt[4];
+      row[5] = (int32_t)uni(pt_steps); row[6] = (int32_t)((uni(pt_it1) << 16) | uni(pt_it2));
+      row[7] = (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - pt_rt0);
+    }
+#endif
   }
 }
 

@@ -135,6 +135,23 @@ def pack8(batch: GraphBatch) -> bool:
     return True
 
 
+def _lane_order(batch: GraphBatch, typical_len: int) -> torch.Tensor:
+    """The order sent_blane_kernel's lanes take the graphs in (64 consecutive entries share a wave, and a wave lasts as
+    long as its slowest walk and, at every step, as its largest bracket).  A heuristic that only moves time, never tokens:
+    graphs are grouped by the number of trail steps they are expected to take (n for a walk that ends by itself; fewer when
+    the row is cut at `typical_len` tokens: a step of a graph of density p writes about 3 + p t tokens at step t), and by
+    density within a group, so that the brackets of a wave's walks grow at the same pace."""
+    n = (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.float64)
+    e = (batch.edge_ptr[1:] - batch.edge_ptr[:-1]).to(torch.float64)
+    if batch.flags & _lib.CSR_SIMPLE_SYMMETRIC:
+        e = e / 2
+    p = (2 * e / (n * n).clamp(min=1)).clamp(min=1e-6, max=1.0)
+    cut = (torch.sqrt(9 + 2 * p * float(typical_len)) - 3) / p            # 3 t + p t^2 / 2 = typical_len
+    steps = torch.where(e + 2 * n > typical_len, torch.minimum(cut, n), n).round().clamp(0, 1023).to(torch.int64)
+    key = steps * 1024 + (p * 1023).round().to(torch.int64)
+    return torch.argsort(key, descending=True, stable=True).to(torch.int32)
+
+
 def adjbits(batch: GraphBatch) -> bool:
     """Give a device batch of graphs with <= 256 nodes its adjacency bit-matrix mirror (gtok_csr_adjbits; once per
     batch, kept on the batch object) and the order its graphs are dealt to lanes (longest walks first, so that the 64
@@ -159,10 +176,6 @@ def adjbits(batch: GraphBatch) -> bool:
     if maxdeg > 255:          # a 256-node graph with a full row and a self loop: 8 counter planes cannot hold it
         return False
     batch.adj_rows, batch.adj_planes, batch.adj_words, batch.adj_max_degree = rows, planes, W, maxdeg
-    if os.environ.get("GTOK_BLANE_ORDER", "1") != "0":
-        # walk length ~ nodes + edges: deal graphs to lanes in descending order of it
-        cost = (batch.edge_ptr[1:] - batch.edge_ptr[:-1]).to(torch.int64) + 2 * (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.int64)
-        batch.lane_order = torch.argsort(cost, descending=True, stable=True).to(torch.int32)
     return True
 
 
@@ -184,7 +197,8 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
     ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
     pack8(batch)
     if not labeled and not remap_zinc and batch.num_graphs >= ADJBITS_MIN_GRAPHS or os.environ.get("GTOK_SENT_KERNEL") == "blane":
-        adjbits(batch)
+        if adjbits(batch) and os.environ.get("GTOK_BLANE_ORDER", "1") != "0" and batch.lane_order_len != max(1, max_len):
+            batch.lane_order, batch.lane_order_len = _lane_order(batch, max(1, max_len)), max(1, max_len)   # once per (batch, max_len)
     p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc),
                        pad_id, 0 if pad else _lib.SENT_NO_PAD, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
                        None if query is None else query.data_ptr())
