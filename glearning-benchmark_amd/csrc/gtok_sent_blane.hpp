@@ -79,6 +79,15 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
 #pragma unroll
         for (int w = 0; w < W; ++w) c[p][w] = valid ? pl[p * W + w] : 0ull;
     }
+    // planes in use in this unit (the same in every lane): counts only go down, so a plane that starts all zero stays so
+    int peff = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      uint64_t any = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) any |= c[p][w];
+      if (__ballot(any != 0)) peff = p + 1;
+    }
     uint64_t validm[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) { const int r = n - 64 * w; validm[w] = r >= 64 ? ~0ull : (r > 0 ? ((1ull << r) - 1ull) : 0ull); }
@@ -245,12 +254,18 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
             // first visit: the node's neighbours lose an unvisited neighbour; visited neighbours (itself included: self
             // loop) other than the trail's predecessor form its bracket
             int nm = 0;
+            uint64_t bw[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) bw[w] = first ? rowc[w] : 0ull;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+              if (p < peff) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) { const uint64_t t = c[p][w]; c[p][w] = t ^ bw[w]; bw[w] &= ~t; }
+              }
 #pragma unroll
             for (int w = 0; w < W; ++w) {
               const uint64_t S = first ? rowc[w] : 0ull;
-              uint64_t b = S;
-#pragma unroll
-              for (int p = 0; p < P; ++p) { const uint64_t t = c[p][w]; c[p][w] = t ^ b; b &= ~t; }
               const uint64_t pickbit = (pick >> 6) == w ? 1ull << (pick & 63) : 0ull;
               const uint64_t predbit = (kind == 0 && (cur >> 6) == w) ? 1ull << (cur & 63) : 0ull;
               vis[w] |= pickbit;
@@ -276,14 +291,17 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
 #pragma unroll
             for (int w = 0; w < W; ++w) { set[w] = rowc[w] & ~vis[w]; cnt += __popcll(set[w]); }
             if (cnt == 0) {   // dead end: visited nodes that still own an uncovered edge, else another component / isolated node
+              uint64_t nz[W];
 #pragma unroll
-              for (int w = 0; w < W; ++w) {
-                uint64_t nz = 0;
+              for (int w = 0; w < W; ++w) nz[w] = 0;
 #pragma unroll
-                for (int p = 0; p < P; ++p) nz |= c[p][w];
-                set[w] = vis[w] & nz;
-                cnt += __popcll(set[w]);
-              }
+              for (int p = 0; p < P; ++p)
+                if (p < peff) {
+#pragma unroll
+                  for (int w = 0; w < W; ++w) nz[w] |= c[p][w];
+                }
+#pragma unroll
+              for (int w = 0; w < W; ++w) { set[w] = vis[w] & nz[w]; cnt += __popcll(set[w]); }
               nkind = 1;
               if (cnt == 0) {
                 nkind = 2;
