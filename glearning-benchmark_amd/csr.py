@@ -67,6 +67,10 @@ class GraphBatch:
     adj_words: int = 0
     adj_max_degree: int = 0
     lane_order_len: int = 0                      # the max_len lane_order was made for (ops.sent)
+    graph_ids: Optional[torch.Tensor] = None     # a batch reordered for the lane-per-graph SENT kernel (ops.lane_sorted):
+    unit_ptr: Optional[torch.Tensor] = None      # int32 [G] dataset index of every slot, int32 [units + 1] slots per wave
+    num_units: int = 0
+    lane_sorted: Optional["GraphBatch"] = None   # the reordered copy of THIS batch (device batches, made on first use)
 
     @property
     def device(self) -> torch.device:
@@ -85,14 +89,16 @@ class GraphBatch:
         return GraphBatch(self.num_graphs, self.max_nodes, self.max_edges, mv(self.node_ptr), mv(self.edge_ptr),
                           mv(self.rowptr), mv(self.col), mv(self.eorder), mv(self.nattr), mv(self.eattr),
                           self.flags, self.chunk_nodes, self.chunk_edges, self.max_degree, mv(self.rowptr8), mv(self.col8),
-                          mv(self.adj_rows), mv(self.adj_planes), mv(self.lane_order), self.adj_words, self.adj_max_degree)
+                          mv(self.adj_rows), mv(self.adj_planes), mv(self.lane_order), self.adj_words, self.adj_max_degree,
+                          0, mv(self.graph_ids), mv(self.unit_ptr), self.num_units)
 
     def c_struct(self) -> GtokCsr:
         p = lambda t: None if t is None else t.data_ptr()
         return GtokCsr(self.num_graphs, self.max_nodes, self.max_edges, self.flags, p(self.node_ptr), p(self.edge_ptr),
                        p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr),
                        self.chunk_nodes, self.chunk_edges, self.max_degree, 0, p(self.rowptr8), p(self.col8),
-                       p(self.adj_rows), p(self.adj_planes), p(self.lane_order), self.adj_words, self.adj_max_degree)
+                       p(self.adj_rows), p(self.adj_planes), p(self.lane_order), self.adj_words, self.adj_max_degree,
+                       p(self.graph_ids), p(self.unit_ptr), self.num_units, 0)
 
     def node_counts(self) -> torch.Tensor:
         return self.node_ptr[1:] - self.node_ptr[:-1]

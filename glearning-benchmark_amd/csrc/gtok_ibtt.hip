@@ -1417,7 +1417,8 @@ static Launch plan(const void *kern, int num_items, int wpb, size_t lds) {
 }
 
 static bool csr_ok(const gtok_csr *g) {
-  return g && g->num_graphs >= 0 && g->node_ptr && g->edge_ptr && g->rowptr && (g->max_edges <= 0 || g->col);
+  return g && g->num_graphs >= 0 && g->node_ptr && g->edge_ptr && g->rowptr && (g->max_edges <= 0 || g->col) &&
+         !g->graph_ids && !g->unit_ptr;   // (a batch reordered for the lane-per-graph SENT kernel is for gtok_sent alone)
 }
 
 }  // namespace gtok

@@ -19,6 +19,7 @@
 #include "gtok.h"
 #include "gtok_sent_reg.hpp"
 #include "gtok_sent_lds.hpp"
+#include <cstdio>
 #include "gtok_sent_lane.hpp"
 #include "gtok_sent_blane.hpp"
 
@@ -45,6 +46,11 @@ static int choose_sent_kernel(const gtok_csr *g, const gtok_sent_params *p) {
                         g->adj_max_degree <= 255;
   if (pin_blane && blane_ok) return 3;
   const bool fold_ok = !p->remap_zinc || g->max_nodes <= p->max_num_nodes;   // remap folded into constants
+  if (g->graph_ids || g->unit_ptr) {   // a reordered batch: the lane kernel or nothing (-1)
+    const bool ok = g->graph_ids && g->unit_ptr && g->num_units > 0 && maxn <= 64 && g->max_edges <= 255 &&
+                    (g->flags & GTOK_CSR_SIMPLE_SYMMETRIC) && fold_ok && g->chunk_nodes > 0;
+    return ok ? 0 : -1;
+  }
   const bool lane_ok = maxn <= 64 && g->max_edges <= 255 && (g->flags & GTOK_CSR_SIMPLE_SYMMETRIC) && fold_ok;
   const bool reg_ok = maxn <= 64 && g->max_edges <= 32768 && fold_ok &&
                       22 + GTOK_SENT_IDX_OFFSET + p->max_num_nodes + p->num_node_types + 256 < kEdgeRef;
@@ -81,6 +87,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   const int cap = p->max_len < ld ? p->max_len : ld;
   const int maxe = g->max_edges > 0 ? g->max_edges : 1;
   const int which = choose_sent_kernel(g, p);
+  if (which < 0) return GTOK_E_INVAL;       // a reordered batch the lane-per-graph kernel cannot take
   const bool lane_path = which == 0, reg_path = which == 1;
   if (which == 3) {
     SentBLaneArgs a;
@@ -139,7 +146,16 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
       const int c = std::atoi(cs);
       if (c >= 1 && c < occ) occ = c;
     }
-    a.units = (g->num_graphs + 63) / 64;
+    a.units = g->unit_ptr ? g->num_units : (g->num_graphs + 63) / 64;
+    a.unit_mul = 0;
+    a.prio_cut[0] = 16; a.prio_cut[1] = 32; a.prio_cut[2] = 48;   // quartiles (profiles/tools/lane_prio_sweep.sh)
+    if (const char *pc = std::getenv("GTOK_LANE_PRIO_CUTS")) std::sscanf(pc, "%d,%d,%d", &a.prio_cut[0], &a.prio_cut[1], &a.prio_cut[2]);   // tuning knob
+    if (g->unit_ptr && a.units > 16) {
+      auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
+      int m = (int)(a.units * 0.6180339887498949);
+      while (gcd(m, a.units) != 1) ++m;
+      a.unit_mul = m;
+    }
     int nb = ncu * occ;
     if (nb > a.units) nb = a.units;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64), (size_t)a.lds, (hipStream_t)stream, a);
@@ -244,7 +260,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
 extern "C" int gtok_csr_adjbits(const gtok_csr *g, int32_t words, uint64_t *rows, uint64_t *planes, int32_t *info, void *stream) {
   gtok::DeviceScope device_scope((hipStream_t)stream);
   if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
-  if (!g || g->num_graphs < 0 || (words != 1 && words != 2 && words != 4)) return GTOK_E_INVAL;
+  if (!g || g->num_graphs < 0 || (words != 1 && words != 2 && words != 4) || g->graph_ids || g->unit_ptr) return GTOK_E_INVAL;
   if (g->max_nodes > 64 * words) return GTOK_E_TOO_LARGE;
   if (g->num_graphs == 0) return GTOK_OK;
   if (!g->node_ptr || !g->edge_ptr || !g->rowptr || (g->max_edges > 0 && !g->col) || !rows || !planes || !info) return GTOK_E_INVAL;
@@ -387,6 +403,7 @@ extern "C" const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_
   const int maxn = g->max_nodes > 0 ? g->max_nodes : 1;
   static const char *bl[] = {"sent_blane_kernel<W=1>", "sent_blane_kernel<W=2>", "sent_blane_kernel<W=4>"};
   switch (choose_sent_kernel(g, p)) {
+    case -1: return "";
     case 0: return "sent_lane_kernel";
     case 1: return "sent_reg_kernel";
     case 3: return bl[maxn <= 64 ? 0 : maxn <= 128 ? 1 : 2];

@@ -91,7 +91,9 @@ struct SentLaneArgs {
   int32_t *out;
   int ld;
   int32_t *out_len;
-  int units;                               // 64-graph units in the batch
+  int units;
+  int unit_mul;   // 0: units in order
+  int prio_cut[3];   // reordered batch: units below these ranks (in 64ths of the stored order) run at priority 3 / 2 / 1                               // 64-graph units in the batch
 };
 
 // PK: the batch carries the byte-packed rowptr / col mirror (gtok_csr.rowptr8 / col8): a unit is staged with 12
@@ -126,10 +128,11 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
   struct Hdr { int g0, gl, N0, N1; int64_t E0, E1; int nb0, nfull, n, e; int64_t e0; bool valid; };
   auto header = [&](int unit) __attribute__((always_inline)) -> Hdr {
     Hdr h;
-    h.g0 = unit * 64; h.gl = min(h.g0 + 64, G);
+    if (a.g.unit_ptr) { h.g0 = sload(a.g.unit_ptr, unit); h.gl = sload(a.g.unit_ptr, unit + 1); }   // reordered batch: <= 64 slots
+    else { h.g0 = unit * 64; h.gl = min(h.g0 + 64, G); }
     h.N0 = sload(a.g.node_ptr, h.g0); h.N1 = sload(a.g.node_ptr, h.gl);
     h.E0 = sload(a.g.edge_ptr, h.g0); h.E1 = sload(a.g.edge_ptr, h.gl);
-    h.valid = h.g0 + lane < G;
+    h.valid = h.g0 + lane < h.gl;
     h.nb0 = h.N0; h.nfull = 0; h.e0 = h.E0; h.e = 0;
     if (h.valid) {
       h.nb0 = a.g.node_ptr[h.g0 + lane];
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
   // Units are dealt round-robin (a unit's time is the longest of its 64 walks: they are all alike); with 16
   // resident waves per CU a ZINC-full launch gives every wave exactly one unit.
   const int stride = (int)gridDim.x;
-  int lw = 0, done_g0 = -1;                 // pad start of this lane's finished row / first graph of the finished unit
+  int lw = 0, done_row = -1, done_cnt = 0;  // pad start of this lane's finished row, that row (-1: none), rows of the finished unit
   // pad the tails of a finished unit's 64 rows: four rows per pass, 16 lanes x 16-byte stores on each
   const bool no_pad = (a.p.flags & GTOK_SENT_NO_PAD) != 0;
   auto pad_rows = [&]() __attribute__((always_inline)) {
@@ -217,9 +220,10 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
     for (int it = 0; it < 16; ++it) {
       const int r = it * 4 + (lane >> 4);
       const int lr = __builtin_amdgcn_ds_bpermute(r << 2, lw);
-      if (done_g0 + it * 4 >= G) break;
-      if (done_g0 + r < G) {
-        int32_t *__restrict__ rowp = a.out + (int64_t)(done_g0 + r) * ld + lr;
+      const int gr = __builtin_amdgcn_ds_bpermute(r << 2, done_row);   // (rows of a reordered batch are not neighbours)
+      if (it * 4 >= done_cnt) break;
+      if (gr >= 0) {
+        int32_t *__restrict__ rowp = a.out + (int64_t)gr * ld + lr;
         const int nrem = ld - lr, nvec = nrem >> 2;
         _Pragma("clang loop vectorize(disable) unroll(disable)")
         for (int t = q; t < nvec; t += 16) store_pad16(rowp + 4 * t, pad);
@@ -231,15 +235,20 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
   uint64_t ts[5] = {0, 0, 0, 0, 0};
   uint32_t rt0 = 0, iters = 0;
   auto stamps_out = [&]() __attribute__((always_inline)) {
-    if (lane == 0 && ld >= 16 && done_g0 >= 0) {
-      int32_t *row = a.out + (int64_t)done_g0 * ld + ld - 8;
+    if (lane == 0 && ld >= 16 && done_row >= 0) {
+      int32_t *row = a.out + (int64_t)done_row * ld + ld - 8;
       row[0] = (int32_t)(ts[1] - ts[0]); row[1] = (int32_t)(ts[2] - ts[1]); row[2] = (int32_t)(ts[3] - ts[2]);
       row[3] = (int32_t)(ts[4] - ts[3]); row[4] = (int32_t)rt0; row[5] = (int32_t)__builtin_amdgcn_s_memrealtime();
       row[6] = (int32_t)iters; row[7] = (int32_t)blockIdx.x;
     }
   };
 #endif
-  for (int unit = virtual_block(); unit < a.units; unit += stride) {
+  // A reordered batch stores its units by descending walk length: dealt as they come, one XCD (virtual_block) or one CU
+  // would get all the long ones.  unit = idx * unit_mul mod units (unit_mul ~ units / golden ratio, coprime): every run of
+  // consecutive workgroups and every arithmetic progression of them - whichever way the dispatcher fills XCDs, CUs and
+  // SIMDs - samples the whole range of lengths.
+  for (int idx = a.unit_mul ? (int)blockIdx.x : virtual_block(); idx < a.units; idx += stride) {
+    const int unit = a.unit_mul ? (int)(((uint64_t)(uint32_t)idx * (uint32_t)a.unit_mul) % (uint32_t)a.units) : idx;
     // ---- stage this unit; the loads of phase A go out ahead of the previous unit's padding stores
 #ifdef GTOK_PHASE_TIMING
     const uint64_t ts0_new = __builtin_amdgcn_s_memtime();
@@ -247,7 +256,7 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
 #endif
     const Hdr h = header(unit);
     auto between = [&]() __attribute__((always_inline)) {   // behind the loads, ahead of the LDS writes
-      if (done_g0 >= 0) pad_rows();
+      if (done_cnt > 0) pad_rows();
 #ifdef GTOK_PHASE_TIMING
       stamps_out();
       ts[0] = ts0_new; rt0 = rt0_new; iters = 0;
@@ -272,16 +281,24 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
 #ifdef GTOK_PHASE_TIMING
     ts[1] = __builtin_amdgcn_s_memtime();
 #endif
-    const int g = h.g0 + lane;
+    const int slot = h.g0 + lane;
     const bool valid = h.valid;
+    // the graph's dataset index: output row, out_len / query entry and RNG identity (slot = where its CSR is stored)
+    const int g = valid && a.g.graph_ids ? a.g.graph_ids[slot] : slot;
     const int n = h.n, e = h.e;
     const int rbase = (h.nb0 - h.N0) + lane, cbase = (int)(h.e0 - h.E0), nbase = h.nb0 - h.N0;
 
 #ifndef GTOK_LANE_NO_PRIO
-    // A unit runs as long as its longest walk, and a launch as long as its slowest unit (one unit per wave): units
-    // that hold one of the batch's largest graphs - the likely stragglers, walk length grows with the node count -
-    // get a higher issue priority than the waves they share a SIMD with, which have slack.
-    {
+    // A unit runs as long as its longest walk, and a launch as long as its slowest unit: the likely stragglers get a
+    // higher issue priority than the waves they share a SIMD with, which have slack.  A reordered batch stores its units
+    // by descending walk length (the first eighth are the stragglers); otherwise the unit's largest graph predicts it.
+    if (a.g.unit_ptr) {
+      const int rank = (int)(((int64_t)unit << 6) / a.units);   // 0..63
+      if (rank < a.prio_cut[0]) __builtin_amdgcn_s_setprio(3);
+      else if (rank < a.prio_cut[1]) __builtin_amdgcn_s_setprio(2);
+      else if (rank < a.prio_cut[2]) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    } else {
       int mx = n;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
@@ -564,12 +581,13 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
     }
 
     lw = padfrom;
-    done_g0 = h.g0;
+    done_row = valid ? g : -1;
+    done_cnt = h.gl - h.g0;
 #ifdef GTOK_PHASE_TIMING
     ts[4] = __builtin_amdgcn_s_memtime();
 #endif
   }
-  if (done_g0 >= 0) pad_rows();
+  if (done_cnt > 0) pad_rows();
 #ifdef GTOK_PHASE_TIMING
   stamps_out();
 #endif

@@ -113,6 +113,17 @@ typedef struct gtok_csr {
   const int32_t *lane_order;
   int32_t adj_words;      /* 1, 2 or 4 = ceil(max_nodes / 64) rounded up to a power of two */
   int32_t adj_max_degree;
+  /* A batch REORDERED for the lane-per-graph SENT kernel (optional; NULL / 0 = the batch is in dataset order).
+   * graph_ids[s] = the dataset index of the graph stored at slot s: the row of the output slab, the entries of out_len
+   * and `query`, and the RNG identity (graph_base + graph_ids[s]) follow it, so the result is that of the batch in
+   * dataset order.  unit_ptr[num_units + 1] = the slots dealt to each wave (<= 64 per unit; chunk_nodes / chunk_edges
+   * = the largest unit's sums).  Storing the graphs by descending walk length lets the 64 walks of a wave end together
+   * (a wave lasts as long as its longest walk).  Only gtok_sent's lane-per-graph kernel accepts such a batch
+   * (GTOK_E_INVAL from every other entry point and when another SENT kernel would be chosen).                      */
+  const int32_t *graph_ids;
+  const int32_t *unit_ptr;
+  int32_t num_units;
+  int32_t reserved2;
 } gtok_csr;
 
 /* LUT layout for gtok_ibtt_zinc (int32 vocab ids; an absent token holds pad_id

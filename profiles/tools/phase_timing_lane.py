@@ -21,7 +21,10 @@ for k in range(3):
     ids, ln = gtok.ops.sent(b, 37, 1024, 0, k, ld=ld, **kw)
 torch.cuda.synchronize()
 assert int(ln.max()) <= ld - 8
-ph = ids[::64, -8:].cpu().numpy().astype(np.int64)
+sb = b.lane_sorted          # the reordered copy ops.sent walks by default (GTOK_NO_LANE_SORT=1: the batch as stored)
+first = torch.arange(0, G, 64, device=dev) if sb is None else sb.graph_ids[sb.unit_ptr[:-1].long()].long()
+print("units", first.numel(), "reordered" if sb is not None else "dataset order")
+ph = ids[first][:, -8:].cpu().numpy().astype(np.int64)
 names = ["staging", "counter init", "walk", "row end"]
 tot = ph[:, :4].sum()
 for i, nme in enumerate(names):

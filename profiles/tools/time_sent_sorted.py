@@ -1,43 +1,31 @@
-"""Experiment: does grouping molecules of similar size into the same 64-graph unit speed the lane kernel up?
-Times gtok_sent on the ZINC-shaped corpus as generated, and with the graphs reordered by node count."""
-import importlib, os, sys
-import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
+"""What would sorting the corpus by molecule size buy sent_lane_kernel?  Times the ZINC-shaped corpus in dataset order
+and physically sorted by node count (descending / ascending)."""
+import importlib, os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
 gtok = importlib.import_module("glearning-benchmark_amd")
 dev = torch.device("cuda", 0)
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 249456
-d = gtok.synth.zinc_like(G, seed=1000)
+d = gtok.synth.zinc_like(249456, seed=1000)
+kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
 
-def reorder(d, perm):
-    nc, ec = d["node_counts"], d["edge_counts"]
-    nptr = np.concatenate([[0], np.cumsum(nc)]); eptr = np.concatenate([[0], np.cumsum(ec)])
-    nidx = np.concatenate([np.arange(nptr[g], nptr[g + 1]) for g in perm]) if len(perm) < 1000 else None
-    # vectorised gather of variable-length segments
-    def seg(ptr, cnt):
-        c = cnt[perm]; start = ptr[perm]
-        off = np.repeat(start - (np.cumsum(c) - c), c)
-        return np.arange(int(c.sum())) + off
-    ni, ei = seg(nptr[:-1], nc), seg(eptr[:-1], ec)
-    return dict(node_counts=nc[perm], edge_counts=ec[perm], src=d["src"][ei], dst=d["dst"][ei], x=d["x"][ni], edge_attr=d["edge_attr"][ei])
 
-def run(tag, d):
-    host = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+def permuted(d, perm):
+    nptr = np.concatenate([[0], np.cumsum(d["node_counts"])]); eptr = np.concatenate([[0], np.cumsum(d["edge_counts"])])
+    nidx = np.concatenate([np.arange(nptr[g], nptr[g + 1]) for g in perm])
+    eidx = np.concatenate([np.arange(eptr[g], eptr[g + 1]) for g in perm])
+    return dict(node_counts=d["node_counts"][perm], edge_counts=d["edge_counts"][perm], src=d["src"][eidx], dst=d["dst"][eidx],
+                x=d["x"][nidx], edge_attr=d["edge_attr"][eidx])
+
+
+for name, perm in (("dataset order", None), ("descending size", np.argsort(-d["node_counts"], kind="stable")),
+                   ("ascending size", np.argsort(d["node_counts"], kind="stable"))):
+    dd = d if perm is None else permuted(d, perm)
+    host = gtok.GraphBatch.from_coo(dd["node_counts"], dd["edge_counts"], dd["src"], dd["dst"], dd["x"], dd["edge_attr"])
     b = host.to(dev)
-    ld = 200
-    ids = torch.empty((G, ld), dtype=torch.int32, device=dev); ln = torch.empty(G, dtype=torch.int32, device=dev)
-    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
-    for _ in range(3):
-        gtok.ops.sent(b, 37, 1024, 0, 0, ld=ld, out=(ids, ln), **kw)
+    ids = torch.empty((b.num_graphs, 208), dtype=torch.int32, device=dev); ln = torch.empty(b.num_graphs, dtype=torch.int32, device=dev)
+    for _ in range(3): gtok.ops.sent(b, 37, 1024, 0, 0, ld=208, out=(ids, ln), **kw)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for k in range(20):
-        gtok.ops.sent(b, 37, 1024, 0, k, ld=ld, out=(ids, ln), **kw)
+    for k in range(20): gtok.ops.sent(b, 37, 1024, 0, k, ld=208, out=(ids, ln), **kw)
     e.record(); torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / 20
-    print(f"{tag:28s} chunk_nodes {host.chunk_nodes:5d} chunk_edges {host.chunk_edges:5d}  {ms:7.4f} ms  {G / ms / 1e3:8.1f} M graphs/s", flush=True)
-
-run("as generated", d)
-run("sorted by node count", reorder(d, np.argsort(d["node_counts"], kind="stable")))
-run("sorted descending", reorder(d, np.argsort(-d["node_counts"], kind="stable")))
+    print(f"{name:16s} {gtok.ops.sent_kernel_name(b, 37, 1024, **kw)} chunk_nodes {b.chunk_nodes} chunk_edges {b.chunk_edges}: {s.elapsed_time(e)/20:.4f} ms", flush=True)

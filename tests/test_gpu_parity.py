@@ -169,15 +169,21 @@ def test_collate():
 
 
 def _pin_sent(monkeypatch, pin):
-    """GTOK_SENT_KERNEL pin; "lane-int32" = the lane kernel staging from the int32 CSR (no byte-packed mirror)."""
+    """GTOK_SENT_KERNEL pin; "lane-int32" = the lane kernel staging from the int32 CSR (no byte-packed mirror),
+    "lane-unsorted" = the lane kernel on the batch as stored (64 neighbouring graphs per wave) instead of its
+    copy reordered by walk length (ops.lane_sorted, the default)."""
     monkeypatch.setenv("GTOK_SENT_KERNEL", pin.split("-")[0])
     if pin == "lane-int32":
         monkeypatch.setenv("GTOK_NO_PACK8", "1")
     else:
         monkeypatch.delenv("GTOK_NO_PACK8", raising=False)
+    if pin == "lane-unsorted":
+        monkeypatch.setenv("GTOK_NO_LANE_SORT", "1")
+    else:
+        monkeypatch.delenv("GTOK_NO_LANE_SORT", raising=False)
 
 
-@pytest.mark.parametrize("pin", ["lane", "lane-int32", "reg", "lds"])
+@pytest.mark.parametrize("pin", ["lane", "lane-int32", "lane-unsorted", "reg", "lds"])
 def test_sent_every_kernel_same_tokens(pin, monkeypatch):
     """Three kernels implement the one SENT spec (lane-per-graph - staged from the byte-packed mirror or from the
     int32 CSR -, register-resident wave-per-graph, LDS bit matrix); GTOK_SENT_KERNEL pins one per call.  Each must
@@ -460,7 +466,7 @@ def test_sent_at_the_size_boundaries_of_the_kernels(top, monkeypatch):
     d = _rings_with_chords(sizes, chords, seed=top)
     batch, coo = both(d)
     assert batch.flags & 1
-    pins = ["lane", "lane-int32", "reg", "lds"] if top <= 64 else ["lds"]
+    pins = ["lane", "lane-int32", "lane-unsorted", "reg", "lds"] if top <= 64 else ["lds"]
     for pin in pins:
         _pin_sent(monkeypatch, pin)
         for labeled in (True, False):
@@ -886,7 +892,7 @@ def test_lane_kernel_many_units_per_wave_and_chunks_beyond_the_staging_registers
             _cmp(ids, ln, ref, rln, f"dense units [{pin}] labeled={labeled} max_len={max_len}")
 
 
-@pytest.mark.parametrize("pin", ["lane", "lane-int32", "reg"])
+@pytest.mark.parametrize("pin", ["lane", "lane-int32", "lane-unsorted", "reg"])
 def test_lane_kernel_row_ends_query_tail_cuts_and_odd_slabs(pin, monkeypatch):
     """Everything sent_lane_kernel does at the END of a row, on graphs it accepts (symmetric molecules): the query tail
     (labelled and unlabelled, remapped or not), rows cut by max_len at every phase of the 4-token window and of the
