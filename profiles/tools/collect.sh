@@ -3,21 +3,26 @@
 # passes (FETCH_SIZE, WRITE_SIZE, SQ instruction mix, SQ waits) for both workloads.  Usage (from the repo root):
 #   gpurun --timeout 1200 -- 'bash profiles/tools/collect.sh r02'
 # Everything lands in gpurun_out/collect_<tag>/; profiles/tools/collect_merge.py turns it into profiles/<tag>/.
-set -e -o pipefail
+set -o pipefail
 tag=${1:-r02}
 out=gpurun_out/collect_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 B="python3 bench.py --steps 20 --warmup 3"
-timeout -k 10 400 $B > $out/bench_zinc_full.json 2> $out/bench_zinc_full.err
-timeout -k 10 400 $B --workload synth_er > $out/bench_synth_er.json 2> $out/bench_synth_er.err
-timeout -k 10 600 $B --workload synth_mix --no-cpu-baseline > $out/bench_synth_mix.json 2> $out/bench_synth_mix.err
-timeout -k 10 400 $B --workload zinc_subset > $out/bench_zinc_subset.json 2> $out/bench_zinc_subset.err
-for wl in zinc_full synth_er; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o s -- $B --workload $wl --no-cpu-baseline --no-unpadded > $out/stats_$wl.log 2>&1
+ok=1       # after a step fails or is killed at its limit no further GPU step is started; what was collected is still trimmed below
+step() { [ $ok = 1 ] || return 0; "$@" || { ok=0; echo "FAILED: $*"; }; }
+run_to() { local o=$1; shift; "$@" > $o 2> ${o%.json}.err; }
+step run_to $out/bench_zinc_full.json timeout -k 10 400 $B
+step run_to $out/bench_synth_er.json timeout -k 10 400 $B --workload synth_er
+step run_to $out/bench_synth_mix.json timeout -k 10 600 $B --workload synth_mix --no-cpu-baseline
+step run_to $out/bench_zinc_subset.json timeout -k 10 400 $B --workload zinc_subset
+prof() { local log=$1; shift; "$@" > $log 2>&1; local rc=$?; find $out -name '*_kernel_trace.csv' -delete; return $rc; }
+for wl in zinc_full synth_er synth_mix; do
+  step prof $out/stats_$wl.log timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o s -- $B --workload $wl --no-cpu-baseline --no-unpadded
+  [ $wl = synth_mix ] && continue      # (its corpus is sampled by thousands of torch launches: far too slow under counter collection)
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS"; do
     name=$(echo $grp | cut -d' ' -f1)
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc_${wl}_$name -o p -- python3 bench.py --steps 5 --warmup 1 --workload $wl --no-cpu-baseline --no-unpadded > $out/pmc_${wl}_$name.log 2>&1
+    step prof $out/pmc_${wl}_$name.log timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc_${wl}_$name -o p -- python3 bench.py --steps 5 --warmup 1 --workload $wl --no-cpu-baseline --no-unpadded
   done
 done
 # keep what collect_merge.py reads: our kernels' counter rows and the stats tables (gpurun returns <= 64 MiB)

@@ -9,10 +9,10 @@ commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "rev-parse
 src, dst = f"gpurun_out/collect_{tag}", f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
 traffic = {}
-for extra in ("synth_mix", "zinc_subset"):
+for extra in ("zinc_subset",):
     if os.path.exists(f"{src}/bench_{extra}.json"):
         shutil.copy(f"{src}/bench_{extra}.json", f"{dst}/bench_{extra}_final.json")
-for wl in ("zinc_full", "synth_er"):
+for wl in ("zinc_full", "synth_er", "synth_mix"):
     shutil.copy(f"{src}/bench_{wl}.json", f"{dst}/bench_{wl}_final.json")
     for f in glob.glob(f"{src}/stats_{wl}/**/*_kernel_stats.csv", recursive=True):
         shutil.copy(f, f"{dst}/bench_{wl}_kernel_stats_final.csv")
@@ -27,6 +27,8 @@ for wl in ("zinc_full", "synth_er"):
     for k, c in kern.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             c["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
+    if not kern:
+        continue
     json.dump({"command": "profiles/tools/collect.sh: rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 bench.py "
                           f"--steps 5 --warmup 1 --workload {wl} --no-cpu-baseline, one pass per counter group",
                "note": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; hbm_bytes_per_launch = (2*FETCH + WRITE) * 1024",
