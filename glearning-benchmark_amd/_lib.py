@@ -109,6 +109,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
 _lib = None
 
 
+ABI_VERSION = 2     # include/gtok.h: GTOK_ABI_VERSION
+
+
 def lib() -> ctypes.CDLL:
     """Load libgtok.so; raise loudly when it has not been built."""
     global _lib
@@ -121,6 +124,9 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
+        if h.gtok_version() != ABI_VERSION:      # struct layouts below would not match the library's
+            raise GtokError(f"{LIB_PATH} has ABI version {h.gtok_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                            "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         _lib = h
     return _lib
 

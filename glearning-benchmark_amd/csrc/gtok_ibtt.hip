@@ -1748,5 +1748,5 @@ extern "C" int gtok_find_token(const int64_t *x, int32_t rows, int32_t ld, int64
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 
-extern "C" int gtok_version(void) { return 1; }
+extern "C" int gtok_version(void) { return GTOK_ABI_VERSION; }
 extern "C" const char *gtok_target(void) { return "gfx950"; }

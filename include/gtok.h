@@ -328,7 +328,9 @@ const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_params *p);
  * only) or "ibtt_zinc_kernel" (wave per graph: any batch).  All emit the same tokens.                          */
 const char *gtok_ibtt_zinc_kernel_name(const gtok_csr *g);
 
-/* Library/ABI version and build target string ("gfx950").                   */
+/* ABI version (GTOK_ABI_VERSION of the header the library was built from: 2 since gtok_csr carries the optional
+ * mirrors - a binding checks it before passing structs) and build target string ("gfx950").                     */
+#define GTOK_ABI_VERSION 2
 int gtok_version(void);
 const char *gtok_target(void);
 

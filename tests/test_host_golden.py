@@ -251,7 +251,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(gtok._lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert gtok.lib().gtok_version() == 1 and gtok.lib().gtok_target() == b"gfx950"
+    assert gtok.lib().gtok_version() == 2 and gtok.lib().gtok_target() == b"gfx950"
 
 
 def test_product_has_no_cpu_path():
