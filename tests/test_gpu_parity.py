@@ -989,3 +989,42 @@ def test_config5_sized_batches_take_the_bit_matrix_lane_kernel():
             assert gtok.ops.sent_kernel_name(b, 256, max_len).startswith("sent_blane_kernel<W=4>")
             ref, rln = orc.sent(coo, 256, max_len, 9, 2, ld=ids.shape[1], nthreads=8)
             _cmp(ids, ln, ref, rln, f"blane default {name} max_len={max_len}")
+
+
+def test_lane_kernel_on_the_reordered_batch(monkeypatch):
+    """ops.lane_sorted: the copy of a batch that sent_lane_kernel walks by default - graphs stored by descending
+    expected walk length, units of <= 64 neighbours cut to the 10 KB LDS budget, graph_ids carrying every slot's
+    dataset index.  Sizes chosen against the packing: 64-node graphs with ~250 entries (about 19 to a unit), single
+    nodes and triangles (64 to a unit), molecule-sized rings in between, a batch smaller than one unit.  Tokens, lengths,
+    query tails and RNG identity (graph_base) must be those of the batch in dataset order = the oracle's."""
+    _pin_sent(monkeypatch, "lane")
+    rng = np.random.default_rng(11)
+    sizes = [64] * 150 + [3] * 700 + [1] * 130 + [37] * 400 + [20] * 300 + [2] * 64
+    rng.shuffle(sizes)
+    big = _rings_with_chords(sizes, 58, seed=21)
+    small = _rings_with_chords([9, 5, 33, 1, 64, 12], 3, seed=22)
+    for name, d in (("mixed", big), ("one unit", small)):
+        q = np.stack([rng.integers(0, np.maximum(d["node_counts"], 1)), rng.integers(0, np.maximum(d["node_counts"], 1))], 1).astype(np.int32)
+        for labeled in (True, False):
+            batch, coo = both(d, labeled)
+            assert batch.flags & 1 and batch.max_edges <= 255
+            b = batch.to(DEV)
+            kw = dict(labeled=labeled, num_node_types=30 if labeled else 0, num_edge_types=7 if labeled else 0)
+            for max_len, query in ((4096, None), (90, None), (4096, q)):
+                ids, ln = gtok.ops.sent(b, 64, max_len, 5, 3, graph_base=1000, query=None if query is None else torch.from_numpy(query), **kw)
+                ref, rln = orc.sent(coo, 64, max_len, 5, 3, graph_base=1000, query=query, ld=ids.shape[1], nthreads=8, **kw)
+                _cmp(ids, ln, ref, rln, f"reordered {name} labeled={labeled} max_len={max_len} query={query is not None}")
+            assert gtok.ops.sent_kernel_name(b, 64, 4096, **kw) == "sent_lane_kernel"
+            sb = b.lane_sorted
+            assert sb is not None and sb.graph_ids is not None and sb.rowptr8 is not None
+            up = sb.unit_ptr.cpu().numpy(); gi = sb.graph_ids.cpu().numpy()
+            assert up[0] == 0 and up[-1] == b.num_graphs and sb.num_units == up.size - 1
+            assert np.array_equal(np.sort(gi), np.arange(b.num_graphs)) and (np.diff(up) >= 1).all() and (np.diff(up) <= 64).all()
+            nc = (b.node_ptr[1:] - b.node_ptr[:-1]).cpu().numpy()[gi]; ec = (b.edge_ptr[1:] - b.edge_ptr[:-1]).cpu().numpy()[gi]
+            cn, ce = np.concatenate([[0], np.cumsum(nc)]), np.concatenate([[0], np.cumsum(ec)])
+            un, ue = cn[up[1:]] - cn[up[:-1]], ce[up[1:]] - ce[up[:-1]]
+            a16 = lambda v: (v + 15) // 16 * 16
+            assert sb.chunk_nodes == un.max() and sb.chunk_edges == ue.max()
+            assert a16(un.max() + 80) + 2 * a16(ue.max() + 8) + a16(un.max() + 8) <= gtok.ops.LANE_UNIT_LDS
+            if name == "mixed":
+                assert sb.num_units > (b.num_graphs + 63) // 64          # the 64-node graphs do not fit 64 to a unit
