@@ -207,6 +207,11 @@ def main():
                            slab_width=ld, slab_width_mode=args.ld, avg_tokens_per_graph=round(tokens_per_step_rank / G, 2),
                            parallelism=f"graph-sharded x{world}, no data-path collective"),
                roofline=roofline)
+    # layout steps done once per resident batch by ops.sent (outside the timed region, like the CSR build): say which were used
+    layouts = [n for n, on in (("byte mirror of rowptr/col", batch.rowptr8 is not None or (batch.lane_sorted is not None and batch.lane_sorted.rowptr8 is not None)),
+                               ("copy reordered by expected walk length (graph_ids + unit table)", batch.lane_sorted is not None),
+                               ("adjacency bit-matrix mirror + lane order", batch.adj_rows is not None)) if on]
+    out["config"]["resident_layouts"] = layouts
     if nopad_ms is not None:
         out["unpadded_rows"] = dict(ms_per_step=round(nopad_ms, 4), graphs_per_sec=round(G / nopad_ms * 1e3, 1),
                                     note="GTOK_SENT_NO_PAD: tokens only, pad tails of the slab not written")

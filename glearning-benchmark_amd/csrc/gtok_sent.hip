@@ -150,6 +150,19 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.unit_mul = 0;
     a.prio_cut[0] = 16; a.prio_cut[1] = 32; a.prio_cut[2] = 48;   // quartiles (profiles/tools/lane_prio_sweep.sh)
     if (const char *pc = std::getenv("GTOK_LANE_PRIO_CUTS")) std::sscanf(pc, "%d,%d,%d", &a.prio_cut[0], &a.prio_cut[1], &a.prio_cut[2]);   // tuning knob
+    // a reordered batch: one 16-wave workgroup per CU (the kernel pairs long units with short ones on every SIMD) when a
+    // wave's share of the CU's 160 KB is enough and the batch fills the chip; else one-wave workgroups with the units spread
+    const char *wg = std::getenv("GTOK_LANE_PER_CU");   // tuning knob: 0 = never
+    if (g->unit_ptr && a.lds * 16 <= 160 * 1024 && a.units >= 4 * ncu && !(wg && wg[0] == '0')) {
+      // (the opt-in to more than 64 KB of dynamic LDS is per kernel and per device: a host-side call of a microsecond)
+      const bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      int occ16 = 0;
+      if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 1024, (size_t)a.lds * 16) == hipSuccess && occ16 >= 1) {
+        hipLaunchKernelGGL(kern, dim3(ncu), dim3(1024), (size_t)a.lds * 16, (hipStream_t)stream, a);
+        return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+      }
+      (void)hipGetLastError();
+    }
     if (g->unit_ptr && a.units > 16) {
       auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
       int m = (int)(a.units * 0.6180339887498949);

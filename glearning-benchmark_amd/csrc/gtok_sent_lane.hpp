@@ -99,9 +99,12 @@ struct SentLaneArgs {
 // PK: the batch carries the byte-packed rowptr / col mirror (gtok_csr.rowptr8 / col8): a unit is staged with 12
 // 16-byte loads per lane, all in flight at once, and no packing instructions
 template <bool LAB, int P, bool REMAP, bool PK>
-__global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = lane_id();
+__global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
+  // one-wave workgroups (batch in dataset order), or ONE 16-wave workgroup per CU (reordered batch: see the unit loop);
+  // waves never cooperate either way, each owns a.lds bytes of the workgroup's LDS
+  extern __shared__ __align__(16) unsigned char smem_all[];
+  const int lane = lane_id(), wave = wave_id();
+  unsigned char *smem = smem_all + (size_t)wave * a.lds;
   uint8_t *srp = smem + a.off_rp, *scol = smem + a.off_col, *seat = smem + a.off_eat, *snat = smem + a.off_nat;
 
   const int lim = a.p.max_len, ld = a.ld, cap = min(lim, ld);
@@ -243,12 +246,24 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
     }
   };
 #endif
-  // A reordered batch stores its units by descending walk length: dealt as they come, one XCD (virtual_block) or one CU
-  // would get all the long ones.  unit = idx * unit_mul mod units (unit_mul ~ units / golden ratio, coprime): every run of
-  // consecutive workgroups and every arithmetic progression of them - whichever way the dispatcher fills XCDs, CUs and
-  // SIMDs - samples the whole range of lengths.
-  for (int idx = a.unit_mul ? (int)blockIdx.x : virtual_block(); idx < a.units; idx += stride) {
-    const int unit = a.unit_mul ? (int)(((uint64_t)(uint32_t)idx * (uint32_t)a.unit_mul) % (uint32_t)a.units) : idx;
+  // A reordered batch stores its units by descending walk length, and a wave is as fast as the company it keeps on its
+  // SIMD lets it be (alone ~2.5 k cycles per step, with three others ~5.2 k): every SIMD should hold one unit of each
+  // quarter of that order.  HIP gives no say in which one-wave workgroups share a SIMD, but inside ONE workgroup the waves
+  // w, w + 4, w + 8, w + 12 share one (observed on gfx950: profiles/tools/probes/wave_simd_probe.hip; speed only) - so the
+  // launch is 256 workgroups of 16 waves, one per CU with all of its LDS, and wave w of workgroup b takes, per round of
+  // 4,096 units, rank (w >> 2) * 1024 + j of the stored order, j = (w & 3) * 256 + b, odd quarters backwards (long with
+  // short).  The quarter is also the wave's issue priority: the stragglers-to-be get the slots their SIMD-mates can spare.
+  const bool percu = blockDim.x > 64;
+  const int nslots = (int)gridDim.x * 16, quarter = wave >> 2, qsize = (int)gridDim.x * 4;
+  const int jq = (wave & 3) * (int)gridDim.x + (int)blockIdx.x;
+  for (int idx = percu ? 0 : (a.unit_mul ? (int)blockIdx.x : virtual_block()); idx < a.units; idx += percu ? nslots : stride) {
+    int unit = idx;
+    if (percu) {
+      unit = idx + quarter * qsize + ((quarter & 1) ? qsize - 1 - jq : jq);
+      if (unit >= a.units) continue;
+    } else if (a.unit_mul) {
+      unit = (int)(((uint64_t)(uint32_t)idx * (uint32_t)a.unit_mul) % (uint32_t)a.units);
+    }
     // ---- stage this unit; the loads of phase A go out ahead of the previous unit's padding stores
 #ifdef GTOK_PHASE_TIMING
     const uint64_t ts0_new = __builtin_amdgcn_s_memtime();
@@ -292,7 +307,12 @@ __global__ void __launch_bounds__(64, 4) sent_lane_kernel(const SentLaneArgs a) 
     // A unit runs as long as its longest walk, and a launch as long as its slowest unit: the likely stragglers get a
     // higher issue priority than the waves they share a SIMD with, which have slack.  A reordered batch stores its units
     // by descending walk length (the first eighth are the stragglers); otherwise the unit's largest graph predicts it.
-    if (a.g.unit_ptr) {
+    if (percu) {
+      if (quarter == 0) __builtin_amdgcn_s_setprio(3);
+      else if (quarter == 1) __builtin_amdgcn_s_setprio(2);
+      else if (quarter == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    } else if (a.g.unit_ptr) {
       const int rank = (int)(((int64_t)unit << 6) / a.units);   // 0..63
       if (rank < a.prio_cut[0]) __builtin_amdgcn_s_setprio(3);
       else if (rank < a.prio_cut[1]) __builtin_amdgcn_s_setprio(2);
