@@ -93,19 +93,23 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     SentBLaneArgs a;
     a.g = *g; a.p = *p; a.out = out_ids; a.ld = ld; a.out_len = out_len;
     a.units = (g->num_graphs + 63) / 64;
+    a.prio = 1;
+    if (const char *cs = std::getenv("GTOK_BLANE_PRIO")) a.prio = cs[0] != '0';   // tuning knob
     const bool p4 = g->adj_max_degree <= 15;
     typedef void (*K)(const SentBLaneArgs);
     K kern = W == 1 ? (p4 ? (K)sent_blane_kernel<1, 4> : (K)sent_blane_kernel<1, 8>)
            : W == 2 ? (p4 ? (K)sent_blane_kernel<2, 4> : (K)sent_blane_kernel<2, 8>)
                     : (p4 ? (K)sent_blane_kernel<4, 4> : (K)sent_blane_kernel<4, 8>);
     const size_t lds = (size_t)4608 * W;   // 18 W dwords per lane (gtok_sent_blane.hpp)
-    int dev = 0, ncu = 256, occ = 1;
+    int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64, lds) != hipSuccess || occ < 1) occ = 1;
-    int nb = ncu * occ;
-    if (nb > a.units) nb = a.units;
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(64), lds, (hipStream_t)stream, a);
+    // one workgroup per CU: 8 waves at W = 4 (144 KB of LDS, 2 per SIMD: the register file holds no more), else 16
+    int nw = W == 4 ? 8 : 16;
+    if (const char *cs = std::getenv("GTOK_BLANE_WAVES")) { const int c = std::atoi(cs); if (c == 4 || c == 8 || c == 16) nw = c < nw ? c : nw; }   // tuning knob
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int nb = a.units < ncu ? a.units : ncu;   // every CU, also when some of its waves stay without a unit
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * nw), lds * nw, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
   }
   if (lane_path) {

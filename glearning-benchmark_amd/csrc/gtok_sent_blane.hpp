@@ -29,16 +29,20 @@ struct SentBLaneArgs {
   int ld;
   int32_t *out_len;
   int units;   // ceil(G / 64)
+  int prio;    // long units at a higher issue priority than the short ones they share a SIMD with
 };
 
 struct __attribute__((aligned(16))) U64x2 { uint64_t a, b; };
 
 template <int W, int P>
-__global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(const SentBLaneArgs a) {
+__global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const SentBLaneArgs a) {
   // LDS, all of it lane-private and laid out [dword][lane] (bank = lane): 16 W dwords node -> visit index (u8 each),
   // 2 W dwords bracket members in visit-index space (zero between brackets)
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = lane_id();
+  // one workgroup per CU (8 waves at W = 4, else 16), each wave with its own 18 W x 256 bytes of the workgroup's LDS;
+  // waves never cooperate
+  extern __shared__ __align__(16) unsigned char smem_all[];
+  const int lane = lane_id(), wave = wave_id();
+  unsigned char *smem = smem_all + (size_t)wave * (18 * W * 256);
   uint8_t *vx = smem + lane * 4;
   auto vx_at = [&](int u) __attribute__((always_inline)) -> uint8_t & { return vx[((u & ~3) << 6) + (u & 3)]; };
   uint32_t *lw = reinterpret_cast<uint32_t *>(smem) + lane;
@@ -54,7 +58,23 @@ __global__ void __launch_bounds__(64, (W * P > 16) ? 2 : 3) sent_blane_kernel(co
   const int G = a.g.num_graphs, pad = a.p.pad_id;
   const bool no_pad = (a.p.flags & GTOK_SENT_NO_PAD) != 0;
 
-  for (int unit = (int)blockIdx.x; unit < a.units; unit += (int)gridDim.x) {
+  // Units are stored by descending expected length (lane_order), and the waves w, w + 4, w + 8, ... of a workgroup share a
+  // SIMD (observed on gfx950, profiles/tools/probes/wave_simd_probe.hip; speed only): per round of gridDim x waves units,
+  // wave w takes rank (w >> 2) * qsize + j of that order, j = (w & 3) * gridDim + block, odd groups backwards - every SIMD
+  // holds long units together with short ones, the long ones at the higher issue priority.
+  const int nwaves = (int)(blockDim.x >> 6), grp = wave >> 2, qsize = (int)gridDim.x * 4, jq = (wave & 3) * (int)gridDim.x + (int)blockIdx.x;
+  __builtin_amdgcn_s_setprio(0);
+  if (!a.prio) {
+  } else if (nwaves > 8) {
+    if (grp == 0) __builtin_amdgcn_s_setprio(3);
+    else if (grp == 1) __builtin_amdgcn_s_setprio(2);
+    else if (grp == 2) __builtin_amdgcn_s_setprio(1);
+  } else if (nwaves > 4 && grp == 0) {
+    __builtin_amdgcn_s_setprio(1);
+  }
+  for (int idx = 0; idx < a.units; idx += (int)gridDim.x * nwaves) {
+    const int unit = idx + grp * qsize + ((grp & 1) ? qsize - 1 - jq : jq);
+    if (unit >= a.units) continue;
     const int slot = unit * 64 + lane;
     const bool valid = slot < G;
     const int g = valid ? (a.g.lane_order ? a.g.lane_order[slot] : slot) : 0;

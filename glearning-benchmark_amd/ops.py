@@ -196,19 +196,42 @@ def lane_sorted(batch: GraphBatch) -> Optional[GraphBatch]:
     return out
 
 
+_POPCOUNT8 = None
+
+
 def _lane_order(batch: GraphBatch, typical_len: int) -> torch.Tensor:
     """The order sent_blane_kernel's lanes take the graphs in (64 consecutive entries share a wave, and a wave lasts as
     long as its slowest walk and, at every step, as its largest bracket).  A heuristic that only moves time, never tokens:
-    graphs are grouped by the number of trail steps they are expected to take (n for a walk that ends by itself; fewer when
-    the row is cut at `typical_len` tokens: a step of a graph of density p writes about 3 + p t tokens at step t), and by
-    density within a group, so that the brackets of a wave's walks grow at the same pace."""
+    graphs are grouped by the number of trail steps they are expected to take and, within a group, by density, so that
+    the brackets of a wave's walks grow at the same pace.  The model: a walk takes n + r steps (r restarts ~ leaves - 1:
+    the walk comes back once per dead end) and writes n position tokens, 2 per restart, the e - n + 1 bracket members and
+    2 per non-empty bracket; members pile up with the square of the steps taken, the rest linearly - a t + q t^2 tokens
+    after t steps - and a row cut at `typical_len` tokens stops where that reaches it (a 256-node star: 1.5 tokens per
+    step, 400 steps of its 510; a dense random graph: 3 t + p t^2 / 2)."""
+    global _POPCOUNT8
+    dev = batch.device
     n = (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.float64)
     e = (batch.edge_ptr[1:] - batch.edge_ptr[:-1]).to(torch.float64)
     if batch.flags & _lib.CSR_SIMPLE_SYMMETRIC:
         e = e / 2
-    p = (2 * e / (n * n).clamp(min=1)).clamp(min=1e-6, max=1.0)
-    cut = (torch.sqrt(9 + 2 * p * float(typical_len)) - 3) / p            # 3 t + p t^2 / 2 = typical_len
-    steps = torch.where(e + 2 * n > typical_len, torch.minimum(cut, n), n).round().clamp(0, 1023).to(torch.int64)
+    # leaves = nodes of closure degree 1: bit 0 of the degree set, every higher bit clear (the mirror's degree planes)
+    pl = batch.adj_planes
+    higher = pl[:, 1]
+    for k in range(2, 8):
+        higher = higher | pl[:, k]
+    deg1 = (pl[:, 0] & ~higher).contiguous().view(torch.uint8)
+    if _POPCOUNT8 is None or _POPCOUNT8.device != dev:
+        _POPCOUNT8 = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=dev)
+    leaves = _POPCOUNT8[deg1.long()].reshape(batch.num_graphs, -1).sum(1).to(torch.float64)
+    r = (leaves - 1).clamp(min=0)
+    members = (e - n + 1).clamp(min=0)
+    steps_full = (n + r).clamp(min=1)
+    a = (n + 2 * r + 2 * torch.minimum(n, members)) / steps_full
+    q = members / (steps_full * steps_full)
+    L = float(typical_len)
+    cut = torch.where(q > 1e-9, (torch.sqrt(a * a + 4 * q * L) - a) / (2 * q).clamp(min=1e-9), L / a.clamp(min=1e-9))
+    steps = torch.minimum(cut, steps_full).round().clamp(0, 1023).to(torch.int64)
+    p = (2 * e / (n * n).clamp(min=1)).clamp(min=0.0, max=1.0)
     key = steps * 1024 + (p * 1023).round().to(torch.int64)
     return torch.argsort(key, descending=True, stable=True).to(torch.int32)
 
