@@ -888,6 +888,7 @@ struct TextArgs {
   int32_t *out; int ld; int32_t *out_len;
   int units, upb;
   int off_vocab, off_wave, ring_off, tok_off, wave_stride;   // LDS: [vocab slots (VLDS)] then per wave: text ring, tokens
+  int off_short;   // VLDS: second table, the keys of up to 7 bytes as {key lo, key hi, id, used} (one 16-byte read per probe)
 };
 
 // The text of one graph is read ONCE, 16 bytes per lane and load, into a 2 KB LDS ring (the chunk being split and
@@ -897,6 +898,12 @@ struct TextArgs {
 // The previous version read the text a byte per lane and hashed / probed straight from global memory: ~10
 // dependent round trips per 64 bytes of text.
 constexpr int kTextChunk = 1024, kTextRing = 2 * kTextChunk, kSlotBytes = 24, kSlotKey = 19;
+
+struct __attribute__((aligned(16))) U32x4a { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint32_t short_key_hash(uint32_t klo, uint32_t khi) {
+  const uint32_t h = (klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu);
+  return h ^ (h >> 15);
+}
 
 template <bool VLDS>
 __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
@@ -914,7 +921,7 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
   if (VLDS) {   // slot s: id (4 B), length (1 B; 255 = empty), key bytes (one unaligned 16-byte load + 3 bytes)
     // bytes readable at key_bytes = the end of the last key (the ABI carries no length): found first, so that the
     // vector loads below never leave the array
-    int *kb_end = reinterpret_cast<int *>(smem + a.off_wave - 16);
+    int *kb_end = reinterpret_cast<int *>(smem + a.off_short - 16);
     if (threadIdx.x == 0) *kb_end = 0;
     __syncthreads();
     int my_end = 0;
@@ -942,7 +949,24 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
       d[4] = (unsigned char)len;
       for (int j = 0; j < kSlotKey; ++j) d[5 + j] = (unsigned char)((j < len) ? (w[j >> 2] >> (8 * (j & 3))) & 255u : 0u);
     }
-    __syncthreads();   // the only workgroup barrier: before any wave can leave
+    __syncthreads();
+    // the short-key table: most tokens of a graph-token or molecule text are a few bytes long (node ids, <e>, <bond>, yes / no)
+    // and are matched as one 64-bit value instead of a hash loop and a compare loop over their bytes
+    uint32_t *st = reinterpret_cast<uint32_t *>(smem + a.off_short);
+    for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) st[sl * 4 + 3] = 0u;
+    __syncthreads();
+    for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
+      const unsigned char *d = vs + (size_t)sl * kSlotBytes;
+      const int len = d[4];
+      if (len >= 1 && len <= 7) {
+        uint32_t klo = 0, khi = 0;
+        for (int j = 0; j < len; ++j) { if (j < 4) klo |= (uint32_t)d[5 + j] << (8 * j); else khi |= (uint32_t)d[5 + j] << (8 * (j - 4)); }
+        uint32_t idx = short_key_hash(klo, khi) & mask;
+        while (atomicCAS(&st[idx * 4 + 3], 0u, 1u) != 0u) idx = (idx + 1) & mask;
+        st[idx * 4 + 0] = klo; st[idx * 4 + 1] = khi; st[idx * 4 + 2] = (uint32_t)*reinterpret_cast<const int32_t *>(d);
+      }
+    }
+    __syncthreads();   // the last workgroup barrier: before any wave can leave
   }
   auto load16 = [&](int64_t abs) -> U8x16 {   // never touches bytes past the end of the blob
     if (abs + 16 <= total) return *reinterpret_cast<const U8x16 *>(a.bytes + abs);
@@ -992,6 +1016,35 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
         bool is_p = false;
         const int t = count + __popcll(sm & lanemask_lt());
         if (start && t < a.max_len) {
+          bool fast = false;
+          if (VLDS && i + 8 <= n) {
+            // tokens of up to 7 bytes: the 8 bytes at i (all in the ring and inside the text) as one 64-bit value, cut at
+            // their first whitespace - found with the zero-byte trick on "byte < 33" (ASCII: exact for the lowest flag) -
+            // and looked up in the short-key table.  Anything else (longer, a control character that is not whitespace,
+            // the last bytes of the text) takes the byte loops below.
+            const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(ring);
+            const uint32_t o = (uint32_t)i & (kTextRing - 1), sh = o & 3u;
+            const uint32_t w0 = ring32[o >> 2], w1 = ring32[((o >> 2) + 1) & (kTextRing / 4 - 1)], w2 = ring32[((o >> 2) + 2) & (kTextRing / 4 - 1)];
+            uint32_t klo = __builtin_amdgcn_alignbyte(w1, w0, sh), khi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            const uint32_t flo = (klo - 0x21212121u) & ~klo & 0x80808080u, fhi = (khi - 0x21212121u) & ~khi & 0x80808080u;
+            if (flo | fhi) {
+              const int len = flo ? (__builtin_ctz(flo) >> 3) : 4 + (__builtin_ctz(fhi) >> 3);
+              const uint32_t delim = (flo ? klo >> (8 * len) : khi >> (8 * (len - 4))) & 255u;
+              if (len >= 1 && py_isspace(delim)) {
+                klo = len >= 4 ? klo : klo & ((1u << (8 * len)) - 1u);
+                khi = len <= 4 ? 0u : khi & ((1u << (8 * (len - 4))) - 1u);
+                const U32x4a *stab = reinterpret_cast<const U32x4a *>(smem + a.off_short);
+                for (uint32_t slot = short_key_hash(klo, khi) & mask;; slot = (slot + 1) & mask) {
+                  const U32x4a e = stab[slot];
+                  if (e.w == 0u) break;                                   // not in the vocab: id stays pad_id, as below
+                  if (e.x == klo && e.y == khi) { id = (int)e.z; break; }
+                }
+                is_p = len == 3 && klo == 0x003E703Cu;                    // "<p>"
+                fast = true;
+              }
+            }
+          }
+          if (!fast) {
           // hash the token (FNV-1a), then probe the open-addressing table
           uint32_t h = 2166136261u;
           int len = 0;
@@ -1024,6 +1077,7 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
               for (int j = 0; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == byte_at(i + j);
               if (eq) { id = a.v.id[slot]; break; }
             }
+          }
           }
           if (t < cap) tok[t] = id;
         }
@@ -1655,14 +1709,15 @@ extern "C" int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr, i
   a.cap = max_len < ld ? max_len : ld;
   const bool vlds = vocab->capacity <= 1024;   // 24 KB of slots per workgroup
   a.off_vocab = 0;
-  a.off_wave = vlds ? align_up(vocab->capacity * kSlotBytes, 16) + 16 : 0;   // + one scratch word for the staging pass
+  a.off_short = vlds ? align_up(vocab->capacity * kSlotBytes, 16) + 16 : 0;   // + one scratch word for the staging pass
+  a.off_wave = vlds ? a.off_short + vocab->capacity * 16 : 0;
   a.ring_off = 0;
   a.tok_off = kTextRing;
   const int64_t wave_bytes = kTextRing + (int64_t)align_up((a.cap > 0 ? a.cap : 1) * 4, 16);
   if (wave_bytes + a.off_wave > 160 * 1024) return GTOK_E_TOO_LARGE;
   a.wave_stride = (int)wave_bytes;
   int wpb = vlds ? 8 : 4;   // the LDS vocab is per workgroup: more waves share one copy
-  while (wpb > 1 && a.off_wave + wpb * a.wave_stride > 64 * 1024) wpb >>= 1;
+  while (wpb > 1 && a.off_wave + wpb * a.wave_stride > 80 * 1024) wpb >>= 1;   // two workgroups per CU
   const size_t lds = (size_t)a.off_wave + (size_t)wpb * a.wave_stride;
   typedef void (*K)(const TextArgs);
   K kern = vlds ? (K)text_ids_kernel<true> : (K)text_ids_kernel<false>;
