@@ -1028,3 +1028,38 @@ def test_lane_kernel_on_the_reordered_batch(monkeypatch):
             assert a16(un.max() + 80) + 2 * a16(ue.max() + 8) + a16(un.max() + 8) <= gtok.ops.LANE_UNIT_LDS
             if name == "mixed":
                 assert sb.num_units > (b.num_graphs + 63) // 64          # the 64-node graphs do not fit 64 to a unit
+
+
+def test_hip_graph_capture_of_the_one_workgroup_per_cu_launches():
+    """The lane-per-graph kernels launch one workgroup per CU with more than 64 KB of dynamic LDS (an attribute the
+    launcher sets on every call: it must be legal while a stream is capturing).  70 k molecules (reordered batch, 16-wave
+    workgroups) and 6 k unlabelled graphs of up to 256 nodes (bit-matrix kernel, 8-wave workgroups): captured once,
+    replayed, equal to the oracle every time."""
+    d = gtok.synth.zinc_like(70000, seed=83)
+    batch, coo = both(d)
+    b = batch.to(DEV)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ld = gtok.ops.sent_safe_ld(batch, True, 1024)
+    e = gtok.synth.er_batch_device(6000, DEV, seed=84)
+    eb, ecoo = both(e, False)
+    ebd = eb.to(DEV)
+    eld = 608
+    s_out = (torch.empty((70000, ld), dtype=torch.int32, device=DEV), torch.empty(70000, dtype=torch.int32, device=DEV))
+    e_out = (torch.empty((6000, eld), dtype=torch.int32, device=DEV), torch.empty(6000, dtype=torch.int32, device=DEV))
+    gtok.ops.sent(b, 37, 1024, 9, 4, ld=ld, out=s_out, **kw)               # warm-up: the resident layouts are made here
+    gtok.ops.sent(ebd, 256, 600, 9, 4, ld=eld, out=e_out)
+    assert gtok.ops.sent_kernel_name(b, 37, 1024, **kw) == "sent_lane_kernel" and b.lane_sorted is not None and b.lane_sorted.num_units >= 1024
+    assert gtok.ops.sent_kernel_name(ebd, 256, 600).startswith("sent_blane_kernel")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gtok.ops.sent(b, 37, 1024, 9, 4, ld=ld, out=s_out, **kw)
+        gtok.ops.sent(ebd, 256, 600, 9, 4, ld=eld, out=e_out)
+    ref, rln = orc.sent(coo, 37, 1024, 9, 4, ld=ld, nthreads=8, **kw)
+    eref, erln = orc.sent(ecoo, 256, 600, 9, 4, ld=eld, nthreads=8)
+    for rep in range(2):
+        s_out[0].fill_(-1); e_out[0].fill_(-1)
+        graph.replay()
+        torch.cuda.synchronize()
+        _cmp(s_out[0], s_out[1], ref, rln, f"graph replay {rep}: sent_lane_kernel, one workgroup per CU")
+        _cmp(e_out[0], e_out[1], eref, erln, f"graph replay {rep}: sent_blane_kernel")
