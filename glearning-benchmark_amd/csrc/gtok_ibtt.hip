@@ -1183,7 +1183,7 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
     const int g = unit * wpb + wave;
     if (g >= a.num_texts) break;
     const uint8_t *__restrict__ s = a.bytes + a.text_ptr[g];
-    const int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
+    int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
     const int64_t ebase = fill ? a.edge_ptr[g] : 0;
     const int64_t ecap = fill ? a.edge_ptr[g + 1] - ebase : 0;
     auto lit = [&](int64_t i, int len, const char *w, int wl) -> bool {   // token == literal (upper-cased text)
@@ -1201,7 +1201,103 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
     bool prev_sp = true;
     // the token that runs into this piece: decimal value so far, length, "digits only so far"
     uint32_t carry_val = 0; int carry_len = 0; bool carry_dig = true;
-    const int64_t t0 = a.text_ptr[g];
+    // ---- the edge zone, streamed.  `INT INT <e>` triples are nearly all of a text, and as long as a 1 KB window holds
+    // nothing but them (and <bos> as token 0) it needs no structure tracking at all: every lane takes 16 bytes - and the 16
+    // before them: a plain token is at most 9 bytes long, so one that ends in the lane's bytes began inside that view - walks
+    // them once (value, length, all-digits, unrolled: every byte sits in a register at a fixed place), notes the tokens that
+    // END in its bytes (at most 8: slot = position / 2), a wave prefix sum numbers them, the triple rule is checked, and only
+    // if the whole window passes are its endpoints stored.  The first window that holds anything else (<n>, a word, a tab, a
+    // long number, a token out of place) and everything after it go through the general loop below, which starts right
+    // behind the last token the stream took, with the token count where the stream left it: same results, byte for byte.
+    int64_t handover = 0;
+    for (int64_t wb = 0; wb < n; wb += 1024) {
+      const int64_t o = wb + 16 * lane;
+      uint32_t w[8];                                              // bytes o - 16 .. o + 15; outside the text: spaces
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int64_t rel = o - 16 + 16 * half;
+        if (rel >= 0 && rel + 16 <= n) {
+          const U8x16 x = *reinterpret_cast<const U8x16 *>(s + rel);
+          w[4 * half] = x.a; w[4 * half + 1] = x.b; w[4 * half + 2] = x.c; w[4 * half + 3] = x.d;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int64_t i = rel + 4 * k + j; v |= ((i >= 0 && i < n) ? (uint32_t)s[i] : 32u) << (8 * j); }
+            w[4 * half + k] = v;
+          }
+        }
+      }
+      const uint32_t after = (o + 16 < n) ? (uint32_t)s[o + 16] : 32u;
+      auto at = [&](int p) __attribute__((always_inline)) -> uint32_t { return (w[(p + 16) >> 2] >> (8 * ((p + 16) & 3))) & 255u; };   // byte o + p
+      uint32_t val = 0, vals[8] = {0, 0, 0, 0, 0, 0, 0, 0}, endm = 0, kinds = 0;
+      int len = 0, lastp = -1;
+      bool dig = true;
+#pragma unroll
+      for (int p = -16; p < 16; ++p) {
+        const uint32_t c = at(p);
+        const bool sp = c == 32u;
+        const uint32_t dd = c - '0';
+        val = sp ? 0u : val * 10u + dd;
+        len = sp ? 0 : len + 1;
+        dig = sp ? true : (dig && dd < 10u);
+        if (p >= 0) {
+          const uint32_t nx = p < 15 ? at(p + 1) : after;
+          const bool is_end = !sp && nx == 32u;
+          const bool is_e = len == 3 && c == '>' && at(p - 1) == 'e' && at(p - 2) == '<';
+          const bool is_bos = len == 5 && c == '>' && at(p - 1) == 's' && at(p - 2) == 'o' && at(p - 3) == 'b' && at(p - 4) == '<';
+          const uint32_t kind = is_e ? 1u : ((dig && len <= 9) ? 0u : (is_bos ? 2u : 3u));
+          const int slot = p >> 1;
+          vals[slot] = is_end ? val : vals[slot];
+          endm |= is_end ? 1u << slot : 0u;
+          kinds |= is_end ? kind << (2 * slot) : 0u;
+          lastp = is_end ? p : lastp;
+        }
+      }
+      const int nt = __popc(endm);
+      int incl = nt;
+#pragma unroll
+      for (int dsh = 1; dsh < kWave; dsh <<= 1) { const int up = __shfl_up(incl, dsh); if (lane >= dsh) incl += up; }
+      const int first_idx = count + incl - nt;
+      bool wrong = false;
+      {
+        int t = first_idx;
+#pragma unroll
+        for (int slot = 0; slot < 8; ++slot)
+          if ((endm >> slot) & 1u) {
+            const uint32_t kind = (kinds >> (2 * slot)) & 3u;
+            const uint32_t r = (uint32_t)(t - 1) - 3u * (__umulhi((uint32_t)(t - 1), 0xAAAAAAABu) >> 1);
+            wrong = wrong || (t == 0 ? kind != 2u : kind != (r == 2u ? 1u : 0u));
+            ++t;
+          }
+      }
+      if (__ballot(wrong) != 0) break;
+      {
+        int t = first_idx;
+#pragma unroll
+        for (int slot = 0; slot < 8; ++slot)
+          if ((endm >> slot) & 1u) {
+            if (t > 0) {
+              const uint32_t k = __umulhi((uint32_t)(t - 1), 0xAAAAAAABu) >> 1, r = (uint32_t)(t - 1) - 3u * k;
+              if (r != 2u) {
+                max_end = max(max_end, (int)vals[slot]);
+                if (fill && (int64_t)k < ecap) { if (r == 0u) a.src[ebase + k] = (int)vals[slot]; else a.dst[ebase + k] = (int)vals[slot]; }
+              }
+            }
+            ++t;
+          }
+      }
+      count += __builtin_amdgcn_readlane(incl, 63);
+      const uint64_t holders = __ballot(endm != 0u);
+      if (holders) {
+        const int l = 63 - __builtin_clzll(holders);
+        handover = wb + 16 * l + __builtin_amdgcn_readlane(lastp, l) + 1;
+      }
+    }
+    s += handover;                                                  // the general loop sees the rest as a text of its own
+    n -= handover;
+    const int64_t t0 = a.text_ptr[g] + handover;
     wave_sync();                                                  // the previous text's last reads of the ring are done
     {
       const U8x16 x0 = load16(t0 + lane * 16), x1 = load16(t0 + kTextChunk + lane * 16);

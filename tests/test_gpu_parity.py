@@ -1063,3 +1063,51 @@ def test_hip_graph_capture_of_the_one_workgroup_per_cu_launches():
         torch.cuda.synchronize()
         _cmp(s_out[0], s_out[1], ref, rln, f"graph replay {rep}: sent_lane_kernel, one workgroup per CU")
         _cmp(e_out[0], e_out[1], eref, erln, f"graph replay {rep}: sent_blane_kernel")
+
+
+def test_graph_token_text_parser_streamed_edge_zone_against_the_host_parser():
+    """parse_graph_text_kernel streams the edge zone 1 KB at a time (16 bytes per lane) and hands the first window that
+    holds anything but `INT INT <e>` triples - and everything behind it - to its general loop.  Texts of up to ~20 KB
+    (a dozen windows), then the same texts damaged at random places: runs of spaces, tabs and newlines (whitespace the
+    stream does not take), junk tokens, long numbers, tags out of place, cuts in the middle of a token or of a triple,
+    leading whitespace.  Whatever the device accepts (status 0) must be what the host parser (the reference's scan) says,
+    and the mirror's device + host-fallback result must equal the host parser on every text."""
+    import importlib
+    gm = importlib.import_module("glearning-benchmark_amd.graph_data_loader.graph_token_dataset_autograph")
+    rng = np.random.default_rng(77)
+    base = []
+    for task in ("cycle_check", "shortest_path"):
+        base += gtok.synth.graph_token_like(60, seed=91, task=task, min_nodes=40, max_nodes=230)["texts"]
+    assert max(len(t) for t in base) > 12000
+    texts = list(base)
+    junk = ["x", "12345678901", "1234567890", "007", "<e>", "<n>", "<q>", "+1", "-2", "3.5", "<bos>", "<E>", "9" * 9, "\x01", "<e", "e>"]
+    for t in base:
+        for _ in range(3):
+            u = t
+            for _ in range(int(rng.integers(1, 4))):
+                k = int(rng.integers(0, len(u)))
+                op = int(rng.integers(0, 6))
+                if op == 0:                                          # stretch a separator
+                    sp = u.find(" ", k)
+                    if sp >= 0:
+                        u = u[:sp] + [" " * int(rng.integers(2, 40)), "\t", "\n", " \r\n ", "\x0b"][int(rng.integers(0, 5))] + u[sp + 1:]
+                elif op == 1:                                        # a token that does not belong
+                    sp = u.find(" ", k)
+                    if sp >= 0:
+                        u = u[:sp] + " " + junk[int(rng.integers(0, len(junk)))] + u[sp:]
+                elif op == 2:                                        # cut
+                    u = u[:k]
+                elif op == 3:                                        # drop a byte (glues or shortens tokens)
+                    u = u[:k] + u[k + 1:]
+                elif op == 4:
+                    u = " " * int(rng.integers(1, 70)) + u
+                else:                                                # overwrite a byte
+                    u = u[:k] + "0a< >e\t9"[int(rng.integers(0, 8))] + u[k + 1:]
+            texts.append(u)
+    got = gm.parse_texts_on_device(texts, DEV)
+    tb, tp = gtok.ops.pack_texts(texts)
+    st = gtok.ops.parse_graph_texts(tb.to(DEV), tp)["status"].cpu().numpy()
+    assert not st[:len(base)].any() and st[len(base):].any() and not st[len(base):].all()
+    for g, text in enumerate(texts):
+        edges, n, label = gm.parse_graph_from_json({"text": text})
+        assert got[g] == (edges, n, label, gm.parse_query_nodes_from_text(text)), (g, int(st[g]), text[:80])
