@@ -125,7 +125,10 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
 
     // ---- token window as in gtok_sent_lane.hpp, flushed four tokens (one 16-byte store) at a time: this kernel is bound
     // by the instructions of its bracket loops, not by its HBM writes
-    constexpr int SG = 1;
+#ifndef GTOK_BLANE_SECTOR_GROUPS
+#define GTOK_BLANE_SECTOR_GROUPS 1
+#endif
+    constexpr int SG = GTOK_BLANE_SECTOR_GROUPS;
     uint64_t pg[SG > 1 ? SG - 1 : 1];
 #pragma unroll
     for (int j = 0; j < SG - 1; ++j) pg[j] = 0;

@@ -22,7 +22,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         d = gtok.synth.zinc_like(int(rng.integers(65536, 90000)), seed=seed); labeled = bool(rng.integers(0, 2)); nn = 40
     elif kind == 2:
         mx = int(rng.integers(12, 300))
-        d = gtok.synth.er_batch(int(rng.integers(1, 400)), seed=seed, min_nodes=int(rng.integers(1, 11)), max_nodes=mx,
+        d = gtok.synth.er_batch(int(rng.integers(1, 700)), seed=seed, min_nodes=int(rng.integers(1, 11)), max_nodes=mx,
                                 min_sparsity=0.02, max_sparsity=float(rng.uniform(0.05, 0.3))); labeled = False; nn = mx
     else:
         d = gtok.synth.graph_token_like(int(rng.integers(1, 300)), seed=seed, with_text=False); labeled = False; nn = 49
@@ -34,15 +34,32 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     sd, ep, base = int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 1000)), int(rng.integers(0, 2 ** 40))
     pins = ["", "reg", "lds"] if batch.max_nodes <= 64 else ["", "lds"]
     if (batch.flags & 1) and batch.max_nodes <= 64 and batch.max_edges <= 255:
-        pins.append("lane")
+        pins += ["lane", "lane-unsorted", "lane-int32"]   # reordered copy (default) / batch as stored / no byte mirror
+    if not labeled and batch.max_nodes <= 256:
+        pins += ["blane", "blane-unordered"]               # adjacency bit-matrix mirror, lanes by expected length / as stored
+    query = None
+    if rng.integers(0, 3) == 0 and coo.G:                  # a query tail on a third of the rounds
+        nc = np.maximum(np.asarray(d["node_counts"]), 1)
+        query = np.stack([rng.integers(0, nc), rng.integers(0, nc)], 1).astype(np.int32)
+    pad = bool(rng.integers(0, 4))
     ref = None
     for pin in pins:
-        os.environ["GTOK_SENT_KERNEL"] = pin
-        ids, ln = gtok.ops.sent(dev, nn, max_len, sd, ep, graph_base=base, **kw)
+        os.environ["GTOK_SENT_KERNEL"] = pin.split("-")[0]
+        os.environ["GTOK_NO_LANE_SORT"] = "1" if pin == "lane-unsorted" else "0"
+        os.environ["GTOK_NO_PACK8"] = "1" if pin == "lane-int32" else "0"
+        os.environ["GTOK_BLANE_ORDER"] = "0" if pin == "blane-unordered" else "1"
+        fresh = batch.to(DEV)                               # the resident layouts are made per pin
+        ids, ln = gtok.ops.sent(fresh, nn, max_len, sd, ep, graph_base=base, query=None if query is None else torch.from_numpy(query), pad=pad, **kw)
         if ref is None:
-            ref = orc.sent(coo, nn, max_len, sd, ep, graph_base=base, ld=ids.shape[1], nthreads=T, **kw)
-        cmp(f"sent it={it} kind={kind} pin={pin or 'auto'} G={coo.G} max_len={max_len}", ids, ln, *ref)
-    os.environ["GTOK_SENT_KERNEL"] = ""
+            ref = orc.sent(coo, nn, max_len, sd, ep, graph_base=base, ld=ids.shape[1], nthreads=T, query=query, **kw)
+        if pad:
+            cmp(f"sent it={it} kind={kind} pin={pin or 'auto'} G={coo.G} max_len={max_len} query={query is not None}", ids, ln, *ref)
+        else:                                               # GTOK_SENT_NO_PAD: rows equal inside their lengths
+            inside = np.arange(ref[0].shape[1])[None, :] < ref[1][:, None]
+            if not (np.array_equal(ln.cpu().numpy(), ref[1]) and np.array_equal(np.where(inside, ids.cpu().numpy(), 0), np.where(inside, ref[0], 0))):
+                fails += 1; print("MISMATCH (no pad)", pin, it, flush=True)
+    for k in ("GTOK_SENT_KERNEL", "GTOK_NO_LANE_SORT", "GTOK_NO_PACK8", "GTOK_BLANE_ORDER"):
+        os.environ[k] = "" if k == "GTOK_SENT_KERNEL" else ("1" if k == "GTOK_BLANE_ORDER" else "0")
     if labeled:
         vocab = zinc_vocab(int(rng.integers(1, 45)), with_fallbacks=bool(rng.integers(0, 2)))
         lut = gtok.ops.zinc_lut(vocab, 45)
