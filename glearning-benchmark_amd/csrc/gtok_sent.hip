@@ -31,8 +31,9 @@ constexpr int GTOK_LANE_MIN_GRAPHS = 28000;     // measured crossover on ZINC-sh
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 
-// below this many graphs the bit-matrix lane kernel cannot fill the chip either (measured crossover, 10-256-node graphs)
-constexpr int GTOK_BLANE_MIN_GRAPHS = 4096;
+// below this many graphs the wave-per-graph LDS kernel is faster: the lane kernel's time is its longest walk (0.37 ms from
+// 4 k to 16 k graphs of 10-256 nodes, profiles/tools/blane_crossover.sh: ER crosses at ~24 k, the family mix at ~11 k)
+constexpr int GTOK_BLANE_MIN_GRAPHS = 20000;
 
 // 0 = lane-per-graph, 1 = register-resident wave-per-graph, 2 = LDS bit matrix, 3 = lane-per-graph over the adjacency
 // bit-matrix mirror.  GTOK_SENT_KERNEL=lane|reg|lds|blane pins a kernel where it is applicable (tests run every path).

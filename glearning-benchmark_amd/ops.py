@@ -111,7 +111,7 @@ def sent_safe_ld(batch: GraphBatch, labeled: bool, max_len: int, with_query: boo
     return (min(max_len, bound) + (3 if with_query else 0) + 15) // 16 * 16
 
 
-ADJBITS_MIN_GRAPHS = 4096     # = GTOK_BLANE_MIN_GRAPHS of gtok_sent.hip: below it gtok_sent never picks the bit-matrix lane kernel
+ADJBITS_MIN_GRAPHS = 20000    # = GTOK_BLANE_MIN_GRAPHS of gtok_sent.hip: below it gtok_sent never picks the bit-matrix lane kernel
 
 
 def pack8(batch: GraphBatch) -> bool:

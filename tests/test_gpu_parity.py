@@ -979,9 +979,9 @@ def test_sent_bit_matrix_lane_kernel(order, monkeypatch):
 
 
 def test_config5_sized_batches_take_the_bit_matrix_lane_kernel():
-    """A config-5 sized batch (>= 4096 unlabelled graphs of 10-256 nodes) is tokenized by sent_blane_kernel by default;
+    """A config-5 sized batch (>= 20 k unlabelled graphs of 10-256 nodes) is tokenized by sent_blane_kernel by default;
     bit-exact against the oracle, ER and the seven-family mix."""
-    for name, d in (("er", gtok.synth.er_batch_device(6000, DEV, seed=3)), ("mix", gtok.synth.mix_batch_device(6000, DEV, seed=4))):
+    for name, d in (("er", gtok.synth.er_batch_device(20480, DEV, seed=3)), ("mix", gtok.synth.mix_batch_device(20480, DEV, seed=4))):
         batch, coo = both(d, False)
         b = batch.to(DEV)
         for max_len in (100000, 600):
@@ -1030,7 +1030,7 @@ def test_lane_kernel_on_the_reordered_batch(monkeypatch):
                 assert sb.num_units > (b.num_graphs + 63) // 64          # the 64-node graphs do not fit 64 to a unit
 
 
-def test_hip_graph_capture_of_the_one_workgroup_per_cu_launches():
+def test_hip_graph_capture_of_the_one_workgroup_per_cu_launches(monkeypatch):
     """The lane-per-graph kernels launch one workgroup per CU with more than 64 KB of dynamic LDS (an attribute the
     launcher sets on every call: it must be legal while a stream is capturing).  70 k molecules (reordered batch, 16-wave
     workgroups) and 6 k unlabelled graphs of up to 256 nodes (bit-matrix kernel, 8-wave workgroups): captured once,
@@ -1047,13 +1047,16 @@ def test_hip_graph_capture_of_the_one_workgroup_per_cu_launches():
     s_out = (torch.empty((70000, ld), dtype=torch.int32, device=DEV), torch.empty(70000, dtype=torch.int32, device=DEV))
     e_out = (torch.empty((6000, eld), dtype=torch.int32, device=DEV), torch.empty(6000, dtype=torch.int32, device=DEV))
     gtok.ops.sent(b, 37, 1024, 9, 4, ld=ld, out=s_out, **kw)               # warm-up: the resident layouts are made here
+    monkeypatch.setenv("GTOK_SENT_KERNEL", "blane")                         # (6 k graphs: below the size where it is the default)
     gtok.ops.sent(ebd, 256, 600, 9, 4, ld=eld, out=e_out)
     assert gtok.ops.sent_kernel_name(b, 37, 1024, **kw) == "sent_lane_kernel" and b.lane_sorted is not None and b.lane_sorted.num_units >= 1024
     assert gtok.ops.sent_kernel_name(ebd, 256, 600).startswith("sent_blane_kernel")
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
+        monkeypatch.delenv("GTOK_SENT_KERNEL")
         gtok.ops.sent(b, 37, 1024, 9, 4, ld=ld, out=s_out, **kw)
+        monkeypatch.setenv("GTOK_SENT_KERNEL", "blane")
         gtok.ops.sent(ebd, 256, 600, 9, 4, ld=eld, out=e_out)
     ref, rln = orc.sent(coo, 37, 1024, 9, 4, ld=ld, nthreads=8, **kw)
     eref, erln = orc.sent(ecoo, 256, 600, 9, 4, ld=eld, nthreads=8)
