@@ -1159,48 +1159,20 @@ struct ParseArgs {
   int units, upb;
 };
 
-__global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a) {
-  // the text travels through a 2 KB LDS ring per wave, 16 bytes per lane and load, the chunk after next in flight while
-  // the current one is split (a byte per lane straight from HBM, one piece ahead, left the waves waiting for memory half
-  // of the time)
-  __shared__ __align__(16) uint8_t ring_all[4][kTextRing];
+// ---------------------------------------------------------------------------------------------
+// graph-token text -> edge list, phase 1: the edge zone, streamed (wave per text, 1 KB per step, registers only: a light
+// kernel with many waves per SIMD, so that the loads of one wave travel behind the work of the others)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) parse_edge_zone_kernel(const ParseArgs a) {
   const int lane = lane_id();
-  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
-  uint8_t *ring = ring_all[wave];
-  U8x16a *ring16 = reinterpret_cast<U8x16a *>(ring);
-  const int64_t total = a.text_ptr[a.num_texts];
-  auto load16 = [&](int64_t abs) -> U8x16 {   // never touches bytes past the end of the blob
-    if (abs + 16 <= total) return *reinterpret_cast<const U8x16 *>(a.bytes + abs);
-    uint32_t w[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
-    for (int b = 0; b < 16; ++b)
-      if (abs + b < total) w[b >> 2] = (w[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | ((uint32_t)a.bytes[abs + b] << (8 * (b & 3)));
-    return U8x16{w[0], w[1], w[2], w[3]};
-  };
+  const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave_id();
+  if (g >= a.num_texts) return;
   const bool fill = a.edge_ptr != nullptr;
-  const int vb = virtual_block();
-  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
-  for (int unit = u0; unit < u1; ++unit) {
-    const int g = unit * wpb + wave;
-    if (g >= a.num_texts) break;
-    const uint8_t *__restrict__ s = a.bytes + a.text_ptr[g];
-    int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
-    const int64_t ebase = fill ? a.edge_ptr[g] : 0;
-    const int64_t ecap = fill ? a.edge_ptr[g + 1] - ebase : 0;
-    auto lit = [&](int64_t i, int len, const char *w, int wl) -> bool {   // token == literal (upper-cased text)
-      if (len != wl) return false;
-      for (int j = 0; j < wl; ++j) {
-        uint32_t c = s[i + j];
-        if (c >= 'a' && c <= 'z') c -= 32;
-        if (c != (uint32_t)w[j]) return false;
-      }
-      return true;
-    };
-    int count = 0, tn = -1, tq = -1, q_t = -1, p_t = -1, cnt_n = 0, cnt_q = 0, cnt_p = 0;
-    int max_end = -1, max_node = -1, nnodes = 0, bad = 0;
-    int sd = 0, qu = -1, qv = -1, qu_ok = 0, qv_ok = 0, label = kNoLabel;
-    bool prev_sp = true;
-    // the token that runs into this piece: decimal value so far, length, "digits only so far"
-    uint32_t carry_val = 0; int carry_len = 0; bool carry_dig = true;
+  const uint8_t *__restrict__ s = a.bytes + a.text_ptr[g];
+  const int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
+  const int64_t ebase = fill ? a.edge_ptr[g] : 0;
+  const int64_t ecap = fill ? a.edge_ptr[g + 1] - ebase : 0;
+  {
     // ---- the edge zone, streamed.  `INT INT <e>` triples are nearly all of a text, and as long as a 1 KB window holds
     // nothing but them (and <bos> as token 0) it needs no structure tracking at all: every lane takes 16 bytes - and the 16
     // before them: a plain token is at most 9 bytes long, so one that ends in the lane's bytes began inside that view - walks
@@ -1210,6 +1182,7 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
     // long number, a token out of place) and everything after it go through the general loop below, which starts right
     // behind the last token the stream took, with the token count where the stream left it: same results, byte for byte.
     int64_t handover = 0;
+    int count = 0, max_end = -1;
     for (int64_t wb = 0; wb < n; wb += 1024) {
       const int64_t o = wb + 16 * lane;
       uint32_t w[8];                                              // bytes o - 16 .. o + 15; outside the text: spaces
@@ -1295,6 +1268,64 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
         handover = wb + 16 * l + __builtin_amdgcn_readlane(lastp, l) + 1;
       }
     }
+    for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
+    if (lane == 0) {   // state for parse_graph_text_kernel (which overwrites these slots with the text's results)
+      a.num_edges[g] = count;
+      a.num_nodes[g] = max_end;
+      a.query[2 * (int64_t)g] = (int32_t)(uint32_t)handover;
+      a.query[2 * (int64_t)g + 1] = (int32_t)(handover >> 32);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a) {
+  // the text travels through a 2 KB LDS ring per wave, 16 bytes per lane and load, the chunk after next in flight while
+  // the current one is split (a byte per lane straight from HBM, one piece ahead, left the waves waiting for memory half
+  // of the time)
+  __shared__ __align__(16) uint8_t ring_all[4][kTextRing];
+  const int lane = lane_id();
+  const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
+  uint8_t *ring = ring_all[wave];
+  U8x16a *ring16 = reinterpret_cast<U8x16a *>(ring);
+  const int64_t total = a.text_ptr[a.num_texts];
+  auto load16 = [&](int64_t abs) -> U8x16 {   // never touches bytes past the end of the blob
+    if (abs + 16 <= total) return *reinterpret_cast<const U8x16 *>(a.bytes + abs);
+    uint32_t w[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+    for (int b = 0; b < 16; ++b)
+      if (abs + b < total) w[b >> 2] = (w[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | ((uint32_t)a.bytes[abs + b] << (8 * (b & 3)));
+    return U8x16{w[0], w[1], w[2], w[3]};
+  };
+  const bool fill = a.edge_ptr != nullptr;
+  const int vb = virtual_block();
+  const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
+  for (int unit = u0; unit < u1; ++unit) {
+    const int g = unit * wpb + wave;
+    if (g >= a.num_texts) break;
+    const uint8_t *__restrict__ s = a.bytes + a.text_ptr[g];
+    int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
+    const int64_t ebase = fill ? a.edge_ptr[g] : 0;
+    const int64_t ecap = fill ? a.edge_ptr[g + 1] - ebase : 0;
+    auto lit = [&](int64_t i, int len, const char *w, int wl) -> bool {   // token == literal (upper-cased text)
+      if (len != wl) return false;
+      for (int j = 0; j < wl; ++j) {
+        uint32_t c = s[i + j];
+        if (c >= 'a' && c <= 'z') c -= 32;
+        if (c != (uint32_t)w[j]) return false;
+      }
+      return true;
+    };
+    int count = 0, tn = -1, tq = -1, q_t = -1, p_t = -1, cnt_n = 0, cnt_q = 0, cnt_p = 0;
+    int max_end = -1, max_node = -1, nnodes = 0, bad = 0;
+    int sd = 0, qu = -1, qv = -1, qu_ok = 0, qv_ok = 0, label = kNoLabel;
+    bool prev_sp = true;
+    // the token that runs into this piece: decimal value so far, length, "digits only so far"
+    uint32_t carry_val = 0; int carry_len = 0; bool carry_dig = true;
+    // ---- the edge zone has been streamed by parse_edge_zone_kernel: it left, in this text's output slots, the token count
+    // and largest endpoint it reached and the byte where this loop takes over (the first window that holds anything but
+    // `INT INT <e>` triples starts there, right behind the last token the stream took)
+    count = a.num_edges[g];
+    max_end = a.num_nodes[g];
+    const int64_t handover = (int64_t)(uint32_t)a.query[2 * (int64_t)g] | ((int64_t)a.query[2 * (int64_t)g + 1] << 32);
     s += handover;                                                  // the general loop sees the rest as a text of its own
     n -= handover;
     const int64_t t0 = a.text_ptr[g] + handover;
@@ -1885,6 +1916,8 @@ extern "C" int gtok_parse_graph_text(const uint8_t *bytes, const int64_t *text_p
   a.num_edges = num_edges; a.num_nodes = num_nodes; a.query = query_nodes; a.label = label; a.status = status;
   const Launch L = plan(reinterpret_cast<const void *>(parse_graph_text_kernel), num_texts, 4, 0);
   a.units = L.units; a.upb = L.upb;
+  hipLaunchKernelGGL(parse_edge_zone_kernel, dim3((num_texts + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  if (hipGetLastError() != hipSuccess) return GTOK_E_LAUNCH;
   hipLaunchKernelGGL(parse_graph_text_kernel, dim3(L.nb), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
