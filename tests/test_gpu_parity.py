@@ -287,6 +287,25 @@ def test_c_abi_error_codes():
     assert L.gtok_ibtt_zinc(ctypes.byref(cs), None, 64, 64, 2, ids.data_ptr(), 64, ln.data_ptr(), None) == -1
     vt = lib_mod.GtokVocabTable(12, 0, None, None, None, None)                                               # not a power of two
     assert L.gtok_text_to_ids(None, ln.data_ptr(), 0, ctypes.byref(vt), 1, 8, ids.data_ptr(), 64, ln.data_ptr(), None) == -1
+    # a batch reordered for the lane-per-graph SENT kernel is for that kernel alone
+    lab9 = lib_mod.GtokSentParams(37, 1, 9, 4, 64, 0, 5, 0, 1, 0, 0, None)
+    gtok.ops.sent(b, 37, 64, 1, labeled=True, num_node_types=9, num_edge_types=4)                            # (makes nothing: too small a batch ...)
+    sb = gtok.ops.lane_sorted(b)                                                                             # ... so ask for the copy
+    assert sb is not None and sb.graph_ids is not None
+    css = sb.c_struct()
+    assert L.gtok_sent(ctypes.byref(css), ctypes.byref(lab9), ids.data_ptr(), 64, ln.data_ptr(), None) == 0
+    lut = gtok.ops.zinc_lut(zinc_vocab(40), 40).to(DEV)
+    assert L.gtok_ibtt_zinc(ctypes.byref(css), lut.data_ptr(), lut.numel(), 64, 2, ids.data_ptr(), 64, ln.data_ptr(), None) == -1
+    info = torch.zeros(1, dtype=torch.int32, device=DEV)
+    rows = torch.empty((sb.num_nodes_total, 1), dtype=torch.int64, device=DEV); planes = torch.empty((8, 8, 1), dtype=torch.int64, device=DEV)
+    assert L.gtok_csr_adjbits(ctypes.byref(css), 1, rows.data_ptr(), planes.data_ptr(), info.data_ptr(), None) == -1
+    assert L.gtok_csr_adjbits(ctypes.byref(cs), 3, rows.data_ptr(), planes.data_ptr(), info.data_ptr(), None) == -1      # words: 1, 2 or 4
+    assert L.gtok_csr_adjbits(ctypes.byref(cs), 1, rows.data_ptr(), planes.data_ptr(), info.data_ptr(), None) == 0
+    half = gtok.GraphBatch(sb.num_graphs, sb.max_nodes, sb.max_edges, sb.node_ptr, sb.edge_ptr, sb.rowptr, sb.col, None, sb.nattr, sb.eattr,
+                           sb.flags, sb.chunk_nodes, sb.chunk_edges, sb.max_degree)
+    half.graph_ids = sb.graph_ids                                                                            # ids without a unit table
+    csh = half.c_struct()
+    assert L.gtok_sent(ctypes.byref(csh), ctypes.byref(lab9), ids.data_ptr(), 64, ln.data_ptr(), None) == -1
     torch.cuda.synchronize()
     with pytest.raises(gtok.GtokError):
         gtok.ops.sent(big, 37, 64, 0)
