@@ -162,8 +162,10 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
       // (the opt-in to more than 64 KB of dynamic LDS is per kernel and per device: a host-side call of a microsecond)
       const bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       int occ16 = 0;
-      if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 1024, (size_t)a.lds * 16) == hipSuccess && occ16 >= 1) {
-        hipLaunchKernelGGL(kern, dim3(ncu), dim3(1024), (size_t)a.lds * 16, (hipStream_t)stream, a);
+      const char *ww = std::getenv("GTOK_LANE_WG_WAVES");   // tuning knob: 8 = two 8-wave workgroups per CU
+      const int wgw = (ww && ww[0] == '8') ? 8 : 16;
+      if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 64 * wgw, (size_t)a.lds * wgw) == hipSuccess && occ16 >= 16 / wgw) {
+        hipLaunchKernelGGL(kern, dim3(ncu * (16 / wgw)), dim3(64 * wgw), (size_t)a.lds * wgw, (hipStream_t)stream, a);
         return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
       }
       (void)hipGetLastError();

@@ -254,8 +254,12 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   // 4,096 units, rank (w >> 2) * 1024 + j of the stored order, j = (w & 3) * 256 + b, odd quarters backwards (long with
   // short).  The quarter is also the wave's issue priority: the stragglers-to-be get the slots their SIMD-mates can spare.
   const bool percu = blockDim.x > 64;
-  const int nslots = (int)gridDim.x * 16, quarter = wave >> 2, qsize = (int)gridDim.x * 4;
-  const int jq = (wave & 3) * (int)gridDim.x + (int)blockIdx.x;
+  // (GTOK_LANE_WG_WAVES=8: two 8-wave workgroups per CU, each balanced in itself - quarters 0 + 3 or 1 + 2 on every SIMD)
+  const int wg_waves = (int)(blockDim.x >> 6), wgs_per_cu = wg_waves == 8 ? 2 : 1;
+  const int cus = (int)gridDim.x / wgs_per_cu, wg_type = (int)blockIdx.x % wgs_per_cu, wg_cu = (int)blockIdx.x / wgs_per_cu;
+  const int nslots = cus * 16, qsize = cus * 4;
+  const int quarter = wg_waves == 8 ? (wg_type == 0 ? ((wave >> 2) ? 3 : 0) : ((wave >> 2) ? 2 : 1)) : wave >> 2;
+  const int jq = (wave & 3) * cus + wg_cu;
   for (int idx = percu ? 0 : (a.unit_mul ? (int)blockIdx.x : virtual_block()); idx < a.units; idx += percu ? nslots : stride) {
     int unit = idx;
     if (percu) {
