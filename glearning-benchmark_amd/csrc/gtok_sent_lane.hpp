@@ -23,6 +23,7 @@
 // filled cooperatively (coalesced) at the end of the unit.  Limits: maxn <= 64, maxe <= 255 (u8 indices),
 // degree < 2^P (the launcher picks P from gtok_csr.max_degree).
 #pragma once
+#include <type_traits>
 #include "gtok_sent_reg.hpp"
 
 namespace gtok {
@@ -40,6 +41,15 @@ __device__ __forceinline__ int kth_bit64(uint64_t w, int k) {
   int base = 0, c = __popc(x);
   if (k >= c) { k -= c; x = (uint32_t)(w >> 32); base = 32; }
   c = __popc(x & 0xFFFFu); if (k >= c) { k -= c; x >>= 16; base += 16; }
+  c = __popc(x & 0xFFu);   if (k >= c) { k -= c; x >>= 8;  base += 8; }
+  c = __popc(x & 0xFu);    if (k >= c) { k -= c; x >>= 4;  base += 4; }
+  c = __popc(x & 0x3u);    if (k >= c) { k -= c; x >>= 2;  base += 2; }
+  return base + ((k >= (int)(x & 1u)) ? 1 : 0);
+}
+
+__device__ __forceinline__ int kth_bit32(uint32_t x, int k) {
+  int base = 0, c = __popc(x & 0xFFFFu);
+  if (k >= c) { k -= c; x >>= 16; base = 16; }
   c = __popc(x & 0xFFu);   if (k >= c) { k -= c; x >>= 8;  base += 8; }
   c = __popc(x & 0xFu);    if (k >= c) { k -= c; x >>= 4;  base += 4; }
   c = __popc(x & 0x3u);    if (k >= c) { k -= c; x >>= 2;  base += 2; }
@@ -333,9 +343,20 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       else __builtin_amdgcn_s_setprio(0);
     }
 #endif
+    // The unit's body, written once and compiled twice: node sets (visited, rows, counter planes, brackets) as 64-bit
+    // words, or as 32-bit words when no graph of the unit has more than 32 nodes - nearly every unit of a molecule corpus,
+    // and half the vector instructions of every set operation (a 64-bit AND / OR / shift / popcount is two).
+    auto unit_body = [&](auto s32_tag) __attribute__((always_inline)) {
+    constexpr bool S32 = decltype(s32_tag)::value;
+    using set_t = typename std::conditional<S32, uint32_t, uint64_t>::type;
+    constexpr int kSetBits = S32 ? 32 : 64;
+    auto bit_of = [](uint32_t i) __attribute__((always_inline)) -> set_t { return (set_t)((set_t)1 << (i & (uint32_t)(kSetBits - 1))); };
+    auto popc_of = [](set_t x) __attribute__((always_inline)) -> int { if constexpr (S32) return __popc(x); else return __popcll(x); };
+    auto ctz_of = [](set_t x) __attribute__((always_inline)) -> int { if constexpr (S32) return __builtin_ctz(x); else return __builtin_ctzll(x); };
+    auto kth_bit_of = [](set_t x, int k) __attribute__((always_inline)) -> int { if constexpr (S32) return kth_bit32(x, k); else return kth_bit64(x, k); };
     // A node's row: bounds, the set of its neighbours, and the first four neighbour ids / edge types as packed
     // bytes (molecules rarely have more; longer rows continue in byte loops).
-    struct Row { uint64_t mask; uint32_t nb4, et4, bm; int rs, deg; };   // bm: byte mask of the valid entries among the first four
+    struct Row { set_t mask; uint32_t nb4, et4, bm; int rs, deg; };   // bm: byte mask of the valid entries among the first four
     auto load_row = [&](int v) __attribute__((always_inline)) -> Row {
       Row r;
       r.rs = srp[rbase + v];
@@ -352,9 +373,9 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       // entries past the row's end are replaced by its first entry (duplicates are harmless in a set): no per-entry select.
       // v_lshlrev_b64 takes the low 6 bits of its shift operand, so the upper bytes need no masking.
       const uint32_t nv = __builtin_amdgcn_perm(r.nb4, r.nb4, 0x03020100u & r.bm);
-      uint64_t m = (1ull << (nv & 63u)) | (1ull << ((nv >> 8) & 63u)) | (1ull << ((nv >> 16) & 63u)) | (1ull << (nv >> 24 & 63u));
-      m = r.deg > 0 ? m : 0ull;
-      for (int k = 4; k < r.deg; ++k) m |= 1ull << (scol[o + k] & 63u);
+      set_t m = bit_of(nv) | bit_of(nv >> 8) | bit_of(nv >> 16) | bit_of(nv >> 24);
+      m = r.deg > 0 ? m : (set_t)0;
+      for (int k = 4; k < r.deg; ++k) m |= bit_of(scol[o + k]);
       r.mask = m;
       return r;
     };
@@ -374,7 +395,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     };
 
     // ---- bit-sliced counters: c[p] bit u = bit p of (number of unvisited neighbours of u); starts at the degree
-    uint64_t c[P];
+    set_t c[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) c[p] = 0;
     if (n > 0) {
@@ -396,7 +417,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
         for (int p = 0; p < P; ++p) {
           const uint32_t x = (dg4 >> p) & 0x01010101u;
           const uint32_t nib = (x | (x >> 7) | (x >> 14) | (x >> 21)) & 15u;
-          c[p] |= (uint64_t)nib << ((4 * i) & 63);
+          c[p] |= (set_t)nib << ((4 * i) & (kSetBits - 1));
         }
         d1 = d2; cur4 = nxt4;
       }
@@ -409,7 +430,8 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
     const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
     int32_t *__restrict__ orow = a.out + (int64_t)g * ld;
-    uint64_t vis = 0, live = 0, wlo = 0;
+    set_t vis = 0, live = 0;
+    uint64_t wlo = 0;
     int nvis = 0, pos = 0, fl = 0, d = 0, cur = 0;
 
     // token window: tokens fl .. pos-1 of the row sit in wlo, 16 bits each (pos - fl <= 3 between appends).  A full
@@ -476,7 +498,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       append((uint64_t)GTOK_SENT_SOS, 1);
       if (n > 0) {
         Row rc{0, 0, 0, 0, 0};   // row of cur, carried from step to step (empty before the first visit)
-        const uint64_t nodes = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        const set_t nodes = n >= kSetBits ? ~(set_t)0 : (set_t)(((set_t)1 << (n & (kSetBits - 1))) - 1);
         // Every step draws exactly one decision and touches exactly one node, so the draw, the pick, the row load
         // and the token group are written ONCE and the step's kind only selects operands.  (With one copy per
         // kind, a wave whose lanes are in different kinds - nearly every step - runs every copy.)
@@ -484,13 +506,13 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
 #ifdef GTOK_PHASE_TIMING
           ++iters;
 #endif
-          const uint64_t row = rc.mask & ~vis;
+          const set_t row = rc.mask & ~vis;
           // 0: extend the trail over an uncovered edge (always towards an unvisited node); 1: dead end, restart from
           // a visited node that still owns uncovered edges; 2: another component or an isolated node
           const int kind = row ? 0 : (live ? 1 : 2);
           if (kind == 2 && nvis >= n) break;
-          const uint64_t set = kind == 0 ? row : (kind == 1 ? live : (~vis & nodes));
-          const int pick = kth_bit64(set, (int)below((uint32_t)__popcll(set)));
+          const set_t set = kind == 0 ? row : (kind == 1 ? live : (set_t)(~vis & nodes));
+          const int pick = kth_bit_of(set, (int)below((uint32_t)popc_of(set)));
           uint32_t et = 0;
           if (LAB && kind == 0) et = find_et(rc, (uint32_t)pick);   // type of the listed entry cur -> pick
           const Row rn = load_row(pick);
@@ -516,28 +538,28 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
           }
           // ---- first visit: neighbours lose an unvisited neighbour; already visited neighbours other than the
           // trail's predecessor are this node's bracket
-          const uint64_t S = first ? rn.mask : 0ull;
-          uint64_t M = S & vis & ~(kind == 0 ? 1ull << cur : 0ull);
+          const set_t S = first ? rn.mask : (set_t)0;
+          set_t M = S & vis & ~(kind == 0 ? bit_of((uint32_t)cur) : (set_t)0);
           {
-            uint64_t b = S, nz = 0;
+            set_t b = S, nz = 0;
 #pragma unroll
-            for (int p = 0; p < P; ++p) { const uint64_t t = c[p]; c[p] = t ^ b; b &= ~t; nz |= c[p]; }
-            vis |= 1ull << pick;
+            for (int p = 0; p < P; ++p) { const set_t t = c[p]; c[p] = t ^ b; b &= ~t; nz |= c[p]; }
+            vis |= bit_of((uint32_t)pick);
             live = vis & nz;
           }
           nvis += first;
           if (M) {   // LADJ, members by ascending visit index ([edge type] position), RADJ
             bool head = true;
             do {
-              uint64_t t = M;
+              set_t t = M;
               int bu = 0, bv = 256;
               do {
-                const int u = __builtin_ctzll(t);
+                const int u = ctz_of(t);
                 t &= t - 1;
                 const int vx = snat[nbase + u];
                 if (vx < bv) { bv = vx; bu = u; }
               } while (t);
-              M &= ~(1ull << bu);
+              M &= ~bit_of((uint32_t)bu);
               uint32_t lo = (uint32_t)(pos_base + bv), hi = 0;
               int cnt = 1;
               if (LAB) {
@@ -610,6 +632,9 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
 #ifdef GTOK_PHASE_TIMING
     ts[4] = __builtin_amdgcn_s_memtime();
 #endif
+    };
+    if (__ballot(valid && n > 32) == 0) unit_body(std::true_type{});
+    else unit_body(std::false_type{});
   }
   if (done_cnt > 0) pad_rows();
 #ifdef GTOK_PHASE_TIMING
