@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     // edge type of the listed entry row -> y (y is listed: symmetric adjacency).  Zero-byte search over the four
     // packed ids (the lowest flag of the classic (x - 0x01..) & ~x & 0x80.. test is exact), byte loop beyond.
     auto find_et = [&](const Row &r, uint32_t y) __attribute__((always_inline)) -> uint32_t {
-      const uint32_t x = r.nb4 ^ (y * 0x01010101u);
+      const uint32_t x = r.nb4 ^ __builtin_amdgcn_perm(y, y, 0u);   // y in all four bytes (a 32-bit multiply is quarter rate)
       const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u & r.bm;
       uint32_t et = 0;
       if (z) {
