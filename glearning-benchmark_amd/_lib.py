@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 # GTOK_LIB: load another build of the same ABI (profiling builds of profiles/tools, e.g. -DGTOK_PHASE_TIMING)
 LIB_PATH = os.environ.get("GTOK_LIB") or os.path.join(_HERE, "csrc", "libgtok.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("gtok_sent.hip", "gtok_ibtt.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("gtok_sent.hip", "gtok_ibtt.hip", "gtok_rows.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "gtok_common.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_blane.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_reg.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_lds.hpp"),
            os.path.join(_HERE, "csrc", "gtok_sent_lane.hpp"),
            os.path.join(_ROOT, "include", "gtok.h")]
@@ -78,6 +78,10 @@ SYMBOLS = {
     "gtok_vocab_stats_text": (_I, [_P, _P, _I, ctypes.c_int64, _I, _P, _P, _P, _P, _P, _P]),
     "gtok_csr_adjbits": (_I, [ctypes.POINTER(GtokCsr), _I, _P, _P, _P, _P]),
     "gtok_csr_pack8": (_I, [ctypes.POINTER(GtokCsr), ctypes.c_int64, ctypes.c_int64, _P, _P, _P]),
+    "gtok_row_offsets": (_I, [_P, ctypes.c_int64, _I, _I, _P, _P]),
+    "gtok_pack_rows": (_I, [_P, _I, _P, ctypes.c_int64, _P, _I, _P, ctypes.c_int64, _P, _P]),
+    "gtok_unpack_rows": (_I, [_P, _I, _P, _P, ctypes.c_int64, _I, ctypes.c_int64, _I, _P, _I, _P]),
+    "gtok_collate_packed": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P]),
     "gtok_sent_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(GtokCsr), ctypes.POINTER(GtokSentParams)]),
     "gtok_ibtt_zinc_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(GtokCsr)]),
     "gtok_version": (_I, []),
@@ -91,15 +95,46 @@ class GtokError(RuntimeError):
     pass
 
 
+def _includes(src: str):
+    """Project headers a source includes (directly), for the rebuild check."""
+    out = []
+    with open(src) as f:
+        for line in f:
+            if line.startswith('#include "'):
+                name = line.split('"')[1]
+                for d in (os.path.join(_HERE, "csrc"), os.path.join(_ROOT, "include")):
+                    if os.path.exists(os.path.join(d, name)):
+                        out.append(os.path.join(d, name))
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into csrc/libgtok.so (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP sources for gfx950 into csrc/libgtok.so (hipcc cross-compiles without a GPU): one object per
+    source under csrc/_obj/ (compiled side by side, only the stale ones), then one link."""
     deps = SOURCES + HEADERS
     if not force and os.path.exists(LIB_PATH) and all(
             os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-I" + os.path.join(_ROOT, "include"), "-o", LIB_PATH] + SOURCES
+    objdir = os.path.join(_HERE, "csrc", "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    common = os.path.join(_HERE, "csrc", "gtok_common.hpp")
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        srcdeps = [src] + _includes(src) + _includes(common)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in srcdeps):
+            continue
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c",
+               "-I" + os.path.join(_ROOT, "include"), "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -109,7 +144,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 _lib = None
 
 
-ABI_VERSION = 2     # include/gtok.h: GTOK_ABI_VERSION
+ABI_VERSION = 3     # include/gtok.h: GTOK_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:

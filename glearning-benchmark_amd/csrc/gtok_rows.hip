@@ -1,0 +1,310 @@
+// gtok_rows.hip — the PACKED (ragged) row format of token slabs: offsets, pack, unpack, collate.
+//
+// A tokenizer entry point writes a padded [rows, ld] int32 slab (include/gtok.h).  More than half of a ZINC slab is
+// padding and every id fits 16 bits, so the copies that leave the GPU - the RCCL all-gather of BASELINE config 4
+// (trainer/train_agtt.py:602-607 needs the rows in dataset order on every rank) and the D2H copy behind
+// TokenizedGraphDataset.__getitem__ (trainer/train_agtt.py:246-273) - move the packed form: row r's
+// n_r = min(len[r], ld) ids, 16 or 32 bits each, contiguous from element row_ptr[r].  Pure data movement: HBM-bound,
+// no LDS, every access a 16-byte vector when the row starts allow it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gtok.h"
+#include "gtok_common.hpp"
+
+namespace gtok {
+
+constexpr int kScanBlock = 256, kScanItems = 16, kScanTile = kScanBlock * kScanItems;   // 4096 rows per scan block
+
+__device__ __forceinline__ int64_t row_cost(const int32_t *__restrict__ len, int64_t i, int ld, int align_mask) {
+  int n = len[i];
+  n = n < 0 ? 0 : (n > ld ? ld : n);
+  return (int64_t)((n + align_mask) & ~align_mask);
+}
+
+// block-wide exclusive scan of one int64 per thread (kScanBlock threads); returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ int64_t block_exclusive(int64_t v, int64_t *total) {
+  __shared__ int64_t wave_sum[kScanBlock / kWave];
+  const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+  int64_t inc = v;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int64_t up = __shfl_up(inc, o);
+    if (lane >= o) inc += up;
+  }
+  if (lane == kWave - 1) wave_sum[w] = inc;
+  __syncthreads();
+  int64_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kScanBlock / kWave; ++k) {
+    const int64_t s = wave_sum[k];
+    if (k < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// pass A: the sum of every tile of kScanTile rows lands in the row_ptr slot that closes the tile
+__global__ void __launch_bounds__(kScanBlock) row_tile_sums_kernel(const int32_t *__restrict__ len, int64_t rows, int ld,
+                                                                   int align_mask, int64_t *__restrict__ row_ptr) {
+  const int64_t lo = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (lo + k < rows) s += row_cost(len, lo + k, ld, align_mask);
+  int64_t total;
+  (void)block_exclusive(s, &total);
+  if (threadIdx.x == 0) {
+    const int64_t end = ((int64_t)blockIdx.x + 1) * kScanTile;
+    row_ptr[end < rows ? end : rows] = total;
+  }
+}
+
+// pass B: one workgroup turns the tile sums into running totals, in place (tiles <= rows / 4096: a few hundred)
+__global__ void __launch_bounds__(kScanBlock) row_tile_scan_kernel(int64_t rows, int64_t *__restrict__ row_ptr) {
+  const int64_t tiles = (rows + kScanTile - 1) / kScanTile;
+  int64_t carry = 0;
+  for (int64_t t0 = 0; t0 < tiles; t0 += kScanBlock) {
+    const int64_t t = t0 + threadIdx.x;
+    const int64_t end = (t + 1) * kScanTile;
+    const int64_t slot = end < rows ? end : rows;
+    const int64_t v = t < tiles ? row_ptr[slot] : 0;
+    int64_t total;
+    const int64_t ex = block_exclusive(v, &total);
+    if (t < tiles) row_ptr[slot] = carry + ex + v;
+    carry += total;
+  }
+  if (threadIdx.x == 0) row_ptr[0] = 0;
+}
+
+// pass C: every tile fills the slots strictly inside it from its base (the slot that closes the previous tile)
+__global__ void __launch_bounds__(kScanBlock) row_tile_fill_kernel(const int32_t *__restrict__ len, int64_t rows, int ld,
+                                                                   int align_mask, int64_t *__restrict__ row_ptr) {
+  const int64_t tile0 = (int64_t)blockIdx.x * kScanTile;
+  const int64_t lo = tile0 + (int64_t)threadIdx.x * kScanItems;
+  int64_t c[kScanItems];
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    c[k] = lo + k < rows ? row_cost(len, lo + k, ld, align_mask) : 0;
+    s += c[k];
+  }
+  int64_t total;
+  int64_t run = block_exclusive(s, &total) + row_ptr[tile0];
+  const int64_t tile_end = tile0 + kScanTile;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    run += c[k];
+    const int64_t slot = lo + k + 1;                      // row_ptr[slot] = end of row slot - 1
+    if (slot < rows && slot < tile_end) row_ptr[slot] = run;
+  }
+}
+
+// a row's start in the packed buffer: segments (the blocks the ranks of an all-gather contributed) restart at
+// multiples of segment_stride elements
+__device__ __forceinline__ int64_t packed_start(const int64_t *__restrict__ row_ptr, int64_t r, int segment_rows,
+                                                int64_t segment_stride) {
+  if (segment_rows <= 0) return row_ptr[r];
+  const int64_t seg = r / segment_rows;
+  return seg * segment_stride + (row_ptr[r] - row_ptr[seg * (int64_t)segment_rows]);
+}
+
+struct RowsArgs {
+  const int32_t *ids;      // pack: source slab; unpack: unused
+  int32_t *out_ids;        // unpack: destination slab
+  const int32_t *len;
+  const int64_t *row_ptr;
+  void *packed;
+  int32_t *status;
+  int64_t rows;
+  int ld, pad_id, segment_rows, tpr_shift;   // threads per row = 1 << tpr_shift
+  int64_t segment_stride, capacity;   // pack: elements `packed` can hold
+};
+
+// E = uint16_t or int32_t.  A thread owns pieces of 8 consecutive ids of one row: two 16-byte loads, one (or two)
+// 16-byte stores; 1 << tpr_shift threads share a row, 256 >> tpr_shift rows a workgroup.
+template <typename E>
+__global__ void __launch_bounds__(256) pack_rows_kernel(const RowsArgs a) {
+  const int tpr = 1 << a.tpr_shift, sub = (int)threadIdx.x & (tpr - 1);
+  const int64_t r = (int64_t)blockIdx.x * (256 >> a.tpr_shift) + ((int)threadIdx.x >> a.tpr_shift);
+  if (r >= a.rows) return;
+  int n = a.len[r];
+  n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
+  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride);
+  const int32_t *__restrict__ row = a.ids + r * (int64_t)a.ld;
+  if (start + n > a.capacity) {                      // a caller-sized buffer that turned out too small: skip, flag
+    if (sub == 0) atomicOr(a.status, 2);
+    return;
+  }
+  E *__restrict__ dst = reinterpret_cast<E *>(a.packed) + start;
+  const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+  uint32_t wide = 0;
+  for (int i = sub * 8; i < n; i += tpr * 8) {
+    if (vec && i + 8 <= n) {
+      const int4 lo = *reinterpret_cast<const int4 *>(row + i), hi = *reinterpret_cast<const int4 *>(row + i + 4);
+      if (sizeof(E) == 2) {
+        wide |= (uint32_t)(lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w);
+        uint4 o;
+        o.x = ((uint32_t)lo.x & 0xFFFFu) | ((uint32_t)lo.y << 16); o.y = ((uint32_t)lo.z & 0xFFFFu) | ((uint32_t)lo.w << 16);
+        o.z = ((uint32_t)hi.x & 0xFFFFu) | ((uint32_t)hi.y << 16); o.w = ((uint32_t)hi.z & 0xFFFFu) | ((uint32_t)hi.w << 16);
+        *reinterpret_cast<uint4 *>(dst + i) = o;
+      } else {
+        *reinterpret_cast<int4 *>(dst + i) = lo;
+        *reinterpret_cast<int4 *>(dst + i + 4) = hi;
+      }
+    } else {
+      for (int k = i; k < n && k < i + 8; ++k) {
+        const int32_t t = row[k];
+        wide |= (uint32_t)t;
+        dst[k] = (E)t;
+      }
+    }
+  }
+  if (sizeof(E) == 2 && (wide & 0xFFFF0000u)) atomicOr(a.status, 1);     // an id that does not fit 16 bits
+}
+
+template <typename E>
+__global__ void __launch_bounds__(256) unpack_rows_kernel(const RowsArgs a) {
+  const int tpr = 1 << a.tpr_shift, sub = (int)threadIdx.x & (tpr - 1);
+  const int64_t r = (int64_t)blockIdx.x * (256 >> a.tpr_shift) + ((int)threadIdx.x >> a.tpr_shift);
+  if (r >= a.rows) return;
+  int n = a.len[r];
+  n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
+  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride);
+  int32_t *__restrict__ row = a.out_ids + r * (int64_t)a.ld;
+  const E *__restrict__ src = reinterpret_cast<const E *>(a.packed) + start;
+  const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+  const int pad = a.pad_id;
+  for (int i = sub * 8; i < a.ld; i += tpr * 8) {
+    if (vec && i + 8 <= a.ld) {
+      int4 lo = make_int4(pad, pad, pad, pad), hi = lo;
+      if (i + 8 <= n) {
+        if (sizeof(E) == 2) {
+          const uint4 p = *reinterpret_cast<const uint4 *>(src + i);
+          lo = make_int4((int)(p.x & 0xFFFFu), (int)(p.x >> 16), (int)(p.y & 0xFFFFu), (int)(p.y >> 16));
+          hi = make_int4((int)(p.z & 0xFFFFu), (int)(p.z >> 16), (int)(p.w & 0xFFFFu), (int)(p.w >> 16));
+        } else {
+          lo = *reinterpret_cast<const int4 *>(src + i);
+          hi = *reinterpret_cast<const int4 *>(src + i + 4);
+        }
+      } else if (i < n) {
+        int32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = i + k < n ? (int32_t)src[i + k] : pad;
+        lo = make_int4(v[0], v[1], v[2], v[3]); hi = make_int4(v[4], v[5], v[6], v[7]);
+      }
+      *reinterpret_cast<int4 *>(row + i) = lo;
+      *reinterpret_cast<int4 *>(row + i + 4) = hi;
+    } else {
+      for (int k = i; k < a.ld && k < i + 8; ++k) row[k] = k < n ? (int32_t)src[k] : pad;
+    }
+  }
+}
+
+// gtok_collate over the packed form: one wave per batch row
+template <typename E>
+__global__ void __launch_bounds__(256) collate_packed_kernel(const void *__restrict__ packed, const int64_t *__restrict__ row_ptr,
+                                                             const int32_t *__restrict__ len, int ld,
+                                                             const int64_t *__restrict__ index, int batch, int pad_id,
+                                                             int64_t *__restrict__ out_x, uint8_t *__restrict__ out_attn,
+                                                             int out_ld) {
+  const int lane = lane_id();
+  const int b = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  if (b >= batch) return;
+  const int64_t src = index[b];
+  int n = len[src];
+  n = n < 0 ? 0 : (n > ld ? ld : n);
+  const E *__restrict__ row = reinterpret_cast<const E *>(packed) + row_ptr[src];
+  for (int i = lane; i < out_ld; i += kWave) {
+    const bool in = i < n;
+    out_x[(int64_t)b * out_ld + i] = in ? (int64_t)row[i] : (int64_t)pad_id;
+    out_attn[(int64_t)b * out_ld + i] = in ? 1 : 0;
+  }
+}
+
+static int tpr_shift_for(int ld) {
+  const int pieces = (ld + 7) / 8;
+  int s = 0;
+  while ((1 << s) < pieces && s < 6) ++s;
+  return s;
+}
+
+}  // namespace gtok
+
+using namespace gtok;
+
+extern "C" int gtok_row_offsets(const int32_t *len, int64_t num_rows, int32_t ld, int32_t align, int64_t *row_ptr,
+                                void *stream) {
+  DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (num_rows < 0 || ld <= 0 || align < 1 || (align & (align - 1)) || !row_ptr) return GTOK_E_INVAL;
+  if (num_rows > 0 && !len) return GTOK_E_INVAL;
+  const int64_t tiles = (num_rows + kScanTile - 1) / kScanTile;
+  if (tiles > 0x7FFFFFFF) return GTOK_E_TOO_LARGE;
+  hipStream_t s = (hipStream_t)stream;
+  if (tiles > 0)
+    hipLaunchKernelGGL(row_tile_sums_kernel, dim3((unsigned)tiles), dim3(kScanBlock), 0, s, len, num_rows, ld, align - 1, row_ptr);
+  hipLaunchKernelGGL(row_tile_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, num_rows, row_ptr);
+  if (tiles > 0)
+    hipLaunchKernelGGL(row_tile_fill_kernel, dim3((unsigned)tiles), dim3(kScanBlock), 0, s, len, num_rows, ld, align - 1, row_ptr);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+static int rows_launch(bool pack, const int32_t *ids, int32_t *out_ids, int32_t ld, const int32_t *len, int64_t num_rows,
+                       const int64_t *row_ptr, int32_t segment_rows, int64_t segment_stride, int32_t elem_bytes,
+                       void *packed, int64_t capacity, int32_t pad_id, int32_t *status, void *stream) {
+  DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (num_rows < 0 || ld <= 0 || (elem_bytes != 2 && elem_bytes != 4) || segment_stride < 0) return GTOK_E_INVAL;
+  if (num_rows == 0) return GTOK_OK;
+  if (!len || !row_ptr || !packed || (pack ? !ids : !out_ids) || (pack && !status) || capacity < 0) return GTOK_E_INVAL;
+  RowsArgs a;
+  a.ids = ids; a.out_ids = out_ids; a.len = len; a.row_ptr = row_ptr; a.packed = packed; a.status = status;
+  a.rows = num_rows; a.ld = ld; a.pad_id = pad_id; a.segment_rows = segment_rows; a.segment_stride = segment_stride; a.capacity = capacity;
+  a.tpr_shift = tpr_shift_for(ld);
+  const int rpb = 256 >> a.tpr_shift;
+  const int64_t nb = (num_rows + rpb - 1) / rpb;
+  if (nb > 0x7FFFFFFF) return GTOK_E_TOO_LARGE;
+  hipStream_t s = (hipStream_t)stream;
+  if (pack) {
+    if (elem_bytes == 2) hipLaunchKernelGGL(pack_rows_kernel<uint16_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pack_rows_kernel<int32_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
+  } else {
+    if (elem_bytes == 2) hipLaunchKernelGGL(unpack_rows_kernel<uint16_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(unpack_rows_kernel<int32_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
+  }
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_pack_rows(const int32_t *ids, int32_t ld, const int32_t *len, int64_t num_rows, const int64_t *row_ptr,
+                              int32_t elem_bytes, void *packed, int64_t capacity, int32_t *status, void *stream) {
+  return rows_launch(true, ids, nullptr, ld, len, num_rows, row_ptr, 0, 0, elem_bytes, packed, capacity, 0, status, stream);
+}
+
+extern "C" int gtok_unpack_rows(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
+                                int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int32_t pad_id,
+                                int32_t *out_ids, int32_t ld, void *stream) {
+  return rows_launch(false, nullptr, out_ids, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
+                     const_cast<void *>(packed), 0, pad_id, nullptr, stream);
+}
+
+extern "C" int gtok_collate_packed(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
+                                   int32_t ld, const int64_t *index, int32_t batch, int32_t pad_id, int64_t *out_x,
+                                   uint8_t *out_attn, int32_t out_ld, void *stream) {
+  DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (!packed || !row_ptr || !len || !index || ld <= 0 || batch < 0 || out_ld < 0 || (elem_bytes != 2 && elem_bytes != 4))
+    return GTOK_E_INVAL;
+  if (batch == 0 || out_ld == 0) return GTOK_OK;
+  if (!out_x || !out_attn) return GTOK_E_INVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (elem_bytes == 2)
+    hipLaunchKernelGGL(collate_packed_kernel<uint16_t>, dim3((batch + 3) / 4), dim3(256), 0, s, packed, row_ptr, len, ld, index,
+                       batch, pad_id, out_x, out_attn, out_ld);
+  else
+    hipLaunchKernelGGL(collate_packed_kernel<int32_t>, dim3((batch + 3) / 4), dim3(256), 0, s, packed, row_ptr, len, ld, index,
+                       batch, pad_id, out_x, out_attn, out_ld);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}

@@ -37,12 +37,22 @@ def shard_of(batch, rank: int = None, world: int = None):
     return batch.shard(lo, hi), lo, hi
 
 
-def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: int, force: bool = False):
+def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: int, force: bool = False,
+                  compact: bool = False, elem_bytes: int = 2, capacity: int = None, rows_impl=None, stats: dict = None):
     """All-gather the per-rank [G_local, ld] slabs + lengths into the full [G, ld] slab on every rank.
 
     Ranks hold blocks from block_bounds(); the last blocks may be short, so every rank pads its
     block to ceil(G/P) rows first (one fixed-size all_gather_into_tensor, no size exchange).
-    force: issue the collective even in a one-rank group (rehearsal of the N>1 path on a one-GPU box)."""
+    force: issue the collective even in a one-rank group (rehearsal of the N>1 path on a one-GPU box).
+
+    compact=True moves the PACKED form over the links instead of the padded slab (include/gtok.h, "packed rows"): every
+    rank packs its rows back to back at `elem_bytes` (2: every SENT / IBTT id fits 16 bits; 4 otherwise) per id
+    (gtok_pack_rows), the packed buffers - sized to the largest rank's total, one all_reduce(MAX) of an int, or to
+    `capacity` elements when the caller knows a bound - and the lengths are gathered, and every rank re-pads locally at
+    HBM speed (gtok_unpack_rows).  More than half of a ZINC slab is padding and ids are 32 bits wide there: 208 MB per
+    corpus become ~46 MB.  Same result as the padded path, bit for bit.  rows_impl: the module providing row_offsets /
+    pack_rows / unpack_rows (default: ops, i.e. the HIP kernels; the CPU tests of the collective pass the oracle's).
+    stats: a dict that receives the bytes each rank contributed to the collective."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return ids, ln
     world = dist.get_world_size()
@@ -52,10 +62,30 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
         fill = per - ids.shape[0]
         ids = torch.cat([ids, torch.full((fill, ld), pad_id, dtype=ids.dtype, device=ids.device)])
         ln = torch.cat([ln, torch.zeros(fill, dtype=ln.dtype, device=ln.device)])
-    all_ids = torch.empty((world * per, ld), dtype=ids.dtype, device=ids.device)
+    ids, ln = ids.contiguous(), ln.contiguous()
     all_ln = torch.empty((world * per,), dtype=ln.dtype, device=ln.device)
-    dist.all_gather_into_tensor(all_ids, ids.contiguous())
-    dist.all_gather_into_tensor(all_ln, ln.contiguous())
+    if not compact:
+        all_ids = torch.empty((world * per, ld), dtype=ids.dtype, device=ids.device)
+        dist.all_gather_into_tensor(all_ids, ids)
+        dist.all_gather_into_tensor(all_ln, ln)
+        if stats is not None:
+            stats.update(bytes_sent_per_rank=ids.numel() * ids.element_size() + ln.numel() * 4, compact=False)
+        return all_ids[:num_graphs], all_ln[:num_graphs]
+    if rows_impl is None:
+        from . import ops as rows_impl
+    row_ptr = rows_impl.row_offsets(ln, ld)
+    if capacity is None:
+        capacity = all_reduce_max_int(int(row_ptr[-1]), ids.device)
+    capacity = max(8, -(-int(capacity) // 8) * 8)           # keeps every rank's segment 16-byte aligned
+    packed, _ = rows_impl.pack_rows(ids, ln, row_ptr, elem_bytes, capacity=capacity)
+    all_packed = torch.empty(world * capacity, dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(all_packed.view(torch.uint8), packed.view(torch.uint8))   # bytes: every backend moves uint8
+    dist.all_gather_into_tensor(all_ln, ln)
+    all_ptr = rows_impl.row_offsets(all_ln, ld)
+    all_ids = rows_impl.unpack_rows(all_packed, all_ptr, all_ln, ld, pad_id, segment_rows=per, segment_stride=capacity)
+    if stats is not None:
+        stats.update(bytes_sent_per_rank=packed.numel() * packed.element_size() + ln.numel() * 4, compact=True,
+                     elem_bytes=elem_bytes, capacity=capacity)
     return all_ids[:num_graphs], all_ln[:num_graphs]
 
 

@@ -354,6 +354,84 @@ def collate(ids: torch.Tensor, ln: torch.Tensor, index: torch.Tensor, pad_id: in
 
 
 # ------------------------------------------------------------------------------------------------
+# packed (ragged) rows: the form token rows take when they leave the GPU (all-gather, D2H)
+# ------------------------------------------------------------------------------------------------
+ROW_ALIGN = 8      # ids: 16-byte aligned row starts at 2 bytes per id (the vector path of pack / unpack)
+
+
+def row_offsets(ln: torch.Tensor, ld: int, align: int = ROW_ALIGN) -> torch.Tensor:
+    """int64 [rows + 1]: row r of the packed form starts at element row_ptr[r] and holds min(len[r], ld) ids;
+    starts are multiples of `align` (gtok_row_offsets)."""
+    _need_gpu(ln, "row_offsets")
+    if ln.dtype != torch.int32 or not ln.is_contiguous():
+        raise ValueError("row_offsets expects a contiguous int32 length vector")
+    ptr = torch.empty(ln.numel() + 1, dtype=torch.int64, device=ln.device)
+    check(lib().gtok_row_offsets(ln.data_ptr(), ln.numel(), int(ld), int(align), ptr.data_ptr(), _stream(ln.device)),
+          "gtok_row_offsets")
+    return ptr
+
+
+def pack_rows(ids: torch.Tensor, ln: torch.Tensor, row_ptr: Optional[torch.Tensor] = None, elem_bytes: int = 2,
+              capacity: Optional[int] = None, align: int = ROW_ALIGN, check_status: bool = True):
+    """[rows, ld] int32 slab + lengths -> (packed, row_ptr): row r's ids back to back from packed[row_ptr[r]], int16
+    storage (ids 0..65535 kept as their 16 bits) or int32.  capacity: elements to allocate (an all-gather needs the
+    same size on every rank); default = exactly row_ptr[-1] (one host read).  Raises when elem_bytes == 2 and an id
+    needs more bits, or when `capacity` is too small; check_status=False hands the status tensor back instead
+    (packed, row_ptr, status) and leaves the host out of it."""
+    _need_gpu(ids, "pack_rows")
+    if ids.dtype != torch.int32 or ids.dim() != 2 or not ids.is_contiguous() or ln.dtype != torch.int32:
+        raise ValueError("pack_rows expects a contiguous int32 [rows, ld] slab and int32 lengths")
+    dev, (rows, ld) = ids.device, ids.shape
+    if int(ln.numel()) != rows:
+        raise ValueError("pack_rows: one length per row")
+    if row_ptr is None:
+        row_ptr = row_offsets(ln, ld, align)
+    cap = int(row_ptr[-1]) if capacity is None else int(capacity)
+    packed = torch.empty(max(cap, 1), dtype=torch.int16 if elem_bytes == 2 else torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().gtok_pack_rows(ids.data_ptr(), ld, ln.data_ptr(), rows, row_ptr.data_ptr(), elem_bytes, packed.data_ptr(),
+                               cap, status.data_ptr(), _stream(dev)), "gtok_pack_rows")
+    if not check_status:
+        return packed, row_ptr, status
+    st = int(status.item())
+    if st & 1:
+        raise _lib.GtokError("pack_rows: an id does not fit 16 bits; pack with elem_bytes=4")
+    if st & 2:
+        raise _lib.GtokError(f"pack_rows: capacity {cap} is too small for these rows")
+    return packed, row_ptr
+
+
+def unpack_rows(packed: torch.Tensor, row_ptr: torch.Tensor, ln: torch.Tensor, ld: int, pad_id: int,
+                segment_rows: int = 0, segment_stride: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """packed rows -> [rows, ld] int32 slab with pad_id behind every row (gtok_unpack_rows).  segment_rows /
+    segment_stride: the packed buffer is the concatenation of per-rank buffers (see include/gtok.h)."""
+    _need_gpu(packed, "unpack_rows")
+    dev, rows = packed.device, int(ln.numel())
+    eb = packed.element_size()
+    if eb not in (2, 4):
+        raise ValueError("unpack_rows expects int16 or int32 storage")
+    ids = torch.empty((rows, ld), dtype=torch.int32, device=dev) if out is None else out
+    check(lib().gtok_unpack_rows(packed.data_ptr(), eb, row_ptr.data_ptr(), ln.data_ptr(), rows, int(segment_rows),
+                                 int(segment_stride), int(pad_id), ids.data_ptr(), int(ld), _stream(dev)), "gtok_unpack_rows")
+    return ids
+
+
+def collate_packed(packed: torch.Tensor, row_ptr: torch.Tensor, ln: torch.Tensor, ld: int, index: torch.Tensor,
+                   pad_id: int, out_ld: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ops.collate over the packed form: rows `index` -> (X int64 [B, out_ld], attn bool [B, out_ld])."""
+    _need_gpu(packed, "collate_packed")
+    dev = packed.device
+    index = index.to(dev, dtype=torch.int64).contiguous()
+    B = int(index.numel())
+    X = torch.empty((B, out_ld), dtype=torch.int64, device=dev)
+    A = torch.empty((B, out_ld), dtype=torch.bool, device=dev)
+    check(lib().gtok_collate_packed(packed.data_ptr(), packed.element_size(), row_ptr.data_ptr(), ln.data_ptr(), int(ld),
+                                    index.data_ptr(), B, int(pad_id), X.data_ptr(), A.data_ptr(), int(out_ld), _stream(dev)),
+          "gtok_collate_packed")
+    return X, A
+
+
+# ------------------------------------------------------------------------------------------------
 # text -> ids (TokenDataset)
 # ------------------------------------------------------------------------------------------------
 NO_LABEL = -2 ** 31

@@ -23,6 +23,11 @@
  *                      (gather rows of a batch, pad to the batch max, bool mask)
  *   gtok_parse_graph_text  graph_token_dataset_autograph.py:14-158 (text -> edges, query, label)
  *   gtok_find_token    the `<q>` search of trainer/train_ibtt.py:88-103 on a collated batch
+ *   gtok_row_offsets / gtok_pack_rows / gtok_unpack_rows / gtok_collate_packed
+ *                      (no reference counterpart) the packed form of a token slab - rows back to back, 16 or 32
+ *                      bits per id - for the copies that leave the GPU: the all-gather that reassembles the rows of
+ *                      every rank in dataset order (val/test loaders, trainer/train_agtt.py:602-607) and the D2H
+ *                      copy behind TokenizedGraphDataset.__getitem__ (trainer/train_agtt.py:246-273)
  *   gtok_csr_pack8     (no reference counterpart) byte-packed mirror of the CSR index arrays of small-graph batches
  *   gtok_csr_adjbits   (no reference counterpart) adjacency bit-matrix mirror of batches of graphs with <= 256 nodes
  *   gtok_vocab_stats_text   the corpus pass of build_vocab_from_texts / the ZINC dynamic-token scan over arbitrary texts
@@ -268,6 +273,33 @@ int gtok_parse_graph_text(const uint8_t *bytes, const int64_t *text_ptr, int32_t
                           int32_t *num_nodes, int32_t *query_nodes, int32_t *label, int32_t *status,
                           void *stream);
 
+/* ---- packed (ragged) rows -------------------------------------------------------------------------------------
+ * The padded slab is the documented output of every tokenizer entry point; more than half of a ZINC slab is padding
+ * and every id fits 16 bits.  The packed form holds row r's n_r = min(len[r], ld) ids contiguously, `elem_bytes`
+ * (2 or 4) bytes each, from element row_ptr[r] of `packed`.
+ *
+ * gtok_row_offsets: row_ptr[0] = 0, row_ptr[r + 1] = row_ptr[r] + round_up(n_r, align) for r < num_rows (int64
+ * [num_rows + 1], align a power of two: 8 keeps every row start 16-byte aligned at 2 bytes per id - the fast path of
+ * pack / unpack - 1 packs tightly).  Three small launches, no workspace.
+ * gtok_pack_rows: slab -> packed, a buffer of `capacity` elements.  status[0] (zeroed by the caller) gets bit 0 when
+ * elem_bytes == 2 and an id does not fit 16 bits (pack again with elem_bytes == 4), bit 1 when capacity <
+ * row_ptr[num_rows] (rows that do not fit are skipped, nothing is written out of bounds).
+ * gtok_unpack_rows: packed -> [num_rows, ld] slab, pad_id behind every row.  segment_rows > 0: the packed buffer is
+ * the concatenation of equally sized segments - what an all-gather of per-rank buffers of segment_stride elements
+ * gives - rows [s * segment_rows, (s + 1) * segment_rows) live in segment s: row r starts at
+ * s * segment_stride + row_ptr[r] - row_ptr[s * segment_rows], with row_ptr = gtok_row_offsets over the gathered
+ * lengths (same align).
+ * gtok_collate_packed: gtok_collate reading the packed form (unsegmented) instead of the slab.                    */
+int gtok_row_offsets(const int32_t *len, int64_t num_rows, int32_t ld, int32_t align, int64_t *row_ptr, void *stream);
+int gtok_pack_rows(const int32_t *ids, int32_t ld, const int32_t *len, int64_t num_rows, const int64_t *row_ptr,
+                   int32_t elem_bytes, void *packed, int64_t capacity, int32_t *status, void *stream);
+int gtok_unpack_rows(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
+                     int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int32_t pad_id,
+                     int32_t *out_ids, int32_t ld, void *stream);
+int gtok_collate_packed(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
+                        int32_t ld, const int64_t *index, int32_t batch, int32_t pad_id, int64_t *out_x,
+                        uint8_t *out_attn, int32_t out_ld, void *stream);
+
 /* First position of `token` in every row of an int64 [rows, ld] batch (what gtok_collate
  * returns): pos[r] = the smallest i with x[r, i] == token, -1 if there is none.  This is the
  * per-sample `<q>` search of trainer/train_ibtt.py:88-103 and trainer/train_agtt.py:78-114 (the
@@ -329,8 +361,8 @@ const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_params *p);
 const char *gtok_ibtt_zinc_kernel_name(const gtok_csr *g);
 
 /* ABI version (GTOK_ABI_VERSION of the header the library was built from: 2 since gtok_csr carries the optional
- * mirrors - a binding checks it before passing structs) and build target string ("gfx950").                     */
-#define GTOK_ABI_VERSION 2
+ * mirrors - a binding checks it before passing structs; 3 adds the packed-row entry points) and build target string ("gfx950").                     */
+#define GTOK_ABI_VERSION 3
 int gtok_version(void);
 const char *gtok_target(void);
 

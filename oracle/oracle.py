@@ -325,3 +325,40 @@ def sent_decode(tokens, max_num_nodes, labeled=False, num_node_types=0):
         pending_et = None
         prev = k
     return nseen, edges, ntypes, etypes, i
+
+
+# ---- packed rows (include/gtok.h, "packed (ragged) rows"): numpy restatement of the format itself ----------------
+def row_offsets(ln, ld, align=8):
+    n = np.clip(np.asarray(ln, np.int64), 0, ld)
+    cost = (n + align - 1) // align * align
+    ptr = np.zeros(n.size + 1, np.int64)
+    np.cumsum(cost, out=ptr[1:])
+    return ptr
+
+
+def pack_rows(ids, ln, ld=None, elem_bytes=2, align=8, capacity=None, fill=0):
+    """(packed, row_ptr): row r's min(len, ld) ids from packed[row_ptr[r]]; slots between rows hold `fill`
+    (the product leaves them unwritten: compare through unpack_rows or row by row)."""
+    ids = np.asarray(ids, np.int32)
+    ld = ids.shape[1] if ld is None else ld
+    ptr = row_offsets(ln, ld, align)
+    dt = np.uint16 if elem_bytes == 2 else np.int32
+    if elem_bytes == 2 and ids.size and any(((ids[r, :min(max(int(l), 0), ld)] >> 16) != 0).any() for r, l in enumerate(ln)):
+        raise ValueError("an id does not fit 16 bits")
+    packed = np.full(int(ptr[-1]) if capacity is None else capacity, fill, dt)
+    for r, l in enumerate(np.clip(np.asarray(ln, np.int64), 0, ld)):
+        packed[ptr[r]:ptr[r] + l] = ids[r, :l].astype(dt)
+    return packed, ptr
+
+
+def unpack_rows(packed, row_ptr, ln, ld, pad_id, segment_rows=0, segment_stride=0):
+    ln = np.asarray(ln, np.int64)
+    out = np.full((ln.size, ld), pad_id, np.int32)
+    for r, l in enumerate(np.clip(ln, 0, ld)):
+        if segment_rows > 0:
+            s = r // segment_rows
+            start = s * segment_stride + row_ptr[r] - row_ptr[s * segment_rows]
+        else:
+            start = row_ptr[r]
+        out[r, :l] = packed[start:start + l].astype(np.int64)
+    return out

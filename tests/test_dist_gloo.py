@@ -16,6 +16,27 @@ def _free_port():
     return p
 
 
+class _OracleRows:
+    """rows_impl for dist.gather_tokens on CPU tensors: the oracle's numpy statement of the packed format (the product's
+    implementation is the HIP kernels; the collective logic around them is what this test covers)."""
+
+    @staticmethod
+    def row_offsets(ln, ld, align=8):
+        return torch.from_numpy(orc.row_offsets(ln.numpy(), ld, align))
+
+    @staticmethod
+    def pack_rows(ids, ln, row_ptr, elem_bytes=2, capacity=None):
+        packed, ptr = orc.pack_rows(ids.numpy(), ln.numpy(), ids.shape[1], elem_bytes, capacity=capacity, fill=0x7ABC)
+        assert np.array_equal(ptr, row_ptr.numpy())
+        return torch.from_numpy(packed.view(np.int16) if elem_bytes == 2 else packed), row_ptr
+
+    @staticmethod
+    def unpack_rows(packed, row_ptr, ln, ld, pad_id, segment_rows=0, segment_stride=0):
+        p = packed.numpy()
+        p = p.view(np.uint16) if p.dtype == np.int16 else p
+        return torch.from_numpy(orc.unpack_rows(p, row_ptr.numpy(), ln.numpy(), ld, pad_id, segment_rows, segment_stride))
+
+
 def _worker(rank, world, port, G, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -31,6 +52,13 @@ def _worker(rank, world, port, G, q):
         ref_ids, ref_ln = orc.sent(coo, int(coo.node_counts.max()), 1024, 11, 2, ld=160, **kw)
         ok = (max_nodes == int(coo.node_counts.max()) and tuple(full_ids.shape) == (G, 160)
               and np.array_equal(full_ids.numpy(), ref_ids) and np.array_equal(full_ln.numpy(), ref_ln))
+        # the compact exchange (packed 16-bit rows + lengths, re-padded locally) gives the same slab, at both widths
+        for eb in (2, 4):
+            st = {}
+            c_ids, c_ln = gtok.dist.gather_tokens(torch.from_numpy(ids), torch.from_numpy(ln), G, 5, compact=True,
+                                                  elem_bytes=eb, rows_impl=_OracleRows, stats=st)
+            ok = ok and torch.equal(c_ids, full_ids) and torch.equal(c_ln, full_ln) and st["compact"] \
+                and st["bytes_sent_per_rank"] < ids.size * 4 * (0.4 if eb == 2 else 0.7)
         # corpus-wide vocab statistics from per-rank tables (SUM / MIN all-reduce)
         s = gtok.synth.graph_token_like(G, seed=78, with_text=False)
         sc = orc.Coo(s["node_counts"], s["edge_counts"], s["src"], s["dst"])
@@ -39,6 +67,10 @@ def _worker(rank, world, port, G, q):
         wc, wf = orc.vocab_stats_synth(sc, 64)
         ok = ok and np.array_equal(c.numpy(), wc) and np.array_equal(f.numpy(), wf)
         q.put((rank, bool(ok)))
+    except Exception:                       # report instead of leaving the parent to time out
+        import traceback
+        traceback.print_exc()
+        q.put((rank, False))
     finally:
         dist.destroy_process_group()
 

@@ -1,0 +1,131 @@
+"""GPU: the packed-row format (gtok_row_offsets / gtok_pack_rows / gtok_unpack_rows / gtok_collate_packed) against the
+oracle's numpy statement of it, and the compact all-gather built on it (real one-rank RCCL group + the segmented layout
+of a 4-rank gather rehearsed on one device)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import both, gtok, orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _slab(rows, ld, seed, max_id=300, long_rows=False):
+    rng = np.random.default_rng(seed)
+    ln = rng.integers(0, ld + 1, rows).astype(np.int32)
+    if long_rows:                       # lengths beyond the slab width: the packed row holds the first ld ids
+        ln[rng.integers(0, rows, max(1, rows // 7))] += ld
+    ln[rng.integers(0, rows, max(1, rows // 9))] = 0
+    ids = rng.integers(0, max_id, (rows, ld)).astype(np.int32)
+    return ids, ln
+
+
+@pytest.mark.parametrize("rows,ld", [(1, 16), (7, 4), (4097, 48), (10000, 208), (513, 1024), (300, 13)])
+@pytest.mark.parametrize("align", [8, 1])
+def test_row_offsets_pack_unpack_roundtrip(rows, ld, align):
+    ids, ln = _slab(rows, ld, seed=rows + ld, long_rows=True)
+    d_ids, d_ln = torch.from_numpy(ids).to(DEV), torch.from_numpy(ln).to(DEV)
+    ptr = gtok.ops.row_offsets(d_ln, ld, align)
+    assert np.array_equal(ptr.cpu().numpy(), orc.row_offsets(ln, ld, align))
+    for eb in (2, 4):
+        packed, p2 = gtok.ops.pack_rows(d_ids, d_ln, ptr, elem_bytes=eb)
+        ref, rptr = orc.pack_rows(ids, ln, ld, eb, align)
+        got = packed.cpu().numpy()
+        got = got.view(np.uint16) if eb == 2 else got
+        n = np.clip(ln, 0, ld)
+        for r in range(rows):           # the slots between rows are not written: compare row by row
+            assert np.array_equal(got[rptr[r]:rptr[r] + n[r]], ref[rptr[r]:rptr[r] + n[r]]), (r, eb)
+        back = gtok.ops.unpack_rows(packed, ptr, d_ln, ld, pad_id=5)
+        want = orc.unpack_rows(ref, rptr, ln, ld, 5)
+        assert np.array_equal(back.cpu().numpy(), want)
+        keep = np.arange(ld)[None, :] < n[:, None]
+        assert np.array_equal(np.where(keep, ids, 5), want)          # = the slab with its tails re-padded
+
+
+def test_pack_rows_flags_wide_ids_and_small_buffers():
+    ids, ln = _slab(2000, 64, seed=3)
+    ids[1234, 0] = 70000
+    ln[1234] = max(ln[1234], 1)
+    d_ids, d_ln = torch.from_numpy(ids).to(DEV), torch.from_numpy(ln).to(DEV)
+    with pytest.raises(gtok.GtokError, match="16 bits"):
+        gtok.ops.pack_rows(d_ids, d_ln, elem_bytes=2)
+    packed, ptr = gtok.ops.pack_rows(d_ids, d_ln, elem_bytes=4)
+    assert np.array_equal(gtok.ops.unpack_rows(packed, ptr, d_ln, 64, 0).cpu().numpy(),
+                          orc.unpack_rows(*orc.pack_rows(ids, ln, 64, 4), ln, 64, 0))
+    with pytest.raises(gtok.GtokError, match="capacity"):
+        gtok.ops.pack_rows(d_ids, d_ln, elem_bytes=4, capacity=int(ptr[-1]) - 8)
+    # empty inputs are no-ops
+    e_ids, e_ln = torch.empty((0, 16), dtype=torch.int32, device=DEV), torch.empty(0, dtype=torch.int32, device=DEV)
+    p, q = gtok.ops.pack_rows(e_ids, e_ln)
+    assert q.tolist() == [0] and gtok.ops.unpack_rows(p, q, e_ln, 16, 5).shape == (0, 16)
+
+
+def test_collate_packed_equals_collate_on_the_slab():
+    d = gtok.synth.zinc_like(3000, seed=12)
+    batch, coo = both(d)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ids, ln = gtok.ops.sent(batch.to(DEV), 37, 1024, 4, 1, **kw)
+    packed, ptr = gtok.ops.pack_rows(ids, ln)
+    idx = torch.randperm(3000, generator=torch.Generator().manual_seed(1))[:128]
+    out_ld = int(ln.cpu()[idx].max())
+    X, A = gtok.ops.collate(ids, ln, idx, 5, out_ld)
+    Xp, Ap = gtok.ops.collate_packed(packed, ptr, ln, ids.shape[1], idx, 5, out_ld)
+    assert torch.equal(X, Xp) and torch.equal(A, Ap)
+    ref, rln = orc.sent(coo, 37, 1024, 4, 1, ld=ids.shape[1], **kw)
+    RX, RA, _ = orc.collate(ref, rln, idx.numpy(), 5, out_ld)
+    assert np.array_equal(Xp.cpu().numpy(), RX) and np.array_equal(Ap.cpu().numpy(), RA)
+
+
+def test_segmented_unpack_is_the_layout_of_a_four_rank_gather():
+    """What dist.gather_tokens(compact=True) does on 4 ranks, on one device: every block packed into its own
+    capacity-sized segment, segments concatenated, one row_offsets over all lengths, one segmented unpack."""
+    ids, ln = _slab(1001, 96, seed=8)
+    world, per = 4, -(-1001 // 4)
+    d_ids, d_ln = torch.from_numpy(ids).to(DEV), torch.from_numpy(ln).to(DEV)
+    parts, lens, totals = [], [], []
+    for r in range(world):
+        lo, hi = gtok.dist.block_bounds(1001, world)[r]
+        bi, bl = d_ids[lo:hi].contiguous(), d_ln[lo:hi].contiguous()
+        if hi - lo < per:
+            bi = torch.cat([bi, torch.full((per - (hi - lo), 96), 5, dtype=torch.int32, device=DEV)])
+            bl = torch.cat([bl, torch.zeros(per - (hi - lo), dtype=torch.int32, device=DEV)])
+        parts.append((bi, bl)); lens.append(bl)
+        totals.append(int(gtok.ops.row_offsets(bl, 96)[-1]))
+    cap = -(-max(totals) // 8) * 8
+    segs = [gtok.ops.pack_rows(bi, bl, capacity=cap)[0] for bi, bl in parts]
+    all_packed, all_ln = torch.cat(segs), torch.cat(lens)
+    out = gtok.ops.unpack_rows(all_packed, gtok.ops.row_offsets(all_ln, 96), all_ln, 96, 5, segment_rows=per, segment_stride=cap)
+    keep = np.arange(96)[None, :] < ln[:, None]
+    assert np.array_equal(out[:1001].cpu().numpy(), np.where(keep, ids, 5))
+
+
+def test_compact_gather_over_rccl_equals_padded_gather():
+    """dist.gather_tokens(compact=True) through a real one-rank `nccl` (RCCL) group: packed 16-bit rows + lengths over
+    the collective, re-padded locally; equal to the padded exchange and to the oracle, at a fraction of the bytes."""
+    import socket
+    import torch.distributed as tdist
+    d = gtok.synth.zinc_like(30001, seed=92)
+    batch, coo = both(d)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ld = gtok.ops.sent_safe_ld(batch, True, 1024)
+    ids, ln = gtok.ops.sent(batch.to(DEV), 37, 1024, 21, 3, ld=ld, **kw)
+    ref, rln = orc.sent(coo, 37, 1024, 21, 3, ld=ld, nthreads=8, **kw)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        sp, sc = {}, {}
+        p_ids, p_ln = gtok.dist.gather_tokens(ids, ln, 30001, 5, force=True, stats=sp)
+        c_ids, c_ln = gtok.dist.gather_tokens(ids, ln, 30001, 5, force=True, compact=True, stats=sc)
+        assert c_ids.data_ptr() != ids.data_ptr()
+        assert torch.equal(c_ids, p_ids) and torch.equal(c_ln, p_ln)
+        assert np.array_equal(c_ids.cpu().numpy(), ref) and np.array_equal(c_ln.cpu().numpy(), rln)
+        assert sc["bytes_sent_per_rank"] < 0.3 * sp["bytes_sent_per_rank"]
+        # a caller-given capacity skips the size exchange
+        k_ids, _ = gtok.dist.gather_tokens(ids, ln, 30001, 5, force=True, compact=True, capacity=sc["capacity"] + 64)
+        assert torch.equal(k_ids, p_ids)
+    finally:
+        tdist.destroy_process_group()
