@@ -9,7 +9,7 @@ from . import _lib  # noqa: F401
 from ._lib import GtokError, build, lib  # noqa: F401
 from . import csr  # noqa: F401
 from .csr import GraphBatch  # noqa: F401
-from . import ops, dist, synth  # noqa: F401,E401
+from . import ops, dist, synth, rows  # noqa: F401,E401
 from . import torch_ops  # noqa: F401  (registers torch.ops.gtok.*)
 from . import graph_data_loader  # noqa: F401  (needs ops / GraphBatch above)
 from . import agtt  # noqa: F401

@@ -13,6 +13,8 @@ import torch
 from torch.utils.data import Dataset
 
 from . import ops as _ops
+from . import rows as _rows
+from . import csr as _csr
 from .csr import GraphBatch
 from .graph_data_loader.zinc_vocab import build_fixed_zinc_vocab
 
@@ -30,9 +32,10 @@ class TokenizedGraphDataset(Dataset):
         self._device = device
         self._batch: Optional[GraphBatch] = None
         self._query = None
+        self._mixed_query = False
         self._epoch = -1
-        self._served: Optional[np.ndarray] = None
-        self._ids = self._lens = self._ids_h = self._lens_h = None
+        self._rows = None                      # rows.EpochRows: the host view __getitem__ serves from
+        self._ids = self._lens = None
 
     def __len__(self):
         return len(self.pyg_dataset)
@@ -44,26 +47,37 @@ class TokenizedGraphDataset(Dataset):
         return torch.device(self._device)
 
     def _graphs(self) -> GraphBatch:
+        """The split as a device-resident batch, built once: from the dataset's own `graph_batch()` (this package's
+        dataset classes: collated storage, no per-item work) or from whatever storage / items it exposes."""
         if self._batch is None:
-            items = [self.pyg_dataset[i] for i in range(len(self))]
-            gb = getattr(self.pyg_dataset, "graph_batch", None)
-            host = gb() if callable(gb) else GraphBatch.from_data_list(items, labeled=self.tokenizer.labeled_graph)
-            self._batch = host.to(self._dev())
-            if self.task == "shortest_path" and items and all(hasattr(d, "query_u") and hasattr(d, "query_v") for d in items):
-                self._query = torch.tensor([[d.query_u, d.query_v] for d in items], dtype=torch.int32)
-            self._mixed_query = self.task == "shortest_path" and self._query is None and \
-                any(hasattr(d, "query_u") and hasattr(d, "query_v") for d in items)
+            ds = self.pyg_dataset
+            gb = getattr(ds, "graph_batch", None)
+            if callable(gb):
+                self._batch = gb(device=self._dev(), labeled=self.tokenizer.labeled_graph)
+            else:
+                self._batch = GraphBatch.from_dataset(ds, labeled=self.tokenizer.labeled_graph, device=self._dev())
+            if self.task == "shortest_path":
+                q = getattr(ds, "queries", None)
+                q = q() if callable(q) else None
+                if q is not None:
+                    self._query = torch.as_tensor(q, dtype=torch.int32)
+                else:
+                    items = [ds[i] for i in range(len(self))]
+                    has = [hasattr(d, "query_u") and hasattr(d, "query_v") for d in items]
+                    if items and all(has):
+                        self._query = torch.tensor([[d.query_u, d.query_v] for d in items], dtype=torch.int32)
+                    self._mixed_query = any(has) and not all(has)
         return self._batch
 
-    def tokenize_epoch(self, epoch: int):
-        """(ids int32 [G, ld], len int32 [G]) on the device for `epoch`; also what __getitem__ serves from."""
+    def tokenize_epoch(self, epoch: int, pad: bool = True):
+        """(ids int32 [G, ld], len int32 [G]) on the device for `epoch`.  pad=True (default): the documented slab,
+        pad id 5 behind every row.  pad=False: rows are only written up to their length (rounded up to 16 ids) and
+        the rest of the slab is UNINITIALISED - for readers that go through `len` (gtok_collate, gtok_pack_rows:
+        what __getitem__ and device_batches use), never for code that consumes the slab whole."""
         batch = self._graphs()
-        # every reader of the slab goes through the lengths (items are cut at len, gtok_collate pads per batch as the
-        # reference's collate_fn does): the pad tails - more than half of a ZINC slab - are not written
         self._ids, self._lens = self.tokenizer.tokenize_batch(batch, epoch=epoch, remap_zinc=self.remap_to_fixed_vocab,
-                                                              query=self._query, pad=False)
-        self._epoch, self._ids_h, self._lens_h = epoch, None, None
-        self._served = np.zeros(len(self), bool)
+                                                              query=self._query, pad=pad)
+        self._epoch, self._rows = epoch, None
         return self._ids, self._lens
 
     def remap_zinc_tokens(self, tokens: torch.Tensor, data=None) -> torch.Tensor:
@@ -90,12 +104,11 @@ class TokenizedGraphDataset(Dataset):
                                      "DataLoader(num_workers=0), as the reference's AGTT configs do")
             self._graphs()
         if self._batched and not self._mixed_query:
-            if self._served is None or self._served[idx]:       # fetched again -> a new random trail
-                self.tokenize_epoch(self._epoch + 1)
-            if self._ids_h is None:
-                self._ids_h, self._lens_h = self._ids.cpu(), self._lens.cpu()
-            self._served[idx] = True
-            tokens = self._ids_h[idx, :int(self._lens_h[idx])].to(torch.long)
+            tokens = self._rows.take(idx) if self._rows is not None else None
+            if tokens is None:                                  # first fetch, or fetched again -> a new random trail
+                ids, lens = self.tokenize_epoch(self._epoch + 1, pad=False)
+                self._rows = _rows.EpochRows(ids, lens, self._epoch)     # ONE packed D2H copy per epoch
+                tokens = self._rows.take(idx)
         else:                                                   # any tokenizer object: per-item call
             tokens = self.tokenizer(data)
             if self.remap_to_fixed_vocab:
@@ -108,18 +121,25 @@ class TokenizedGraphDataset(Dataset):
     def device_batches(self, batch_size: int, epoch: int, shuffle: bool = False,
                        generator: Optional[torch.Generator] = None):
         """Yield collate_fn's tuple with X/attn/labels on the device (gtok_collate over the epoch's slab)."""
-        ids, lens = self.tokenize_epoch(epoch)
+        ids, lens = self.tokenize_epoch(epoch, pad=False)
         n = len(self)
-        items = [self.pyg_dataset[i] for i in range(n)]
-        labels = [d.y.item() for d in items]
-        is_float = n > 0 and isinstance(labels[0], float)
-        y = torch.tensor(labels, dtype=torch.float if is_float else torch.long, device=ids.device)
+        ds = self.pyg_dataset
+        got = _csr.collated_storage(ds) or _csr.collated_storage(getattr(ds, "zinc_dataset", None))
+        if got is not None and got["y"] is not None:            # labels from the collated storage: no item is touched
+            yv = torch.as_tensor(got["y"]).reshape(-1)
+            if got["indices"] is not None:
+                yv = yv[torch.as_tensor(got["indices"], dtype=torch.int64)]
+            y = yv.to(torch.float if yv.is_floating_point() else torch.long).to(ids.device)
+        else:
+            labels = [ds[i].y.item() for i in range(n)]
+            is_float = n > 0 and isinstance(labels[0], float)
+            y = torch.tensor(labels, dtype=torch.float if is_float else torch.long, device=ids.device)
         lens_h = lens.cpu()
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
         for s in range(0, n, batch_size):
             idx = order[s:s + batch_size]
             X, A = _ops.collate(ids, lens, idx, PAD, int(lens_h[idx].max()))
-            yield X, A, y[idx.to(ids.device)], [items[i] for i in idx.tolist()]
+            yield X, A, y[idx.to(ids.device)], [ds[i] for i in idx.tolist()]
 
 
 def collate_fn(batch):

@@ -14,6 +14,7 @@ import torch
 import importlib
 import os
 import sys
+import weakref
 
 _PKG_DIR = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 if os.path.basename(_PKG_DIR) in sys.modules:
@@ -21,7 +22,7 @@ if os.path.basename(_PKG_DIR) in sys.modules:
 else:
     sys.path.insert(0, os.path.dirname(_PKG_DIR))
     _pkg = importlib.import_module(os.path.basename(_PKG_DIR))
-_ops, GtokError, GraphBatch = _pkg.ops, _pkg.GtokError, _pkg.GraphBatch
+_ops, _rows, GtokError, GraphBatch = _pkg.ops, _pkg.rows, _pkg.GtokError, _pkg.GraphBatch
 
 
 class Graph2TrailTokenizer:
@@ -47,6 +48,8 @@ class Graph2TrailTokenizer:
         self.seed = seed
         self.device = device
         self._calls = 0
+        self.launches = 0                        # gtok_sent launches issued so far (tests / bench read it)
+        self._splits = weakref.WeakKeyDictionary()    # dataset -> _Split: the split's resident CSR and its current epoch
 
     # ---- configuration (same call order as train_agtt.py:534-540)
     def set_num_nodes(self, max_num_nodes: int) -> None:
@@ -82,15 +85,56 @@ class Graph2TrailTokenizer:
         pad=False: rows are only written up to their length (consumers that read through `len`: ops.collate)."""
         if self.max_num_nodes is None:
             raise RuntimeError("call set_num_nodes() first")
+        self.launches += 1
         return _ops.sent(batch, self.max_num_nodes, self._max_len(), self.seed, epoch, labeled=self.labeled_graph,
                          num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
                          remap_zinc=remap_zinc, pad_id=self.pad, graph_base=graph_base, query=query, ld=ld, out=out, pad=pad)
 
     # ---- reference call site: one Data in, one 1-D LongTensor out, a fresh random trail per call
+    def _signature(self):
+        return (self.max_num_nodes, self.labeled_graph, self.num_node_types, self.num_edge_types, self._max_len(), self.seed)
+
+    def _serve(self, owner, idx: int):
+        """Row `idx` of the item's split.  The split is tokenized as a whole - ONE launch per epoch - the first time an
+        item of it is asked for and again whenever an item is asked for a second time (in the reference every fetch
+        is a new random trail: a second fetch of an item is the next epoch)."""
+        sp = self._splits.get(owner)
+        if sp is None or sp.signature != self._signature() or sp.batch.num_graphs != len(owner):
+            gb = getattr(owner, "graph_batch", None)
+            if not callable(gb):
+                return None
+            sp = _Split(gb(device=self._device(), labeled=self.labeled_graph), self._signature())
+            self._splits[owner] = sp
+        if not 0 <= idx < sp.batch.num_graphs:
+            return None
+        row = sp.rows.take(idx) if sp.rows is not None else None
+        if row is None:
+            sp.epoch += 1
+            ids, ln = self.tokenize_batch(sp.batch, epoch=sp.epoch, pad=False)
+            sp.rows = _rows.EpochRows(ids, ln, sp.epoch)
+            row = sp.rows.take(idx)
+        return row
+
     def tokenize(self, data) -> torch.Tensor:
+        """`tokens = tokenizer(data)` (trainer/train_agtt.py:250).  An item that came out of one of this package's
+        dataset classes (they mark what they return: rows.tag_item) is served from its split's epoch - one launch
+        per split and epoch however the items are fetched; any other object is tokenized on its own (one small
+        launch per call)."""
+        src = _rows.item_source(data)
+        if src is not None:
+            row = self._serve(*src)
+            if row is not None:
+                return row
         batch = GraphBatch.from_data_list([data], labeled=self.labeled_graph).to(self._device())
         ids, ln = self.tokenize_batch(batch, epoch=0, graph_base=self._calls)
         self._calls += 1
         return ids[0, :int(ln[0])].to(torch.long).cpu()
 
     __call__ = tokenize
+
+
+class _Split:
+    __slots__ = ("batch", "signature", "epoch", "rows")
+
+    def __init__(self, batch, signature):
+        self.batch, self.signature, self.epoch, self.rows = batch, signature, -1, None

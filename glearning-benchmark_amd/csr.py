@@ -256,27 +256,161 @@ class GraphBatch:
                           nattr, eattr, flags, chunk_max(nc), chunk_max(ec), int(cnt.max()) if N else 0)
 
     @staticmethod
+    def from_collated(node_counts, edge_index, edge_slices, x=None, edge_attr=None, indices=None, device=None,
+                      check_symmetric: bool = True) -> "GraphBatch":
+        """From COLLATED storage - the form torch_geometric's InMemoryDataset keeps a split in (`data, slices` of
+        graph_token_dataset_autograph.py:407-408; torch_geometric.datasets.ZINC behind zinc_dataset_autograph.py:44
+        and zinc_dataset_indexbase.py:79): `edge_index` [2, sum E] with LOCAL node ids (collate does not increment
+        them), `edge_slices` [G+1] the per-graph offsets into it, `node_counts` [G], optional `x` [sum N(, 1)] and
+        `edge_attr` [sum E(, 1)] concatenated the same way.  No per-graph Python: the whole split is a handful of
+        array operations (on `device` when given: from_coo_device).  indices: the graphs to take, in order (a
+        dataset subset, `dataset.indices()`); None = all."""
+        t = lambda a: None if a is None else torch.as_tensor(a)
+        nc, es, ei = t(node_counts).reshape(-1).to(torch.int64), t(edge_slices).reshape(-1).to(torch.int64), t(edge_index)
+        if ei.dim() != 2 or ei.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E]")
+        if es.numel() != nc.numel() + 1:
+            raise ValueError("edge_slices must have one more entry than node_counts")
+        ec = es[1:] - es[:-1]
+        xa = None if x is None else t(x).reshape(t(x).shape[0], -1)[:, 0]
+        ea = None if edge_attr is None else t(edge_attr).reshape(-1)
+        src, dst = ei[0], ei[1]
+        if indices is not None:
+            idx = torch.as_tensor(list(indices) if not torch.is_tensor(indices) else indices, dtype=torch.int64).reshape(-1)
+            nptr = torch.zeros(nc.numel() + 1, dtype=torch.int64); torch.cumsum(nc, 0, out=nptr[1:])
+            nsel, esel = nc[idx], ec[idx]
+            ar = lambda n: torch.arange(n, dtype=torch.int64)
+            pick = lambda starts, counts: torch.repeat_interleave(starts - (torch.cumsum(counts, 0) - counts), counts) + ar(int(counts.sum()))
+            e_take, n_take = pick(es[:-1][idx], esel), pick(nptr[:-1][idx], nsel)
+            src, dst = src[e_take], dst[e_take]
+            xa = None if xa is None else xa[n_take]
+            ea = None if ea is None else ea[e_take]
+            nc, ec = nsel, esel
+        elif int(es[0]) != 0 or int(es[-1]) != src.numel():
+            raise ValueError("edge_slices does not cover edge_index")
+        if device is not None and torch.device(device).type == "cuda":
+            return GraphBatch.from_coo_device(nc, ec, src, dst, xa, ea, device=device, check_symmetric=check_symmetric)
+        return GraphBatch.from_coo(nc.numpy(), ec.numpy(), src.numpy(), dst.numpy(), None if xa is None else xa.numpy(),
+                                   None if ea is None else ea.numpy(), check_symmetric=check_symmetric)
+
+    @staticmethod
+    def from_dataset(dataset, labeled: Optional[bool] = None, device=None) -> "GraphBatch":
+        """The whole split behind a dataset object as one batch.  Collated storage (see from_collated) is read
+        directly when the dataset exposes it the way torch_geometric's InMemoryDataset does - `_data` / `data` with
+        `slices`, optional `_indices`, no `transform` - or through a `collated()` method (this package's datasets);
+        otherwise the items are fetched one by one (from_data_list)."""
+        got = collated_storage(dataset)
+        if got is not None:
+            if labeled is None:
+                labeled = got["x"] is not None and got["edge_attr"] is not None
+            return GraphBatch.from_collated(got["node_counts"], got["edge_index"], got["edge_slices"],
+                                            got["x"] if labeled else None, got["edge_attr"] if labeled else None,
+                                            indices=got["indices"], device=device)
+        b = GraphBatch.from_data_list([dataset[i] for i in range(len(dataset))], labeled=labeled)
+        return b if device is None else b.to(device)
+
+    @staticmethod
     def from_data_list(data_list: Sequence, labeled: Optional[bool] = None) -> "GraphBatch":
-        """From PyG-like objects exposing edge_index [2,E], num_nodes (or x), and optionally x / edge_attr."""
-        ncs, ecs, srcs, dsts, xs, eas = [], [], [], [], [], []
+        """From PyG-like objects exposing edge_index [2,E], num_nodes (or x), and optionally x / edge_attr.  The
+        per-item work is attribute access only; the arrays are concatenated once."""
         if labeled is None:
             labeled = len(data_list) > 0 and getattr(data_list[0], "x", None) is not None \
                 and getattr(data_list[0], "edge_attr", None) is not None
-        for d in data_list:
-            ei = np.asarray(d.edge_index, dtype=np.int64).reshape(2, -1)
-            x = getattr(d, "x", None)
+        if not len(data_list):
+            z = np.zeros(0, np.int64)
+            return GraphBatch.from_coo(z, z, z, z, z if labeled else None, z if labeled else None)
+        eis = [d.edge_index for d in data_list]
+        tens = all(map(torch.is_tensor, eis))
+        if tens:
+            try:                                   # the common case: every edge_index is already [2, E_g]
+                ei = torch.cat(eis, dim=1)
+                if ei.dim() != 2 or ei.shape[0] != 2:
+                    raise RuntimeError
+            except RuntimeError:
+                eis = [e.reshape(2, -1) for e in eis]
+                ei = torch.cat(eis, dim=1)
+            ecs = np.fromiter((e.shape[-1] for e in eis), np.int64, len(eis))
+            ei = ei.to(torch.int64).numpy()
+        else:
+            eis = [np.asarray(e, dtype=np.int64).reshape(2, -1) for e in eis]
+            ecs = np.fromiter((e.shape[1] for e in eis), np.int64, len(eis))
+            ei = np.concatenate(eis, axis=1)
+
+        def count(d):
             n = getattr(d, "num_nodes", None)
-            if n is None:
-                n = int(np.asarray(x).shape[0])
-            ncs.append(int(n)); ecs.append(ei.shape[1]); srcs.append(ei[0]); dsts.append(ei[1])
-            if labeled:
-                xa = np.asarray(x, dtype=np.int64)
-                xs.append(xa.reshape(xa.shape[0], -1)[:, 0] if xa.size else xa.reshape(-1))
-                ea = np.asarray(d.edge_attr, dtype=np.int64).reshape(-1)
-                # zinc_dataset_indexbase.py:183: edges past len(bond_types) read as 'unknown'
-                if ea.size < ei.shape[1]:
-                    ea = np.concatenate([ea, np.zeros(ei.shape[1] - ea.size, np.int64)])
-                eas.append(ea[:ei.shape[1]])
-        cat = lambda l: np.concatenate(l) if l else np.zeros(0, np.int64)
-        return GraphBatch.from_coo(ncs, ecs, cat(srcs), cat(dsts), cat(xs) if labeled else None,
-                                   cat(eas) if labeled else None)
+            return int(n) if n is not None else int(d.x.shape[0])
+        ncs = np.fromiter(map(count, data_list), np.int64, len(data_list))
+        xs = eas = None
+        if labeled:
+            def cat_first_column(parts):           # [n] or [n, k] per item -> column 0, concatenated
+                if all(map(torch.is_tensor, parts)):
+                    try:
+                        c = torch.cat(parts)
+                    except RuntimeError:           # ranks differ from item to item
+                        c = torch.cat([p.reshape(p.shape[0], -1)[:, :1] if p.dim() > 1 and p.numel() else p.reshape(-1, 1) for p in parts])
+                    return (c.reshape(c.shape[0], -1)[:, 0] if c.dim() > 1 else c).to(torch.int64).numpy()
+                first = lambda a: a[:, 0] if a.ndim > 1 and a.shape[1] > 0 else a.reshape(-1)[:a.shape[0] if a.ndim else 1]
+                return np.concatenate([first(np.asarray(p, dtype=np.int64)) for p in parts])
+            xs = cat_first_column([d.x for d in data_list])
+            ea_parts = [d.edge_attr for d in data_list]
+            ea_tens = all(map(torch.is_tensor, ea_parts))
+            ea_len = np.fromiter((p.numel() if torch.is_tensor(p) else np.size(p) for p in ea_parts), np.int64, len(ea_parts))
+            if np.array_equal(ea_len, ecs):
+                if ea_tens:
+                    try:
+                        eas = torch.cat(ea_parts).reshape(-1).to(torch.int64).numpy()
+                    except RuntimeError:
+                        eas = torch.cat([p.reshape(-1) for p in ea_parts]).to(torch.int64).numpy()
+                else:
+                    eas = np.concatenate([np.asarray(p, dtype=np.int64).reshape(-1) for p in ea_parts])
+            else:
+                # zinc_dataset_indexbase.py:183: edges past len(bond_types) read as 'unknown' (attr 0); extra attrs are ignored
+                eas = np.zeros(int(ecs.sum()), np.int64)
+                eptr = np.concatenate([[0], np.cumsum(ecs)])
+                for g, p in enumerate(ea_parts):
+                    a = np.asarray(p, dtype=np.int64).reshape(-1)[:ecs[g]]
+                    eas[eptr[g]:eptr[g] + a.size] = a
+        return GraphBatch.from_coo(ncs, ecs, ei[0], ei[1], xs, eas)
+
+
+def collated_storage(dataset):
+    """The collated arrays behind `dataset`, or None when it does not expose any (then items must be fetched one by
+    one).  Understood: a `collated()` method returning the dict below (this package's datasets), or
+    torch_geometric's InMemoryDataset layout - `_data` (or `data`) holding x / edge_index / edge_attr concatenated
+    over the split, `slices[name]` the per-graph offsets, `_indices` an optional subset - as long as no per-item
+    `transform` is installed (the transform could change what an item holds).
+    Returns dict(node_counts, edge_index, edge_slices, x, edge_attr, y, indices)."""
+    fn = getattr(dataset, "collated", None)
+    if callable(fn):
+        return fn()
+    try:
+        slices = getattr(dataset, "slices", None)
+        data = dataset.__dict__.get("_data", None) if hasattr(dataset, "__dict__") else None
+        if data is None:
+            data = getattr(dataset, "_data", None)
+        if data is None or slices is None or getattr(dataset, "transform", None) is not None:
+            return None
+        get = (lambda k: data.get(k)) if isinstance(data, dict) else (lambda k: getattr(data, k, None))
+        ei = get("edge_index")
+        if ei is None or "edge_index" not in slices:
+            return None
+        es = torch.as_tensor(slices["edge_index"]).to(torch.int64)
+        G = int(es.numel()) - 1
+        x = get("x")
+        if x is not None and "x" in slices:
+            ns = torch.as_tensor(slices["x"]).to(torch.int64)
+            nc = ns[1:] - ns[:-1]
+        else:
+            x = None
+            nn = data.get("_num_nodes") if isinstance(data, dict) else getattr(data, "_num_nodes", None)
+            if nn is None:
+                nn = get("num_nodes")
+            nc = torch.as_tensor(nn).reshape(-1).to(torch.int64)
+            if nc.numel() != G:
+                return None
+        ea = get("edge_attr") if "edge_attr" in slices else None
+        idx = getattr(dataset, "_indices", None)
+        return dict(node_counts=nc, edge_index=ei, edge_slices=es, x=x, edge_attr=ea, y=get("y"),
+                    indices=None if idx is None else list(idx))
+    except Exception:
+        return None

@@ -17,6 +17,7 @@ import torch
 from ._root import root as _root
 
 GraphBatch = _root().GraphBatch
+_tag_item = _root().rows.tag_item
 
 _STOP = ("<q>", "<p>", "<eos>")
 
@@ -134,11 +135,14 @@ def parse_texts_on_device(texts: List[str], device="cuda"):
 
 class GraphTokenDatasetForAutoGraph:
     """Same constructor arguments, sampling rules and cache key as the reference class (:161-408).  The graphs are
-    held in memory as items and as the batched CSR the kernels read.  Cache: `<root>/processed/<key>/data.pt` with
-    the reference's key (:233-253) holds `(data, slices)` in the shape InMemoryDataset.collate gives them —
-    attributes concatenated, `slices[name]` the per-item offsets — but as plain dicts of tensors: a pickled
-    torch_geometric `Data` cannot be written or read without torch_geometric.  A `data.pt` that is not in this
-    form (one written by the reference itself) is left alone and the JSON files are processed again."""
+    held in COLLATED form - `(data, slices)` in the shape InMemoryDataset.collate gives them: attributes
+    concatenated, `slices[name]` the per-item offsets - which is what the batched CSR is built from without any
+    per-item work; items are views made on demand.  Cache: `<root>/processed/<key>/data_gtok.pt` with the reference's
+    key (:233-253) but a file name of its own, holding the collated pair as plain dicts of tensors (a pickled
+    torch_geometric `Data` cannot be written or read without torch_geometric).  The reference's own `data.pt` in the
+    same directory is neither read nor written: each side only ever sees its own file."""
+
+    CACHE_NAME = "data_gtok.pt"
 
     def __init__(self, root: str, task: str = "cycle_check", algorithm=None, split: str = "train",
                  use_split_tasks_dirs: bool = True, seed: int = 0, num_graphs: Optional[int] = None,
@@ -150,14 +154,24 @@ class GraphTokenDatasetForAutoGraph:
         self.split, self.use_split_tasks_dirs, self.seed = split, use_split_tasks_dirs, seed
         self.num_graphs, self.num_pairs_per_graph = num_graphs, num_pairs_per_graph
         self._root, self.transform, self.pre_transform, self.pre_filter = root, transform, pre_transform, pre_filter
-        self._batch = None
-        cached = self._load_cache() if use_cache else None
-        if cached is None:
-            self._data_list = self.process()
-            if use_cache:
-                self._save_cache()
-        else:
-            self._data_list = cached
+        self._batches = {}
+        self._items = {}
+        self._coll = self._load_cache() if use_cache else None
+        if self._coll is None:
+            data_list = self.process()
+            self._plain = all(type(d) is Data and set(d.__dict__) <= {"edge_index", "y", "num_nodes", "query_u", "query_v"}
+                              for d in data_list)
+            if self._plain:                       # the collated pair is the storage; items are made from it on demand
+                self._coll = self.collate(data_list)
+                if use_cache:
+                    self._save_cache()
+            else:                                 # a pre_transform added fields: keep the objects it returned
+                self._coll = None
+                self._items = dict(enumerate(data_list))
+                self._len = len(data_list)
+        if self._coll is not None:
+            self._len = int(self._coll[0]["num_nodes"].numel())
+            self._es = self._coll[1]["edge_index"].tolist()
 
     # ---- reference :218-253
     @property
@@ -203,35 +217,36 @@ class GraphTokenDatasetForAutoGraph:
                   "has_query": one}
         return data, slices
 
-    @staticmethod
-    def _uncollate(data, slices) -> List[Data]:
-        out = []
-        es = slices["edge_index"].tolist()
-        for i in range(len(es) - 1):
-            d = Data(edge_index=data["edge_index"][:, es[i]:es[i + 1]].contiguous(), y=data["y"][i:i + 1].clone(),
-                     num_nodes=int(data["num_nodes"][i]))
-            if bool(data["has_query"][i]):
-                d.query_u, d.query_v = int(data["query_u"][i]), int(data["query_v"][i])
-            out.append(d)
-        return out
+    @property
+    def cache_path(self) -> str:
+        return os.path.join(self.processed_dir, self.CACHE_NAME)
 
-    def _load_cache(self) -> Optional[List[Data]]:
-        path = self.processed_paths[0]
+    def _item(self, i: int) -> Data:
+        data, _ = self._coll
+        a, b = self._es[i], self._es[i + 1]
+        d = Data(edge_index=data["edge_index"][:, a:b], y=data["y"][i:i + 1], num_nodes=int(data["num_nodes"][i]))
+        if bool(data["has_query"][i]):
+            d.query_u, d.query_v = int(data["query_u"][i]), int(data["query_v"][i])
+        return d
+
+    def _load_cache(self):
+        path = self.cache_path
         if not os.path.exists(path) or self.pre_transform is not None or self.pre_filter is not None:
             return None
         try:
             data, slices = torch.load(path, weights_only=True)
-            return self._uncollate(data, slices)
-        except Exception:       # not ours (e.g. the reference's PyG pickle): process again, leave the file alone
-            self._foreign_cache = True
+            if not {"edge_index", "y", "num_nodes", "query_u", "query_v", "has_query"} <= set(data) or "edge_index" not in slices:
+                return None
+            return data, slices
+        except Exception:       # unreadable / truncated: process again
             return None
 
     def _save_cache(self) -> None:
-        if getattr(self, "_foreign_cache", False) or self.pre_transform is not None or self.pre_filter is not None:
+        if self.pre_transform is not None or self.pre_filter is not None:
             return
         try:
             os.makedirs(self.processed_dir, exist_ok=True)
-            torch.save(self.collate(self._data_list), self.processed_paths[0])
+            torch.save(self._coll, self.cache_path)
         except OSError:         # read-only data tree: stay in memory
             pass
 
@@ -296,22 +311,47 @@ class GraphTokenDatasetForAutoGraph:
         return out
 
     def __len__(self):
-        return len(self._data_list)
+        return self._len
 
     def __getitem__(self, idx):
-        d = self._data_list[idx]
-        return self.transform(d) if self.transform is not None else d
+        if isinstance(idx, slice):
+            return [self[i] for i in range(*idx.indices(len(self)))]
+        i = idx + self._len if idx < 0 else idx
+        if not 0 <= i < self._len:
+            raise IndexError(idx)
+        d = self._items.get(i)
+        if d is None:
+            d = self._items[i] = self._item(i)
+        if self.transform is not None:            # the batch below would not see what a transform does: no mark
+            return self.transform(d)
+        return _tag_item(self, i, d)              # lets Graph2TrailTokenizer tokenize the item's whole split at once
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
 
-    def graph_batch(self) -> GraphBatch:
-        if self._batch is None:
-            self._batch = GraphBatch.from_data_list(self._data_list, labeled=False)
-        return self._batch
+    def collated(self):
+        """The split's arrays for GraphBatch.from_collated (csr.collated_storage picks this up), or None."""
+        if self._coll is None or self.transform is not None:
+            return None
+        data, slices = self._coll
+        return dict(node_counts=data["num_nodes"], edge_index=data["edge_index"], edge_slices=slices["edge_index"],
+                    x=None, edge_attr=None, y=data["y"], indices=None)
+
+    def graph_batch(self, device=None, labeled: bool = False) -> GraphBatch:
+        """The split as one batched CSR (built once per device), straight from the collated arrays."""
+        key = None if device is None else str(device)
+        if key not in self._batches:
+            self._batches[key] = GraphBatch.from_dataset(self, labeled=False, device=device)
+        return self._batches[key]
 
     def queries(self) -> Optional[np.ndarray]:
         """[G,2] (query_u, query_v) when every item carries a query, else None."""
-        if not self._data_list or not all(hasattr(d, "query_u") for d in self._data_list):
+        if self._coll is not None:
+            data = self._coll[0]
+            if not len(self) or not bool(data["has_query"].all()):
+                return None
+            return torch.stack([data["query_u"], data["query_v"]], 1).to(torch.int32).numpy()
+        items = [self._items[i] for i in range(len(self))]
+        if not items or not all(hasattr(d, "query_u") for d in items):
             return None
-        return np.array([[d.query_u, d.query_v] for d in self._data_list], np.int32)
+        return np.array([[d.query_u, d.query_v] for d in items], np.int32)

@@ -6,6 +6,7 @@ from torch.utils.data import Dataset
 from ._root import root as _root
 
 GraphBatch = _root().GraphBatch
+_tag_item = _root().rows.tag_item
 
 
 class ZINCDatasetForAutoGraph(Dataset):
@@ -20,7 +21,7 @@ class ZINCDatasetForAutoGraph(Dataset):
             from torch_geometric.datasets import ZINC
             zinc_dataset = ZINC(root=zinc_root, subset=subset, split=split)
         self.zinc_dataset = zinc_dataset
-        self._batch = None
+        self._batches = {}
         print(f"Loaded ZINC {split} split: {len(self.zinc_dataset)} molecules")
 
     def __len__(self):
@@ -31,12 +32,15 @@ class ZINCDatasetForAutoGraph(Dataset):
         ea = data.edge_attr
         if ea.dim() == 2 and ea.size(1) == 1:
             data.edge_attr = ea.flatten()
-        return data
+        return _tag_item(self, idx, data)        # lets Graph2TrailTokenizer tokenize the split this item belongs to at once
 
-    def graph_batch(self) -> GraphBatch:
-        if self._batch is None:
-            self._batch = GraphBatch.from_data_list([self[i] for i in range(len(self))], labeled=True)
-        return self._batch
+    def graph_batch(self, device=None, labeled: bool = True) -> GraphBatch:
+        """The split as one batched CSR (built once per device): straight from the collated storage behind
+        torch_geometric's ZINC when it is exposed (no per-item work), item by item otherwise."""
+        key = (None if device is None else str(device), bool(labeled))
+        if key not in self._batches:
+            self._batches[key] = GraphBatch.from_dataset(self.zinc_dataset, labeled=labeled, device=device)
+        return self._batches[key]
 
 
 def get_zinc_num_types():

@@ -81,23 +81,30 @@ class ZINCTokenizationDataset(Dataset):
         return {"text": text, "label": label, "graph_id": f"zinc_{self.split}_{idx}"}
 
     # -- device interface --------------------------------------------------------------------
-    def graph_batch(self) -> GraphBatch:
+    def graph_batch(self, device=None) -> GraphBatch:
+        """The split as one batched CSR (built once per device): straight from the collated storage behind
+        torch_geometric's ZINC when it is exposed (no per-item work), item by item otherwise."""
+        key = None if device is None else str(device)
         if self._batch is None:
-            self._batch = GraphBatch.from_data_list([self.zinc_dataset[i] for i in range(len(self))], labeled=True)
-        return self._batch
+            self._batch = {}
+        if key not in self._batch:
+            self._batch[key] = GraphBatch.from_dataset(self.zinc_dataset, labeled=True, device=device)
+        return self._batch[key]
 
     def labels(self) -> torch.Tensor:
+        got = _root().csr.collated_storage(self.zinc_dataset)
+        if got is not None and got["y"] is not None:
+            y = torch.as_tensor(got["y"]).reshape(-1).to(torch.float32)
+            return y if got["indices"] is None else y[torch.as_tensor(got["indices"], dtype=torch.int64)]
         return torch.tensor([float(self.zinc_dataset[i].y.item()) for i in range(len(self))], dtype=torch.float32)
 
     def tokenize(self, vocab: Dict[str, int], max_len: Optional[int] = None, device=None,
                  ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """ids int32 [G, ld] + lengths on the device, equal to TokenDataset(self[i]..., vocab, max_len) row by row."""
         max_len = self.max_len if max_len is None else max_len
-        batch = self.graph_batch()
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        if batch.device != torch.device(device):
-            batch = self._batch = batch.to(device)
+        batch = self.graph_batch(device)
         lut = _ops.zinc_lut(vocab, max(batch.max_nodes, 1))
         return _ops.ibtt_zinc(batch, lut, max_len, vocab["<pad>"], ld=ld)
 

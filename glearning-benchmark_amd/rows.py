@@ -1,0 +1,78 @@
+"""Host-side view of one tokenized epoch: what the per-item call sites of the reference read from.
+
+trainer/train_agtt.py:246-273 fetches one graph at a time (`tokens = self.tokenizer(data)`, 1-D LongTensor).  The
+kernels tokenize a whole split per launch, so an epoch crosses to the host ONCE, in the packed form (include/gtok.h,
+"packed rows": no padding, rows back to back) and widened to int64 on the device - one pinned D2H copy - and items are
+zero-copy slices of that buffer.  A new epoch gets a new buffer: rows handed out earlier stay valid.
+"""
+import weakref
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops as _ops
+
+
+class EpochRows:
+    """Rows of one [G, ld] slab + lengths (device) as slices of one host int64 buffer."""
+
+    def __init__(self, ids: torch.Tensor, lens: torch.Tensor, epoch: int = 0):
+        ld = int(ids.shape[1])
+        packed, ptr = _ops.pack_rows(ids, lens, elem_bytes=4, check_status=False)[:2]
+        n = torch.clamp(lens, 0, ld)
+        wide = packed.to(torch.int64)
+        self.epoch = epoch
+        self.tokens = torch.empty(wide.shape, dtype=torch.int64, pin_memory=True)
+        self.tokens.copy_(wide, non_blocking=True)
+        ptr_h = torch.empty(ptr.shape, dtype=torch.int64, pin_memory=True); ptr_h.copy_(ptr, non_blocking=True)
+        n_h = torch.empty(n.shape, dtype=n.dtype, pin_memory=True); n_h.copy_(n, non_blocking=True)
+        torch.cuda.current_stream(ids.device).synchronize()
+        self.start = ptr_h[:-1].tolist()            # Python ints: indexing a list is cheaper than a tensor element
+        self.count = n_h.tolist()
+        self.served = bytearray(len(self.count))
+
+    def __len__(self) -> int:
+        return len(self.count)
+
+    def row(self, i: int) -> torch.Tensor:
+        s = self.start[i]
+        return self.tokens[s:s + self.count[i]]
+
+    def take(self, i: int) -> Optional[torch.Tensor]:
+        """Row i, once per epoch: None when it was handed out before (the caller starts a new epoch - a second fetch
+        of an item means a new random trail in the reference, which tokenizes on every fetch)."""
+        if self.served[i]:
+            return None
+        self.served[i] = 1
+        return self.row(i)
+
+
+# ---- which split does an item come from? ------------------------------------------------------------------------------
+# The reference's per-item loop is `data = self.pyg_dataset[idx]; tokens = self.tokenizer(data)` (train_agtt.py:247-250):
+# the tokenizer sees one graph and nothing else.  This package's dataset classes mark what they return with (dataset,
+# index), so that the tokenizer can tokenize the item's whole split in one launch and serve rows from it.
+_LAST = [None, -1, None]       # (weakref to the dataset, index, the object returned): fallback for objects that refuse attributes
+
+
+def tag_item(owner, idx: int, data):
+    ref = weakref.ref(owner)
+    try:
+        data._gtok_src = (ref, int(idx))         # a private attribute: torch_geometric's Data keeps those out of its keys
+    except Exception:
+        pass
+    _LAST[0], _LAST[1], _LAST[2] = ref, int(idx), data
+    return data
+
+
+def item_source(data) -> Optional[Tuple[object, int]]:
+    """(dataset, index) the item was fetched from, or None (an object built by the caller: tokenize it on its own)."""
+    try:
+        src = getattr(data, "_gtok_src", None)
+    except Exception:
+        src = None
+    if src is None and _LAST[2] is data:
+        src = (_LAST[0], _LAST[1])
+    if src is None:
+        return None
+    owner = src[0]()
+    return None if owner is None else (owner, src[1])

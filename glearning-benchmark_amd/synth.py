@@ -302,3 +302,45 @@ def mix_batch_device(num_graphs: int, device, seed: int = 0, min_nodes: int = 10
     cat = lambda l: torch.cat(l).cpu().numpy()
     return dict(node_counts=n.cpu().numpy().astype(np.int64), edge_counts=cat(counts).astype(np.int64),
                 src=cat(srcs).astype(np.int64), dst=cat(dsts).astype(np.int64), family=fam.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+class _Bag:
+    """Attribute bag standing in for torch_geometric.data.Data."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class InMemoryLike:
+    """A split held the way torch_geometric's InMemoryDataset holds one (what torch_geometric.datasets.ZINC is,
+    zinc_dataset_autograph.py:44 / zinc_dataset_indexbase.py:79; no torch_geometric offline):
+    `_data` = every attribute concatenated over the graphs (x [sum N, 1], edge_index [2, sum E] with LOCAL node ids,
+    edge_attr [sum E], y [G]), `slices[name]` = the per-graph offsets, `_indices` = an optional subset, items
+    separated on demand (a fresh object per fetch, like InMemoryDataset.get's copy).  Built from a batched-COO dict
+    (zinc_like())."""
+
+    def __init__(self, d: Dict[str, np.ndarray], indices: Optional[Sequence[int]] = None, transform=None):
+        import torch
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+        self._data = _Bag(x=t(d["x"], torch.long).view(-1, 1), edge_index=torch.stack([t(d["src"], torch.long), t(d["dst"], torch.long)]),
+                          edge_attr=t(d["edge_attr"], torch.long), y=t(d["y"], torch.float32))
+        nptr, eptr = t(_ptr(np.asarray(d["node_counts"])), torch.long), t(_ptr(np.asarray(d["edge_counts"])), torch.long)
+        self.slices = {"x": nptr, "edge_index": eptr, "edge_attr": eptr, "y": torch.arange(len(d["node_counts"]) + 1)}
+        self._indices = None if indices is None else list(indices)
+        self.transform = transform
+        self._n, self._e = nptr.tolist(), eptr.tolist()
+
+    def indices(self):
+        return range(len(self._n) - 1) if self._indices is None else self._indices
+
+    def __len__(self):
+        return len(self.indices())
+
+    def __getitem__(self, idx):
+        g = self.indices()[idx]
+        n0, n1, e0, e1 = self._n[g], self._n[g + 1], self._e[g], self._e[g + 1]
+        dt = self._data
+        item = _Bag(x=dt.x[n0:n1], edge_index=dt.edge_index[:, e0:e1], edge_attr=dt.edge_attr[e0:e1], y=dt.y[g:g + 1],
+                    num_nodes=n1 - n0)
+        return item if self.transform is None else self.transform(item)

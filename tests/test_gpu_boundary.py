@@ -1,0 +1,130 @@
+"""GPU: throughput-critical behaviour of the drop-in boundary (what `train.py --model agtt/ibtt` sees).
+
+ * the reference's per-item AGTT loop (trainer/train_agtt.py:246-273, restated below) over this package's dataset
+   classes costs ONE gtok_sent launch per split and epoch, and yields exactly the rows of the batched call;
+ * a split held in collated storage (torch_geometric's InMemoryDataset layout: zinc_dataset_autograph.py:44) reaches
+   the device as a batched CSR without any per-item work - ZINC-full in well under a second.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from _util import both, gtok, orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+gdl = gtok.graph_data_loader
+
+
+def _reference_getitem(pyg_dataset, tokenizer, idx, remap, task="zinc"):
+    """trainer/train_agtt.py:246-273, restated: fetch, tokenize, (remap), (query tail), mask, label."""
+    data = pyg_dataset[idx]
+    tokens = tokenizer(data)
+    if remap:
+        io, no, eo = tokenizer.idx_offset, tokenizer.node_idx_offset, tokenizer.edge_idx_offset
+        tokens = torch.from_numpy(orc.remap_zinc(tokens.numpy().astype(np.int32)[None, :], np.array([tokens.numel()], np.int32), io, no, eo)[0]).long()
+    if task == "shortest_path" and hasattr(data, "query_u") and hasattr(data, "query_v"):
+        off = tokenizer.idx_offset
+        tokens = torch.cat([tokens, torch.tensor([off + data.num_nodes, off + data.query_u, off + data.query_v], dtype=torch.long)])
+    return tokens, torch.ones(tokens.size(0), dtype=torch.bool), data.y.item(), data
+
+
+def _zinc_tokenizer(max_nodes):
+    tok = gtok.Graph2TrailTokenizer(dataset_names=[], max_length=1024, truncation_length=1024, labeled_graph=True, undirected=True,
+                                    seed=5, device=DEV)
+    tok.set_num_nodes(max_nodes); tok.set_num_node_and_edge_types(*gdl.get_zinc_num_types())
+    return tok
+
+
+def test_reference_per_item_loop_is_one_launch_per_epoch():
+    G = 12000                                                            # BASELINE config 2
+    d = gtok.synth.zinc_like(G, seed=40)
+    batch, coo = both(d)
+    pyg = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=gtok.synth.InMemoryLike(d))
+    tok = _zinc_tokenizer(37)
+    order = torch.randperm(G, generator=torch.Generator().manual_seed(3)).tolist()      # shuffle=True loader
+    for epoch in range(2):
+        got = {}
+        for i in order:
+            tokens, mask, label, data = _reference_getitem(pyg, tok, i, remap=True)
+            got[i] = tokens
+            assert mask.all() and mask.numel() == tokens.numel() and label == pytest.approx(float(d["y"][i]))
+        assert tok.launches == epoch + 1, "one gtok_sent launch per epoch, however the items are fetched"
+        ids, ln = tok.tokenize_batch(batch.to(DEV), epoch=epoch, remap_zinc=True)       # the batched call, fused remap
+        ref, rln = orc.sent(coo, 37, 1024, 5, epoch, ld=ids.shape[1], labeled=True, num_node_types=9, num_edge_types=4,
+                            remap_zinc=True, nthreads=8)
+        tok.launches -= 1
+        assert np.array_equal(ids.cpu().numpy(), ref) and np.array_equal(ln.cpu().numpy(), rln)
+        for i in range(G):
+            assert got[i].dtype == torch.long and np.array_equal(got[i].numpy(), ref[i, :rln[i]]), (epoch, i)
+    # an object the datasets did not hand out is tokenized on its own (one small launch), still a valid SENT
+    loose = gtok.synth.InMemoryLike(d)[11]
+    before = tok.launches
+    one = tok(loose)
+    assert tok.launches == before + 1 and one[0] == 0 and one[-1] == 4
+    # fetching one item of a finished epoch again starts the next epoch (a new random trail), once
+    before = tok.launches
+    t1 = tok(pyg[0]); t2 = tok(pyg[1])
+    assert tok.launches == before + 1
+
+
+def test_three_splits_share_a_tokenizer_and_the_swapped_in_dataset_serves_packed_rows():
+    """train_agtt.py:594-607: train / val / test datasets around ONE tokenizer.  Each split keeps its own epoch; the
+    one-line-swap class (agtt.TokenizedGraphDataset) gives the same rows through its own packed host copy."""
+    ds = [gtok.synth.zinc_like(n, seed=60 + k) for k, n in enumerate((3000, 700, 500))]
+    pygs = [gdl.ZINCDatasetForAutoGraph(split=s, zinc_dataset=gtok.synth.InMemoryLike(d)) for s, d in zip(("train", "val", "test"), ds)]
+    tok = _zinc_tokenizer(37)
+    for rounds, pyg in zip((2, 1, 1), pygs):
+        for _ in range(rounds):
+            for i in range(len(pyg)):
+                tok(pyg[i])
+    assert tok.launches == 4
+    for pyg, d in zip(pygs, ds):
+        _, coo = both(d)
+        fast = gtok.agtt.TokenizedGraphDataset(pyg, tok, task="zinc", remap_to_fixed_vocab=True, device=DEV)
+        before = tok.launches
+        items = [fast[i] for i in range(len(fast))]
+        assert tok.launches == before + 1
+        ref, rln = orc.sent(coo, 37, 1024, 5, 0, ld=256, labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True, nthreads=8)
+        for i, (t, m, y, data) in enumerate(items):
+            assert np.array_equal(t.numpy(), ref[i, :rln[i]]) and m.all() and isinstance(y, float)
+        again = fast[0][0]                                               # second fetch: next epoch's trail
+        assert tok.launches == before + 2 and fast._epoch == 1
+
+
+def test_graph_token_split_with_queries_through_the_reference_loop(tmp_path):
+    tree = gtok.synth.graph_token_tree(30, seed=9, task="shortest_path")
+    gtok.synth.write_tree(str(tmp_path), tree)
+    pyg = gdl.GraphTokenDatasetForAutoGraph(root=str(tmp_path), task="shortest_path", algorithm=["er", "ba", "sbm"], split="train",
+                                            num_pairs_per_graph=3)
+    tok = gtok.Graph2TrailTokenizer(dataset_names=[], max_length=600, truncation_length=600, labeled_graph=False, seed=2, device=DEV)
+    tok.set_num_nodes(max(dd.num_nodes for dd in pyg))
+    rows = [_reference_getitem(pyg, tok, i, remap=False, task="shortest_path")[0] for i in range(len(pyg))]
+    assert tok.launches == 1 and len(rows) > 50
+    b = pyg.graph_batch(device=DEV)
+    ids, ln = tok.tokenize_batch(b, epoch=0, query=torch.as_tensor(pyg.queries()))
+    for i, r in enumerate(rows):
+        assert np.array_equal(r.numpy(), ids[i, :int(ln[i])].cpu().numpy()), i
+    fast = gtok.agtt.TokenizedGraphDataset(pyg, tok, task="shortest_path", device=DEV)
+    assert all(torch.equal(fast[i][0], rows[i]) for i in range(len(pyg)))
+
+
+def test_zinc_full_ingestion_from_collated_storage_under_a_second():
+    G = 249456
+    d = gtok.synth.zinc_like(G, seed=1000)
+    ds = gtok.synth.InMemoryLike(d)
+    gtok.GraphBatch.from_dataset(gtok.synth.InMemoryLike(gtok.synth.zinc_like(2000, seed=1)), device=DEV)   # torch kernels warmed up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b = gtok.GraphBatch.from_dataset(ds, device=DEV)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ref = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+    for k in ("node_ptr", "edge_ptr", "rowptr", "col", "nattr", "eattr"):
+        assert torch.equal(getattr(b, k).cpu(), getattr(ref, k)), k
+    assert b.eorder is None and (b.flags, b.max_nodes, b.max_edges, b.chunk_nodes, b.chunk_edges, b.max_degree) == \
+        (ref.flags, ref.max_nodes, ref.max_edges, ref.chunk_nodes, ref.chunk_edges, ref.max_degree)
+    print(f"ZINC-full ingestion from collated storage: {dt:.3f} s")
+    assert dt < 1.0, f"{dt:.3f} s"

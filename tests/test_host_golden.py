@@ -146,15 +146,16 @@ def test_graph_token_dataset_for_autograph_matches_reference(tmp_path):
             assert os.path.relpath(g["processed_dir"], str(root)) == want["processed_dir"], attempt
             assert os.path.relpath(g["raw_dir"], str(root)) == want["raw_dir"]
             assert g["items"] == want["items"], (attempt, want["kwargs"])
-            assert os.path.exists(os.path.join(g["processed_dir"], "data.pt"))
+            assert os.listdir(g["processed_dir"]) == ["data_gtok.pt"]      # our cache; never the reference's data.pt
     assert sum(len(c["items"]) for c in meta["agds_cases"]) > 100
     D = gdl.GraphTokenDatasetForAutoGraph
     with pytest.raises(RuntimeError) as e:
         D(str(root), task="cycle_check", algorithm=["nope"], split="train")
     assert str(e.value) == meta["agds_missing_error"]
-    # a data.pt that is not ours (the reference's PyG pickle) is neither read nor overwritten
+    # the reference's own data.pt (a PyG pickle) in the same directory is neither read nor overwritten
     ds = D(str(root), task="cycle_check", algorithm=["er", "ba", "path"], split="train")
     path = ds.processed_paths[0]
+    assert path.endswith("data.pt") and not os.path.exists(path)
     with open(path, "wb") as f:
         f.write(b"not a gtok cache")
     ds2 = D(str(root), task="cycle_check", algorithm=["er", "ba", "path"], split="train")
@@ -251,7 +252,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(gtok._lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert gtok.lib().gtok_version() == 2 and gtok.lib().gtok_target() == b"gfx950"
+    assert gtok.lib().gtok_version() == gtok._lib.ABI_VERSION and gtok.lib().gtok_target() == b"gfx950"
 
 
 def test_product_has_no_cpu_path():

@@ -1,0 +1,105 @@
+"""CPU: graphs reach the batched CSR without a per-item Python loop when the dataset exposes collated storage
+(torch_geometric's InMemoryDataset layout), with the same arrays as the item-by-item builder; items are marked with
+the split they come from; the graph-token dataset's cache never shadows the reference's own `data.pt`."""
+import os
+
+import numpy as np
+import torch
+
+from _util import gtok, zinc_data_list
+
+FIELDS = ("node_ptr", "edge_ptr", "rowptr", "col", "nattr", "eattr")
+
+
+def _same(a, b):
+    for k in FIELDS:
+        x, y = getattr(a, k), getattr(b, k)
+        assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), k
+    assert (a.eorder is None) == (b.eorder is None) and (a.eorder is None or torch.equal(a.eorder, b.eorder))
+    assert (a.num_graphs, a.max_nodes, a.max_edges, a.flags, a.chunk_nodes, a.chunk_edges, a.max_degree) == \
+           (b.num_graphs, b.max_nodes, b.max_edges, b.flags, b.chunk_nodes, b.chunk_edges, b.max_degree)
+
+
+def test_collated_storage_gives_the_arrays_of_the_item_loop():
+    for coalesced in (True, False):
+        d = gtok.synth.zinc_like(700, seed=31, coalesced=coalesced)
+        ref = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+        ds = gtok.synth.InMemoryLike(d)
+        assert gtok.csr.collated_storage(ds) is not None
+        _same(gtok.GraphBatch.from_dataset(ds), ref)
+        _same(gtok.GraphBatch.from_data_list([ds[i] for i in range(len(ds))]), ref)
+        _same(gtok.GraphBatch.from_data_list(zinc_data_list(d)), ref)
+        # unlabelled view of the same storage
+        un = gtok.GraphBatch.from_dataset(ds, labeled=False)
+        assert un.nattr is None and un.eattr is None and torch.equal(un.col, ref.col)
+    # a subset (dataset.indices()) in its own order, graphs repeated or skipped
+    idx = [5, 3, 699, 0, 7, 7, 123]
+    sub = gtok.synth.InMemoryLike(d, indices=idx)
+    _same(gtok.GraphBatch.from_dataset(sub), gtok.GraphBatch.from_data_list([ds[i] for i in idx]))
+    # a per-item transform could change what an item holds: the storage is not trusted, items are fetched
+    def drop_last_edge(item):
+        item.edge_index, item.edge_attr = item.edge_index[:, :-2], item.edge_attr[:-2]
+        return item
+    tr = gtok.synth.InMemoryLike(d, transform=drop_last_edge)
+    assert gtok.csr.collated_storage(tr) is None
+    b = gtok.GraphBatch.from_dataset(tr)
+    assert b.num_edges_total == ref.num_edges_total - 2 * 700
+
+
+def test_from_data_list_tolerates_ragged_items():
+    """edge_attr shorter than the edge list reads as 0 ('unknown', zinc_dataset_indexbase.py:183), [E,1] attrs, numpy
+    and list inputs, items without num_nodes."""
+    from _util import PygLike
+    items = [PygLike(x=torch.tensor([[1], [2], [3]]), edge_index=torch.tensor([[0, 1, 2], [1, 2, 0]]), edge_attr=torch.tensor([[1], [2]])),
+             PygLike(x=np.array([4, 5]), edge_index=[[0], [1]], edge_attr=[3]),
+             PygLike(x=torch.zeros((0, 1), dtype=torch.long), edge_index=torch.empty((2, 0), dtype=torch.long),
+                     edge_attr=torch.empty(0, dtype=torch.long))]
+    b = gtok.GraphBatch.from_data_list(items, labeled=True)
+    assert b.node_ptr.tolist() == [0, 3, 5, 5] and b.edge_ptr.tolist() == [0, 3, 4, 4]
+    assert b.nattr.tolist() == [1, 2, 3, 4, 5] and b.eattr.tolist() == [1, 2, 0, 3] and b.col.tolist() == [1, 2, 0, 1]
+
+
+def test_items_carry_their_split():
+    d = gtok.synth.zinc_like(20, seed=2)
+    gdl = gtok.graph_data_loader
+    ds = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=gtok.synth.InMemoryLike(d))
+    it = ds[7]
+    owner, idx = gtok.rows.item_source(it)
+    assert owner is ds and idx == 7 and it.edge_attr.dim() == 1
+    assert gtok.rows.item_source(gtok.synth._Bag(x=1)) is None
+    class Frozen:                       # an object that refuses attributes is still recognised right after the fetch
+        __slots__ = ("y",)
+    f = Frozen()
+    gtok.rows.tag_item(ds, 3, f)
+    assert gtok.rows.item_source(f) == (ds, 3) and gtok.rows.item_source(Frozen()) is None
+    _same(ds.graph_batch(), gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"]))
+    ib = gdl.ZINCTokenizationDataset(split="train", zinc_dataset=gtok.synth.InMemoryLike(d))
+    _same(ib.graph_batch(), ds.graph_batch())
+    assert torch.allclose(ib.labels(), torch.from_numpy(d["y"]))
+
+
+def test_graph_token_cache_does_not_shadow_the_reference_file(tmp_path):
+    """The reference loads `<root>/processed/<key>/data.pt` with torch.load and skips process() whenever that file
+    exists (graph_token_dataset_autograph.py:233-253, :407-408).  Our cache lives beside it under another name: a
+    reference-written data.pt is left byte for byte as it was, and we never create one."""
+    tree = gtok.synth.graph_token_tree(12, seed=5, task="shortest_path")
+    gtok.synth.write_tree(str(tmp_path), tree)
+    kw = dict(root=str(tmp_path), task="shortest_path", algorithm=["er", "ba"], split="train", num_pairs_per_graph=2)
+    G = gtok.graph_data_loader.GraphTokenDatasetForAutoGraph
+    first = G(**kw)
+    key_dir = first.processed_dir
+    assert os.listdir(key_dir) == ["data_gtok.pt"] and first.processed_paths[0].endswith("data.pt")
+    # what the reference would leave there
+    ref_file = os.path.join(key_dir, "data.pt")
+    with open(ref_file, "wb") as f:
+        f.write(b"reference-owned bytes")
+    again = G(**kw)                      # served from our cache, the reference's file untouched
+    assert open(ref_file, "rb").read() == b"reference-owned bytes"
+    assert len(again) == len(first) > 0
+    for a, b in zip(first, again):
+        assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.y, b.y) and a.num_nodes == b.num_nodes \
+            and (a.query_u, a.query_v) == (b.query_u, b.query_v)
+    # items are marked, the split's CSR comes from the collated arrays
+    assert gtok.rows.item_source(again[3]) == (again, 3)
+    _same(again.graph_batch(), gtok.GraphBatch.from_data_list([again[i] for i in range(len(again))], labeled=False))
+    assert again.queries().shape == (len(again), 2)
