@@ -78,6 +78,107 @@ def timed_loop(fn, steps, multi, per_launch_events=True):
     return wall, (ms if per_launch_events else [ms[0] / steps] * steps)
 
 
+def boundary_section(d, G, dev, max_nodes, max_len):
+    """Throughput THROUGH the drop-in boundary, i.e. what the reference's call sites see (items/s; outside the timed
+    region; rank 0, N=1).  The corpus is handed over the way torch_geometric hands ZINC over: an InMemoryDataset-like
+    object with collated storage (synth.InMemoryLike).  Python per-item work (fetching an item object, slicing a row)
+    bounds every per-item call site at ~10^5 items/s whatever the kernels do; device_batches / tokenize are the
+    batched routes."""
+    import contextlib
+    gdl = gtok.graph_data_loader
+    out = {}
+    with contextlib.redirect_stdout(sys.stderr):             # the dataset classes print like the reference's do
+        pyg = gtok.synth.InMemoryLike(d)
+        sync = torch.cuda.synchronize
+
+        def clock(f):
+            sync(); t0 = time.perf_counter(); r = f(); sync()
+            return time.perf_counter() - t0, r
+        # CSR ingestion (once per split)
+        gtok.GraphBatch.from_dataset(gtok.synth.InMemoryLike(gtok.synth.zinc_like(2000, seed=1)), device=dev)      # torch warm-up
+        t, _ = clock(lambda: gtok.GraphBatch.from_dataset(pyg, device=dev))
+        S = min(G, 50000)
+        t_fetch, items = clock(lambda: [pyg[i] for i in range(S)])
+        t_list, _ = clock(lambda: gtok.GraphBatch.from_data_list(items))
+        out["csr_ingestion"] = dict(collated_storage_graphs_per_sec=round(G / t, 1), collated_storage_seconds=round(t, 4), graphs=G,
+                                    item_list_graphs_per_sec=round(S / t_list, 1), item_list_sample=S,
+                                    item_fetch_graphs_per_sec=round(S / t_fetch, 1),
+                                    note="collated: GraphBatch.from_dataset on InMemoryDataset-style storage, built on the device; "
+                                         "item list: GraphBatch.from_data_list over already fetched items (host); item fetch = the stand-in's __getitem__")
+        del items
+
+        def tokenizer():
+            tok = gtok.Graph2TrailTokenizer(dataset_names=[], max_length=max_len, truncation_length=max_len, labeled_graph=True,
+                                            undirected=True, device=dev)
+            tok.set_num_nodes(max_nodes); tok.set_num_node_and_edge_types(*gdl.get_zinc_num_types())
+            return tok
+        # AGTT, zero-edit: the reference's own __getitem__ calls tokenizer(data) per item (train_agtt.py:246-250)
+        src = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=pyg)
+        tok = tokenizer()
+
+        def per_item_loop():
+            n = 0
+            for i in range(G):
+                n += tok(src[i]).numel()
+            return n
+        t1, _ = clock(per_item_loop)                           # epoch 0: includes ingestion + the first launch
+        t2, ntok = clock(per_item_loop)                        # epoch 1: steady state
+        out["agtt_zero_edit_tokenizer_call"] = dict(items_per_sec=round(G / t2, 1), first_epoch_items_per_sec=round(G / t1, 1),
+                                                    launches_per_epoch=tok.launches / 2, tokens_per_sec=round(ntok / t2, 1), items=G,
+                                                    note="for i: tokens = tokenizer(pyg_dataset[i]) with this package's ZINCDatasetForAutoGraph: "
+                                                         "one gtok_sent launch + one packed D2H copy per epoch, rows are slices of it")
+        S = min(G, 2000)
+        loose = [pyg[i] for i in range(S)]                     # objects the datasets did not hand out: one launch per call
+        t, _ = clock(lambda: [tok(x) for x in loose])
+        out["agtt_untagged_tokenizer_call"] = dict(items_per_sec=round(S / t, 1), sample=S,
+                                                   note="tokenizer(data) on foreign objects: CSR of one graph + H2D + launch + D2H per item")
+        # AGTT, one-line swap: agtt.TokenizedGraphDataset.__getitem__ over a full epoch, and device_batches
+        ds = gtok.agtt.TokenizedGraphDataset(src, tokenizer(), task="zinc", remap_to_fixed_vocab=True, device=dev)
+
+        def getitem_loop():
+            n = 0
+            for i in range(G):
+                n += ds[i][0].numel()
+            return n
+        clock(getitem_loop)
+        t, _ = clock(getitem_loop)
+        out["agtt_dataset_getitem"] = dict(items_per_sec=round(G / t, 1), items=G,
+                                           note="agtt.TokenizedGraphDataset.__getitem__ over a whole epoch (fused remap; incl. the packed D2H copy)")
+
+        def batches(with_data, bs=128):
+            n = 0
+            for X, A, Y, dl in ds.device_batches(bs, epoch=7, with_data=with_data):
+                n += X.shape[0]
+            return n
+        clock(lambda: batches(True))
+        t, n = clock(lambda: batches(True))
+        t_nd, _ = clock(lambda: batches(False))
+        out["agtt_device_batches"] = dict(items_per_sec=round(n / t, 1), items_per_sec_without_data_list=round(n / t_nd, 1), batch_size=128, items=n,
+                                          note="agtt.TokenizedGraphDataset.device_batches(128): X / attn / labels stay on the device; "
+                                               "the list of Data objects collate_fn returns is fetched item by item unless with_data=False")
+        # IBTT: strings -> TokenDataset (train_ibtt.py:229-235, :395-397) and the string-free route
+        zds = gdl.ZINCTokenizationDataset(split="train", max_len=max_len, zinc_dataset=pyg)
+        S = min(G, 20000)
+        t_str, ex = clock(lambda: [zds[i] for i in range(S)])
+        vocab, _ = gdl.build_fixed_zinc_vocab()
+        dyn = []
+        seen = set(vocab)
+        for e in ex:
+            for w in e["text"].split():
+                if w not in seen:
+                    seen.add(w); dyn.append(w)
+        vocab = gdl.extend_vocab_with_dynamic_tokens(vocab, dyn)
+        t_td, td = clock(lambda: gdl.TokenDataset(ex, vocab, max_len, device=dev))
+        out["ibtt_strings"] = dict(items_per_sec=round(S / t_str, 1), sample=S, note="[ds[i] for i in range(n)]: ZINCTokenizationDataset.__getitem__ strings")
+        out["ibtt_token_dataset_init"] = dict(items_per_sec=round(S / t_td, 1), sample=S,
+                                              note="TokenDataset(examples, vocab, max_len): pack texts + gtok_text_to_ids + host copy of the rows")
+        t1, _ = clock(lambda: zds.tokenize(vocab, max_len, device=dev))
+        t2, _ = clock(lambda: zds.tokenize(vocab, max_len, device=dev))
+        out["ibtt_tokenize_csr"] = dict(first_call_graphs_per_sec=round(G / t1, 1), resident_graphs_per_sec=round(G / t2, 1), graphs=G,
+                                        note="ZINCTokenizationDataset.tokenize(vocab): CSR -> ids, no strings (first call includes ingestion)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +195,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None, help="graphs in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ibtt", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary section (call-site throughput through the Dataset classes)")
     ap.add_argument("--no-unpadded", action="store_true", help="skip the GTOK_SENT_NO_PAD leg (profiling runs: one launch flavour per kernel name)")
     args = ap.parse_args()
 
@@ -375,6 +477,10 @@ def main():
                        ms_per_step=out["strong_scaling"]["tokenize_and_allgather_ms_per_step"])
             out["config"]["parallelism"] = f"one corpus block-sharded x{world} + RCCL all-gather of the padded slab"
             out["config"]["graphs_per_gpu"] = hi - lo
+
+    # throughput through the Dataset classes the trainers call (not the kernels): rank 0, N=1, ZINC-shaped workloads
+    if rank == 0 and world == 1 and zinc and not args.no_boundary:
+        out["boundary"] = boundary_section(d, G, dev, max_nodes, max_len)
 
     # CPU baseline: the oracle (a port, not the reference's Python) on a bounded sample, rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

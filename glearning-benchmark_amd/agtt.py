@@ -119,8 +119,10 @@ class TokenizedGraphDataset(Dataset):
         return tokens, torch.ones(tokens.size(0), dtype=torch.bool), data.y.item(), data
 
     def device_batches(self, batch_size: int, epoch: int, shuffle: bool = False,
-                       generator: Optional[torch.Generator] = None):
-        """Yield collate_fn's tuple with X/attn/labels on the device (gtok_collate over the epoch's slab)."""
+                       generator: Optional[torch.Generator] = None, with_data: bool = True):
+        """Yield collate_fn's tuple with X/attn/labels on the device (gtok_collate over the epoch's slab).
+        with_data=False: the 4th element (the batch's Data objects, which collate_fn hands on and the model only reads
+        for shortest_path's query nodes, train_agtt.py:127-133) is an empty list and no item object is touched."""
         ids, lens = self.tokenize_epoch(epoch, pad=False)
         n = len(self)
         ds = self.pyg_dataset
@@ -136,10 +138,12 @@ class TokenizedGraphDataset(Dataset):
             y = torch.tensor(labels, dtype=torch.float if is_float else torch.long, device=ids.device)
         lens_h = lens.cpu()
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
+        order_d = order.to(ids.device)
         for s in range(0, n, batch_size):
             idx = order[s:s + batch_size]
-            X, A = _ops.collate(ids, lens, idx, PAD, int(lens_h[idx].max()))
-            yield X, A, y[idx.to(ids.device)], [ds[i] for i in idx.tolist()]
+            idx_d = order_d[s:s + batch_size]
+            X, A = _ops.collate(ids, lens, idx_d, PAD, int(lens_h[idx].max()))
+            yield X, A, y[idx_d], ([ds[i] for i in idx.tolist()] if with_data else [])
 
 
 def collate_fn(batch):
