@@ -195,6 +195,26 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     // Edge types: et[a][b] = type of the first listed entry a->b, else of the first b->a — reverse cells
     // first, forward cells on top, each lane walking its row backwards so the earliest entry wins.
     uint64_t adj = 0;
+    if (a.g.flags & GTOK_CSR_SIMPLE_SYMMETRIC) {
+      // host-verified simple undirected graphs listed in both directions: a node's row IS its neighbour set and the
+      // type of (a,b) is the type of the listed entry a->b - one pass over the own row, no transposed bits, no atomics
+      for (int k0 = rs; k0 < re; k0 += 4) {
+        int v[4], at[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = min(k0 + j, re - 1);
+          v[j] = colL[k];
+          if (LAB) at[j] = eatL[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (k0 + j < re && (unsigned)v[j] < (unsigned)n) {
+            adj |= 1ull << v[j];
+            if (LAB) et[lane * S + v[j]] = (uint8_t)at[j];
+          }
+        }
+      }
+    } else {
     for (int k0 = rs + ((re - rs - 1) & ~3); k0 >= rs; k0 -= 4) {   // chunks of 4, last chunk first
       int v[4], at[4];
 #pragma unroll
@@ -228,6 +248,7 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       }
     }
     adj |= adjT[lane];
+    }
 
     // ---- walk.  The kernel is bound by SCALAR issue (measured: ~1000 SALU vs ~900 VALU per molecule, scalar
     // pipe ~70 % busy), so only what steers control flow lives in SGPRs (vis, cur, its bit, the decision
