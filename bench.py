@@ -158,20 +158,23 @@ def boundary_section(d, G, dev, max_nodes, max_len):
                                                "the list of Data objects collate_fn returns is fetched item by item unless with_data=False")
         # IBTT: strings -> TokenDataset (train_ibtt.py:229-235, :395-397) and the string-free route
         zds = gdl.ZINCTokenizationDataset(split="train", max_len=max_len, zinc_dataset=pyg)
-        S = min(G, 20000)
-        t_str, ex = clock(lambda: [zds[i] for i in range(S)])
+        t_str, ex = clock(lambda: [zds[i] for i in range(G)])          # first fetch renders the whole split on the device
         vocab, _ = gdl.build_fixed_zinc_vocab()
-        dyn = []
-        seen = set(vocab)
-        for e in ex:
-            for w in e["text"].split():
-                if w not in seen:
-                    seen.add(w); dyn.append(w)
-        vocab = gdl.extend_vocab_with_dynamic_tokens(vocab, dyn)
+        t_voc, vocab = clock(lambda: gdl.build_zinc_vocab_on_device([e["text"] for e in ex], device=dev))
         t_td, td = clock(lambda: gdl.TokenDataset(ex, vocab, max_len, device=dev))
-        out["ibtt_strings"] = dict(items_per_sec=round(S / t_str, 1), sample=S, note="[ds[i] for i in range(n)]: ZINCTokenizationDataset.__getitem__ strings")
-        out["ibtt_token_dataset_init"] = dict(items_per_sec=round(S / t_td, 1), sample=S,
-                                              note="TokenDataset(examples, vocab, max_len): pack texts + gtok_text_to_ids + host copy of the rows")
+        out["ibtt_strings"] = dict(items_per_sec=round(G / t_str, 1), seconds=round(t_str, 3), items=G,
+                                   note="[ds[i] for i in range(n)] (train_ibtt.py:229-235): ZINCTokenizationDataset renders the split's strings "
+                                        "with gtok_ibtt_zinc + gtok_ids_to_text on the first fetch, items are served from that")
+        out["ibtt_vocab_scan"] = dict(items_per_sec=round(G / t_voc, 1), seconds=round(t_voc, 3), vocab_size=len(vocab),
+                                      note="build_zinc_vocab_on_device(texts): the dynamic-token scan of train_ibtt.py:361-372 (gtok_vocab_stats_text)")
+        out["ibtt_token_dataset_init"] = dict(items_per_sec=round(G / t_td, 1), seconds=round(t_td, 3), items=G,
+                                              note="TokenDataset(examples, vocab, max_len): pack texts + gtok_text_to_ids + one packed host copy of the rows")
+        out["ibtt_examples_to_token_dataset_seconds"] = round(t_str + t_td, 3)
+        S = min(G, 5000)
+        zds._bulk = False; zds._texts = None
+        t_py, _ = clock(lambda: [zds[i] for i in range(S)])
+        zds._bulk = True
+        out["ibtt_strings_per_item_python"] = dict(items_per_sec=round(S / t_py, 1), sample=S, note="the restated per-item Python renderer (no GPU: host tests)")
         t1, _ = clock(lambda: zds.tokenize(vocab, max_len, device=dev))
         t2, _ = clock(lambda: zds.tokenize(vocab, max_len, device=dev))
         out["ibtt_tokenize_csr"] = dict(first_call_graphs_per_sec=round(G / t1, 1), resident_graphs_per_sec=round(G / t2, 1), graphs=G,
@@ -195,6 +198,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None, help="graphs in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ibtt", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 1 s back-to-back leg")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary section (call-site throughput through the Dataset classes)")
     ap.add_argument("--no-unpadded", action="store_true", help="skip the GTOK_SENT_NO_PAD leg (profiling runs: one launch flavour per kernel name)")
     args = ap.parse_args()
@@ -268,6 +272,64 @@ def main():
                             args.steps, multi, per_launch_events=False)
         nopad_ms = float(np.mean(npm))
 
+    # sustained: >= 1 s of back-to-back launches (clocks, L2 / MALL state of a slab rewritten in place), one event pair around all
+    sustained = None
+    if not args.no_sustained:
+        n_s = max(args.steps, int(1.2 / max(float(np.mean(kern_ms)) * 1e-3, 2e-5)))
+        _, sm = timed_loop(lambda k: step(args.warmup + k, scratch_len), n_s, multi, per_launch_events=False)
+        sustained = dict(launches=n_s, seconds=round(float(sm[0]) * n_s * 1e-3, 3), ms_per_step=round(float(sm[0]), 4),
+                         graphs_per_sec=round(G / float(sm[0]) * 1e3, 1))
+
+    # one-off layout steps ops.sent did inside the warm-up (like the CSR build: once per resident batch, never per epoch):
+    # their time and bytes, re-measured on a fresh copy of the batch, and the kernel WITHOUT any of them (what a C-ABI
+    # caller that passes only the int32 CSR gets)
+    layout = {}
+
+    def fresh():
+        b = gtok.GraphBatch(batch.num_graphs, batch.max_nodes, batch.max_edges, batch.node_ptr, batch.edge_ptr, batch.rowptr, batch.col,
+                            batch.eorder, batch.nattr, batch.eattr, batch.flags, batch.chunk_nodes, batch.chunk_edges, batch.max_degree)
+        return b
+
+    def once(f):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, r
+    nbytes = lambda *ts: int(sum(t.numel() * t.element_size() for t in ts if t is not None))
+    if batch.rowptr8 is not None or (batch.lane_sorted is not None and batch.lane_sorted.rowptr8 is not None):
+        fb = fresh(); once(lambda: gtok.ops.pack8(fresh()))
+        ms, _ = once(lambda: gtok.ops.pack8(fb))
+        layout["pack8"] = dict(ms=round(ms, 3), bytes=nbytes(fb.rowptr8, fb.col8))
+    if batch.lane_sorted is not None:
+        fb = fresh()
+        ms, sb = once(lambda: gtok.ops.lane_sorted(fb))
+        layout["lane_sorted"] = dict(ms=round(ms, 3), units=sb.num_units,
+                                     bytes=nbytes(sb.node_ptr, sb.edge_ptr, sb.rowptr, sb.col, sb.nattr, sb.eattr, sb.rowptr8, sb.col8, sb.graph_ids, sb.unit_ptr))
+    if batch.adj_rows is not None:
+        fb = fresh()
+        ms, _ = once(lambda: gtok.ops.adjbits(fb))
+        layout["adjbits"] = dict(ms=round(ms, 3), bytes=nbytes(fb.adj_rows, fb.adj_planes))
+        ms, lo = once(lambda: gtok.ops._lane_order(fb, max(1, max_len)))
+        layout["lane_order"] = dict(ms=round(ms, 3), bytes=nbytes(lo))
+    if layout:
+        saved = {k: os.environ.get(k) for k in ("GTOK_NO_LANE_SORT", "GTOK_NO_PACK8", "GTOK_NO_ADJBITS")}
+        os.environ.update(GTOK_NO_LANE_SORT="1", GTOK_NO_PACK8="1", GTOK_NO_ADJBITS="1")
+        try:
+            fb = fresh()
+            for w in range(args.warmup):
+                gtok.ops.sent(fb, max_nodes, max_len, seed=0, epoch=w, ld=ld, out=(ids, scratch_len), **kw)
+            _, nm = timed_loop(lambda k: gtok.ops.sent(fb, max_nodes, max_len, seed=0, epoch=args.warmup + k, ld=ld, out=(ids, scratch_len), **kw),
+                               args.steps, multi, per_launch_events=False)
+            layout["without_any_mirror"] = dict(kernel=gtok.ops.sent_kernel_name(fb, max_nodes, max_len, labeled=zinc, num_node_types=ntypes,
+                                                                                 num_edge_types=etypes, remap_zinc=zinc),
+                                                ms_per_step=round(float(np.mean(nm)), 4), graphs_per_sec=round(G / float(np.mean(nm)) * 1e3, 1),
+                                                note="the same batch as plain int32 CSR (no byte mirror, no reordered copy, no bit matrix)")
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        step(args.warmup, scratch_len)      # back on the resident layouts for the legs below
+
     all_len = torch.stack(lens)
     if int(all_len.max().item()) > ld:
         raise SystemExit(f"slab width {ld} too narrow for a timed step (max len {int(all_len.max())}): rerun with --ld safe")
@@ -295,11 +357,28 @@ def main():
         if rec and rec.get("kernel_label", kname) == kname:
             traffic = rec["hbm_bytes_per_launch"]
             traffic_source = f"{rec.get('source', 'profiles/pmc_traffic.json')} (rocprofv3 --pmc, measured at commit {rec.get('commit', 'unknown')}, not in this run)"
+    # rows cut at max_len stop the walk early: the bytes such a walk NEEDS are those of the rows it visited.  Visited nodes per
+    # row come from the tokens (sent_decode); the entries behind them are taken in proportion (E_g * visited / N_g), so this
+    # second yardstick is an estimate, reported beside the fixed one of SURVEY section 8d
+    trunc = None
+    if not zinc:
+        step(args.warmup, scratch_len)
+        dec = gtok.ops.sent_decode(ids, scratch_len, max_nodes, False, 0, edge_cap=4, node_cap=4)
+        vis_n = dec["num_nodes"].to(torch.float64)
+        nc_t = (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.float64).clamp(min=1)
+        ec_t = (batch.edge_ptr[1:] - batch.edge_ptr[:-1]).to(torch.float64)
+        need_read = float((4 * (vis_n + 1) + 4 * ec_t * (vis_n / nc_t).clamp(max=1.0)).sum().item())
+        tb = need_read + write_b
+        trunc = dict(bytes_per_launch=int(tb), achieved=round(tb / kern_s / 1e9, 2), frac=round(tb / kern_s / 1e9 / HBM_PEAK_GBS, 5),
+                     rows_cut=int((scratch_len >= max_len).sum().item()), avg_nodes_visited=round(float(vis_n.mean().item()), 2),
+                     note="4(k+1) + 4 E k/N + 4L + 4 with k = nodes the walk reached before max_len (estimate: entries in proportion)")
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(read_b + write_b), kernel_ms=round(kern_s * 1e3, 4),
                     kernel_ms_event_pair_per_launch=round(float(np.mean(kern_each_ms)), 4),
                     padded_slab_bytes_per_launch=int(4 * G * ld))
+    if trunc is not None:
+        roofline["truncation_aware"] = trunc
 
     out = dict(metric="graphs_tokenized_per_sec", value=round(value, 1), unit="graphs/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 4),
@@ -314,6 +393,10 @@ def main():
                                ("copy reordered by expected walk length (graph_ids + unit table)", batch.lane_sorted is not None),
                                ("adjacency bit-matrix mirror + lane order", batch.adj_rows is not None)) if on]
     out["config"]["resident_layouts"] = layouts
+    if sustained is not None:
+        out["sustained"] = sustained
+    if layout:
+        out["layout"] = layout
     if nopad_ms is not None:
         out["unpadded_rows"] = dict(ms_per_step=round(nopad_ms, 4), graphs_per_sec=round(G / nopad_ms * 1e3, 1),
                                     note="GTOK_SENT_NO_PAD: tokens only, pad tails of the slab not written")
@@ -504,10 +587,22 @@ def main():
         step(args.warmup + reps - 1, scratch_len)
         torch.cuda.synchronize()
         same = np.array_equal(ids[:chk].cpu().numpy(), ref[:chk]) and np.array_equal(scratch_len[:chk].cpu().numpy(), rln[:chk])
+        # the same restatement on ONE thread (SURVEY section 8d asks for both), on a smaller slice of the sample
+        S1 = min(S, max(2000, int(S * 4 / max(cores, 4))))
+        coo1 = coo.slice(0, S1)
+        okw1 = dict(okw, nthreads=1)
+        reps1, t0 = 0, time.perf_counter()
+        while reps1 < 2 or time.perf_counter() - t0 < 4.0:
+            _, rln1 = orc.sent(coo1, max_nodes, max_len, 0, reps1, **okw1)
+            reps1 += 1
+        cpu1_s = (time.perf_counter() - t0) / reps1
         out["cpu_baseline"] = dict(value=round(S / cpu_s, 1), unit="graphs/s", cores=cores, kind="port",
                                    sample=f"first {S} graphs of the same corpus, oracle/gtok_oracle.c:oracle_sent "
                                           f"(OpenMP, {cores} threads), {reps} passes",
-                                   tokens_per_sec=round(float(rln.sum()) / cpu_s, 1), parity_with_gpu=bool(same))
+                                   tokens_per_sec=round(float(rln.sum()) / cpu_s, 1), parity_with_gpu=bool(same),
+                                   single_thread=dict(value=round(S1 / cpu1_s, 1), unit="graphs/s", cores=1,
+                                                      tokens_per_sec=round(float(rln1.sum()) / cpu1_s, 1),
+                                                      sample=f"first {S1} graphs of the same corpus, 1 thread, {reps1} passes"))
         if zinc and not args.no_ibtt:      # the IBTT serialiser's CPU restatement on the same sample
             lut_h = lut.cpu().numpy()
             orc.ibtt_zinc(coo.slice(0, min(S, 2000)), lut_h, max_len, vocab["<pad>"], ild, nthreads=cores)

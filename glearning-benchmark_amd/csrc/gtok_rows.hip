@@ -224,6 +224,55 @@ __global__ void __launch_bounds__(256) collate_packed_kernel(const void *__restr
   }
 }
 
+// ---- id rows -> text (the strings ZINCTokenizationDataset.__getitem__ hands to the trainer, zinc_dataset_indexbase.py:143-227,
+// rendered for a whole split at once).  One wave per row; lane = token: the row's text is the table strings of its first
+// take[r] ids joined by single spaces, then the row's suffix bytes verbatim.
+struct TextArgsR {
+  const int32_t *ids; int ld; const int32_t *take; int64_t rows;
+  const uint8_t *tab_bytes; const int32_t *tab_ptr; int num_strings;
+  const uint8_t *suf_bytes; const int64_t *suf_ptr;
+  const int64_t *text_ptr; uint8_t *out; int64_t *text_len;
+};
+
+__global__ void __launch_bounds__(256) ids_to_text_kernel(const TextArgsR a) {
+  const int lane = lane_id();
+  const int64_t r = (int64_t)blockIdx.x * (int)(blockDim.x >> 6) + wave_id();
+  if (r >= a.rows) return;
+  int n = a.take[r];
+  n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
+  const int32_t *__restrict__ row = a.ids + r * (int64_t)a.ld;
+  const int64_t s0 = a.suf_ptr ? a.suf_ptr[r] : 0, s1 = a.suf_ptr ? a.suf_ptr[r + 1] : 0;
+  uint8_t *__restrict__ dst = a.out ? a.out + a.text_ptr[r] : nullptr;
+  int64_t run = 0;                                   // bytes of the text before this chunk of 64 tokens
+  for (int c0 = 0; c0 < n; c0 += kWave) {
+    const int i = c0 + lane;
+    int len = 0, off = 0;
+    if (i < n) {
+      const int t = row[i];
+      if (t >= 0 && t < a.num_strings) { off = a.tab_ptr[t]; len = a.tab_ptr[t + 1] - off; }
+    }
+    const int cost = i < n ? len + (i > 0 ? 1 : 0) : 0;   // a space in front of every token but the first
+    int inc = cost;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int up = __shfl_up(inc, o);
+      if (lane >= o) inc += up;
+    }
+    if (dst && i < n) {
+      uint8_t *p = dst + run + (inc - cost);
+      if (i > 0) *p++ = (uint8_t)' ';
+      const uint8_t *q = a.tab_bytes + off;
+      for (int b = 0; b < len; ++b) p[b] = q[b];
+    }
+    run += __shfl(inc, kWave - 1);
+  }
+  if (dst) {
+    for (int64_t b = lane; b < s1 - s0; b += kWave) dst[run + b] = a.suf_bytes[s0 + b];
+  } else if (lane == 0) {
+    a.text_len[r] = run + (s1 - s0);
+  }
+}
+
 static int tpr_shift_for(int ld) {
   const int pieces = (ld + 7) / 8;
   int s = 0;
@@ -306,5 +355,23 @@ extern "C" int gtok_collate_packed(const void *packed, int32_t elem_bytes, const
   else
     hipLaunchKernelGGL(collate_packed_kernel<int32_t>, dim3((batch + 3) / 4), dim3(256), 0, s, packed, row_ptr, len, ld, index,
                        batch, pad_id, out_x, out_attn, out_ld);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_ids_to_text(const int32_t *ids, int32_t ld, const int32_t *take, int64_t num_rows, const uint8_t *tab_bytes,
+                                const int32_t *tab_ptr, int32_t num_strings, const uint8_t *suf_bytes, const int64_t *suf_ptr,
+                                const int64_t *text_ptr, uint8_t *out_bytes, int64_t *text_len, void *stream) {
+  DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (num_rows < 0 || ld <= 0 || num_strings < 0) return GTOK_E_INVAL;
+  if (num_rows == 0) return GTOK_OK;
+  if (!ids || !take || !tab_bytes || !tab_ptr || (suf_ptr && !suf_bytes)) return GTOK_E_INVAL;
+  if (out_bytes ? !text_ptr : !text_len) return GTOK_E_INVAL;
+  const int64_t nb = (num_rows + 3) / 4;
+  if (nb > 0x7FFFFFFF) return GTOK_E_TOO_LARGE;
+  TextArgsR a;
+  a.ids = ids; a.ld = ld; a.take = take; a.rows = num_rows; a.tab_bytes = tab_bytes; a.tab_ptr = tab_ptr; a.num_strings = num_strings;
+  a.suf_bytes = suf_bytes; a.suf_ptr = suf_ptr; a.text_ptr = text_ptr; a.out = out_bytes; a.text_len = text_len;
+  hipLaunchKernelGGL(ids_to_text_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }

@@ -334,19 +334,23 @@ class TokenDataset(Dataset):
                 continue
             texts.append(text)
             labels.append(int(label) if label is not None else 0)       # int() truncates ZINC's float labels
-        self.labels = [torch.tensor(v, dtype=torch.long) for v in labels]
         self._y = torch.tensor(labels, dtype=torch.long)
+        self.labels = list(self._y.unbind(0)) if labels else []          # 0-dim views of one tensor
         if texts:
             blob, ptr = _ops.pack_texts(texts)
             self._table = _ops.VocabTable(vocab, self.device)
             self.ids, self.lens = _ops.text_to_ids(blob.to(self.device), ptr, self._table, max_len, strip_label)
+            # host copy, made here in the parent process: ONE packed int64 buffer (rows back to back, no padding) crosses
+            # to the host, row i is a view of it cut at its length - what the reference stores as one tensor per example
+            rows = _root().rows.EpochRows(self.ids, self.lens, pin=False)   # pageable: forked DataLoader workers read it
+            self._lens_h = torch.tensor(rows.count, dtype=torch.int32)
+            self.seqs: List[torch.Tensor] = [rows.row(i) for i in range(len(rows))]
         else:
             self._table = None
             self.ids = torch.empty((0, 4), dtype=torch.int32, device=self.device)
             self.lens = torch.empty((0,), dtype=torch.int32, device=self.device)
-        # host copy, made here in the parent process (one D2H of the slab): row i cut at its length
-        ids_h, self._lens_h = self.ids.cpu().to(torch.long), self.lens.cpu()
-        self.seqs: List[torch.Tensor] = [ids_h[i, :l].clone() for i, l in enumerate(self._lens_h.tolist())]
+            self._lens_h = torch.empty((0,), dtype=torch.int32)
+            self.seqs = []
 
     def __getstate__(self):
         state = dict(self.__dict__)

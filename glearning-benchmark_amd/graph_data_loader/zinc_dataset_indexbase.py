@@ -40,6 +40,8 @@ class ZINCTokenizationDataset(Dataset):
             zinc_dataset = ZINC(root=zinc_root, subset=subset, split=split)
         self.zinc_dataset = zinc_dataset
         self._batch: Optional[GraphBatch] = None
+        self._texts = self._labels = None
+        self._bulk = True                 # render the split at once on the first fetch when a GPU is there
         print(f"Loaded ZINC {split} split: {len(self.zinc_dataset)} molecules")
 
     def __len__(self):
@@ -71,7 +73,7 @@ class ZINCTokenizationDataset(Dataset):
         toks += ["<q>", "regression", "<p>", _label_token(label), "<eos>"]
         return " ".join(toks)
 
-    def __getitem__(self, idx):
+    def _item(self, idx):
         data = self.zinc_dataset[idx]
         label = data.y.item()
         text = self.tokenize_molecule(data, label)
@@ -79,6 +81,41 @@ class ZINCTokenizationDataset(Dataset):
         if len(toks) > self.max_len:                       # reference :217-221
             text = " ".join(toks[:self.max_len - 1] + ["<eos>"])
         return {"text": text, "label": label, "graph_id": f"zinc_{self.split}_{idx}"}
+
+    def render_all(self, device=None):
+        """(texts, labels) of the WHOLE split in two launches instead of a Python loop per atom and bond: the
+        serialiser kernel (gtok_ibtt_zinc) emits, per molecule, the positions of its tokens in a string table, and
+        gtok_ids_to_text joins the strings.  The label token and `<eos>` (one distinct string per molecule: val_x_xx,
+        reference :192) and the `max_len` cut (:217-221) are attached per row on the host.  Same strings as `_item`."""
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        batch = self.graph_batch(device)
+        G = batch.num_graphs
+        strings = ["<bos>", "<eos>", "<atom>", "<bond>", "<q>", "regression", "<p>"] + list(_ops.ZINC_ATOM_SYMBOLS) \
+            + list(_ops.ZINC_BOND_NAMES) + [str(i) for i in range(max(batch.max_nodes, 1))]
+        lut = torch.arange(len(strings), dtype=torch.int32)        # the kernel's LUT position IS the string's index
+        ids, ln = _ops.ibtt_zinc(batch, lut, 1 << 30, 0)
+        labels = self.labels().tolist()
+        ln_h = ln.cpu().numpy().astype(np.int64)
+        cut = ln_h + 2 > self.max_len                              # tokens = ids + [label, <eos>]
+        take = np.where(cut, self.max_len - 1, ln_h)
+        tail = [(b" <eos>" if k else b"<eos>") if c else (" " + _label_token(v) + " <eos>").encode("ascii")
+                for c, k, v in zip(cut.tolist(), take.tolist(), labels)]
+        blob, ptr = _ops.ids_to_text(ids, torch.from_numpy(take.astype(np.int32)).to(ids.device), strings, tail)
+        raw = bytes(blob.cpu().numpy())
+        p = ptr.cpu().tolist()
+        return [raw[p[i]:p[i + 1]].decode("ascii") for i in range(G)], labels
+
+    def __getitem__(self, idx):
+        """{'text','label','graph_id'} (reference :197-227).  With a GPU the whole split is rendered on the first
+        fetch (render_all) and items are served from that; without one - host-side tests, plumbing - the item is
+        rendered on its own by the restated Python."""
+        if self._texts is None and self._bulk and self.max_len >= 2 and len(self) > 1 and torch.cuda.is_available():
+            self._texts, self._labels = self.render_all()
+        if self._texts is None:
+            return self._item(idx)
+        i = idx + len(self) if idx < 0 else idx
+        return {"text": self._texts[i], "label": self._labels[i], "graph_id": f"zinc_{self.split}_{idx}"}
 
     # -- device interface --------------------------------------------------------------------
     def graph_batch(self, device=None) -> GraphBatch:

@@ -431,6 +431,37 @@ def collate_packed(packed: torch.Tensor, row_ptr: torch.Tensor, ln: torch.Tensor
     return X, A
 
 
+def ids_to_text(ids: torch.Tensor, take: torch.Tensor, strings: Sequence[str], suffixes: Optional[Sequence[bytes]] = None):
+    """Rows of ids -> texts on the device (gtok_ids_to_text): row r = the strings of its first take[r] ids joined by single
+    spaces + suffixes[r] verbatim.  Returns (blob uint8 [total], text_ptr int64 [rows + 1]) on the device; text r is
+    blob[text_ptr[r] : text_ptr[r + 1]].  `strings[t]` is the text of id t (ASCII)."""
+    _need_gpu(ids, "ids_to_text")
+    if ids.dtype != torch.int32 or ids.dim() != 2 or not ids.is_contiguous() or take.dtype != torch.int32:
+        raise ValueError("ids_to_text expects a contiguous int32 [rows, ld] slab and int32 counts")
+    dev, (rows, ld) = ids.device, ids.shape
+    enc = [t.encode("ascii") for t in strings]
+    tptr = np.zeros(len(enc) + 1, np.int32); np.cumsum([len(b) for b in enc], out=tptr[1:])
+    tab = torch.frombuffer(bytearray(b"".join(enc) or b"\0"), dtype=torch.uint8).to(dev)
+    tab_ptr = torch.from_numpy(tptr).to(dev)
+    sb = sp = None
+    if suffixes is not None:
+        if len(suffixes) != rows:
+            raise ValueError("one suffix per row")
+        sptr = np.zeros(rows + 1, np.int64); np.cumsum(np.fromiter(map(len, suffixes), np.int64, rows), out=sptr[1:])
+        sb = torch.frombuffer(bytearray(b"".join(suffixes) or b"\0"), dtype=torch.uint8).to(dev)
+        sp = torch.from_numpy(sptr).to(dev)
+    tlen = torch.empty(rows, dtype=torch.int64, device=dev)
+    L = lib()
+    args = (ids.data_ptr(), ld, take.data_ptr(), rows, tab.data_ptr(), tab_ptr.data_ptr(), len(enc),
+            None if sb is None else sb.data_ptr(), None if sp is None else sp.data_ptr())
+    check(L.gtok_ids_to_text(*args, None, None, tlen.data_ptr(), _stream(dev)), "gtok_ids_to_text")
+    text_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(tlen, 0, out=text_ptr[1:])
+    blob = torch.empty(max(int(text_ptr[-1]), 1), dtype=torch.uint8, device=dev)
+    check(L.gtok_ids_to_text(*args, text_ptr.data_ptr(), blob.data_ptr(), None, _stream(dev)), "gtok_ids_to_text")
+    return blob[:int(text_ptr[-1])], text_ptr
+
+
 # ------------------------------------------------------------------------------------------------
 # text -> ids (TokenDataset)
 # ------------------------------------------------------------------------------------------------
@@ -604,16 +635,14 @@ class VocabTable:
 def pack_texts(texts: Sequence[str]) -> Tuple[torch.Tensor, torch.Tensor]:
     """Concatenate texts into (bytes uint8 [total], text_ptr int64 [G+1]); ASCII only (str.split() on
     non-ASCII whitespace is not reproduced on the device)."""
-    enc = []
-    for t in texts:
-        b = t.encode("utf-8")
-        if len(b) != len(t):
-            raise ValueError("gtok text path handles ASCII text only")
-        enc.append(b)
+    try:
+        enc = [t.encode("ascii") for t in texts]
+    except UnicodeEncodeError:
+        raise ValueError("gtok text path handles ASCII text only") from None
     ptr = np.zeros(len(enc) + 1, np.int64)
-    np.cumsum([len(b) for b in enc], out=ptr[1:])
+    np.cumsum(np.fromiter(map(len, enc), np.int64, len(enc)), out=ptr[1:])
     blob = b"".join(enc) or b"\0"
-    return torch.frombuffer(bytearray(blob), dtype=torch.uint8).clone(), torch.from_numpy(ptr)
+    return torch.frombuffer(bytearray(blob), dtype=torch.uint8), torch.from_numpy(ptr)
 
 
 def text_to_ids(text_bytes: torch.Tensor, text_ptr: torch.Tensor, table: VocabTable, max_len: int,

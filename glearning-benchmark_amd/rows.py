@@ -16,14 +16,16 @@ from . import ops as _ops
 class EpochRows:
     """Rows of one [G, ld] slab + lengths (device) as slices of one host int64 buffer."""
 
-    def __init__(self, ids: torch.Tensor, lens: torch.Tensor, epoch: int = 0):
+    def __init__(self, ids: torch.Tensor, lens: torch.Tensor, epoch: int = 0, pin: bool = True):
+        """pin=False: the buffer is ordinary pageable memory (rows that DataLoader worker processes will read: pinned
+        allocations are not reliably inherited across fork)."""
         ld = int(ids.shape[1])
         packed, ptr = _ops.pack_rows(ids, lens, elem_bytes=4, check_status=False)[:2]
         n = torch.clamp(lens, 0, ld)
         wide = packed.to(torch.int64)
         self.epoch = epoch
-        self.tokens = torch.empty(wide.shape, dtype=torch.int64, pin_memory=True)
-        self.tokens.copy_(wide, non_blocking=True)
+        self.tokens = torch.empty(wide.shape, dtype=torch.int64, pin_memory=pin)
+        self.tokens.copy_(wide, non_blocking=pin)
         ptr_h = torch.empty(ptr.shape, dtype=torch.int64, pin_memory=True); ptr_h.copy_(ptr, non_blocking=True)
         n_h = torch.empty(n.shape, dtype=n.dtype, pin_memory=True); n_h.copy_(n, non_blocking=True)
         torch.cuda.current_stream(ids.device).synchronize()

@@ -28,6 +28,7 @@
  *                      bits per id - for the copies that leave the GPU: the all-gather that reassembles the rows of
  *                      every rank in dataset order (val/test loaders, trainer/train_agtt.py:602-607) and the D2H
  *                      copy behind TokenizedGraphDataset.__getitem__ (trainer/train_agtt.py:246-273)
+ *   gtok_ids_to_text   graph_data_loader/zinc_dataset_indexbase.py:143-227, the STRING form (ids rendered through a string table)
  *   gtok_csr_pack8     (no reference counterpart) byte-packed mirror of the CSR index arrays of small-graph batches
  *   gtok_csr_adjbits   (no reference counterpart) adjacency bit-matrix mirror of batches of graphs with <= 256 nodes
  *   gtok_vocab_stats_text   the corpus pass of build_vocab_from_texts / the ZINC dynamic-token scan over arbitrary texts
@@ -299,6 +300,17 @@ int gtok_unpack_rows(const void *packed, int32_t elem_bytes, const int64_t *row_
 int gtok_collate_packed(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
                         int32_t ld, const int64_t *index, int32_t batch, int32_t pad_id, int64_t *out_x,
                         uint8_t *out_attn, int32_t out_ld, void *stream);
+
+/* Rows of ids -> TEXT: the strings ZINCTokenizationDataset.__getitem__ returns (zinc_dataset_indexbase.py:143-227: the
+ * trainer builds its vocab from them, trainer/train_ibtt.py:229-235, :361-372) rendered for a whole split at once.  Row
+ * r's text = the strings of its first take[r] ids (string t = tab_bytes[tab_ptr[t] .. tab_ptr[t+1]), t < num_strings; ids
+ * outside the table render as empty strings) joined by single spaces, followed VERBATIM by the row's suffix bytes
+ * suf_bytes[suf_ptr[r] .. suf_ptr[r+1]) (suf_ptr NULL = none; the label token and <eos>, which differ per molecule, travel
+ * here).  Two passes like gtok_parse_graph_text: out_bytes == NULL writes text_len[r]; the caller prefix-sums it into
+ * text_ptr[num_rows+1] and calls again with out_bytes (capacity text_ptr[num_rows]).                                       */
+int gtok_ids_to_text(const int32_t *ids, int32_t ld, const int32_t *take, int64_t num_rows, const uint8_t *tab_bytes,
+                     const int32_t *tab_ptr, int32_t num_strings, const uint8_t *suf_bytes, const int64_t *suf_ptr,
+                     const int64_t *text_ptr, uint8_t *out_bytes, int64_t *text_len, void *stream);
 
 /* First position of `token` in every row of an int64 [rows, ld] batch (what gtok_collate
  * returns): pos[r] = the smallest i with x[r, i] == token, -1 if there is none.  This is the

@@ -4,7 +4,7 @@
 #   gpurun --timeout 1200 -- 'bash profiles/tools/collect.sh r02'
 # Everything lands in gpurun_out/collect_<tag>/; profiles/tools/collect_merge.py turns it into profiles/<tag>/.
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/collect_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -17,12 +17,13 @@ step run_to $out/bench_synth_er.json timeout -k 10 400 $B --workload synth_er
 step run_to $out/bench_synth_mix.json timeout -k 10 600 $B --workload synth_mix --no-cpu-baseline
 step run_to $out/bench_zinc_subset.json timeout -k 10 400 $B --workload zinc_subset
 prof() { local log=$1; shift; "$@" > $log 2>&1; local rc=$?; find $out -name '*_kernel_trace.csv' -delete; return $rc; }
-for wl in zinc_full synth_er synth_mix; do
-  step prof $out/stats_$wl.log timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o s -- $B --workload $wl --no-cpu-baseline --no-unpadded
-  [ $wl = synth_mix ] && continue      # (its corpus is sampled by thousands of torch launches: far too slow under counter collection)
+# counters are collected for OUR kernels only (--kernel-include-regex gtok): the corpora are sampled by thousands of torch
+# launches, which made counter collection of synth_mix impractical before
+for wl in zinc_full synth_er synth_mix zinc_subset; do
+  step prof $out/stats_$wl.log timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o s -- $B --workload $wl --no-cpu-baseline --no-unpadded --no-boundary --no-sustained
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS"; do
     name=$(echo $grp | cut -d' ' -f1)
-    step prof $out/pmc_${wl}_$name.log timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc_${wl}_$name -o p -- python3 bench.py --steps 5 --warmup 1 --workload $wl --no-cpu-baseline --no-unpadded
+    step prof $out/pmc_${wl}_$name.log timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex gtok --output-format csv -d $out/pmc_${wl}_$name -o p -- python3 bench.py --steps 5 --warmup 1 --workload $wl --no-cpu-baseline --no-unpadded --no-boundary --no-sustained
   done
 done
 # keep what collect_merge.py reads: our kernels' counter rows and the stats tables (gpurun returns <= 64 MiB)

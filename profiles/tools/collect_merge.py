@@ -4,15 +4,12 @@ bench JSON lines, per-kernel stats CSVs, one PMC summary per workload, and profi
 /opt/skills/guides/MI355X_MICROARCH.md, HBM section)."""
 import collections, csv, glob, json, os, shutil, sys
 import subprocess
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 src, dst = f"gpurun_out/collect_{tag}", f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
 traffic = {}
-for extra in ("zinc_subset",):
-    if os.path.exists(f"{src}/bench_{extra}.json"):
-        shutil.copy(f"{src}/bench_{extra}.json", f"{dst}/bench_{extra}_final.json")
-for wl in ("zinc_full", "synth_er", "synth_mix"):
+for wl in ("zinc_full", "synth_er", "synth_mix", "zinc_subset"):
     shutil.copy(f"{src}/bench_{wl}.json", f"{dst}/bench_{wl}_final.json")
     for f in glob.glob(f"{src}/stats_{wl}/**/*_kernel_stats.csv", recursive=True):
         shutil.copy(f, f"{dst}/bench_{wl}_kernel_stats_final.csv")

@@ -128,3 +128,29 @@ def test_zinc_full_ingestion_from_collated_storage_under_a_second():
         (ref.flags, ref.max_nodes, ref.max_edges, ref.chunk_nodes, ref.chunk_edges, ref.max_degree)
     print(f"ZINC-full ingestion from collated storage: {dt:.3f} s")
     assert dt < 1.0, f"{dt:.3f} s"
+
+
+@pytest.mark.parametrize("max_len", [1024, 48, 2])
+def test_zinc_strings_rendered_on_the_device_equal_the_reference(max_len):
+    """ZINCTokenizationDataset.__getitem__ strings (zinc_dataset_indexbase.py:143-227; train_ibtt.py:229-235 fetches
+    every item of every split): rendered for the whole split by gtok_ibtt_zinc + gtok_ids_to_text, equal to the texts
+    the reference itself produced (golden) and to the per-item Python restatement on corpora with every fallback."""
+    from _util import golden, golden_zinc_coo, zinc_data_list, edge_case_graphs
+    _, meta = golden()
+    ds = gdl.ZINCTokenizationDataset(split="train", max_len=max_len, zinc_dataset=zinc_data_list(golden_zinc_coo()))
+    items = [ds[i] for i in range(len(ds))]
+    assert ds._texts is not None, "the split was rendered in one go"
+    if max_len in (1024, 48):
+        assert [it["text"] for it in items] == meta[f"zinc_L{max_len}_texts"]
+        assert [it["label"] for it in items] == meta[f"zinc_L{max_len}_labels"]
+        assert [it["graph_id"] for it in items] == meta[f"zinc_L{max_len}_graph_ids"]
+    assert [it["text"] for it in items] == [ds._item(i)["text"] for i in range(len(ds))]
+    for d in (gtok.synth.zinc_like(3000, seed=5), gtok.synth.zinc_like(500, seed=6, coalesced=False), edge_case_graphs()):
+        d = dict(d)
+        d.setdefault("y", np.linspace(-3.0, 3.0, len(d["node_counts"])).astype(np.float32))
+        d["y"][:3] = [-0.004, 0.005, -12.345]                       # val_neg0_00, rounding, sign
+        for src in (zinc_data_list(d), gtok.synth.InMemoryLike(d)):
+            z = gdl.ZINCTokenizationDataset(split="val", max_len=max_len, zinc_dataset=src)
+            got = [z[i] for i in range(len(z))]
+            want = [z._item(i) for i in range(len(z))]
+            assert z._texts is not None and got == want
