@@ -89,7 +89,7 @@ SYMBOLS = {
     "gtok_target": (ctypes.c_char_p, []),
 }
 
-ERRORS = {-1: "GTOK_E_INVAL", -2: "GTOK_E_TOO_LARGE", -3: "GTOK_E_LAUNCH", -4: "GTOK_E_NO_DEVICE"}
+ERRORS = {-1: "GTOK_E_INVAL", -2: "GTOK_E_TOO_LARGE", -3: "GTOK_E_LAUNCH", -4: "GTOK_E_NO_DEVICE", -5: "GTOK_E_GRAPH_SLOTS"}
 
 
 class GtokError(RuntimeError):

@@ -71,6 +71,7 @@ class GraphBatch:
     unit_ptr: Optional[torch.Tensor] = None      # int32 [G] dataset index of every slot, int32 [units + 1] slots per wave
     num_units: int = 0
     lane_sorted: Optional["GraphBatch"] = None   # the reordered copy of THIS batch (device batches, made on first use)
+    adj_unusable: bool = False                   # gtok_csr_adjbits found a closure degree above 255: do not try again
 
     @property
     def device(self) -> torch.device:

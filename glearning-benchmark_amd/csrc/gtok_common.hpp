@@ -133,12 +133,15 @@ struct Tickets {
 // that event when the ring has wrapped onto a launch still in flight (256+ launches queued without a
 // synchronisation) - two live launches never share counters.  Launches issued while the stream is being CAPTURED
 // into a hipGraph get a slot of their own from a reserved pool that is never recycled (a replay must find the
-// counters it was captured with, and event queries are not capturable): at most kGraphSlots captured launches per
-// device.  The first call on a device allocates (not capturable: warm up once before capturing).
+// counters it was captured with, and event queries are not capturable): at most kGraphSlots captured launches of the
+// ticket-scheduled kernels per device and process - the 65th capture fails with GTOK_E_GRAPH_SLOTS (capture once and
+// replay; a graph that is re-captured per epoch or per shape should pin one of the kernels without tickets).  The first
+// call on a device allocates (not capturable: warm up once before capturing).
 struct QueueSlot {
   int *counters = nullptr;
   int index = -1;       // ring index, -1: reserved (captured) slot - nothing to record
   int dev = 0;
+  bool graph_pool_empty = false;   // a captured launch found all kGraphSlots reserved slots taken (GTOK_E_GRAPH_SLOTS)
 };
 constexpr int kSlots = 256, kGraphSlots = 64, kMaxDev = 64, kSlotInts = (2 * kQueues + 1) * kQueueStride;
 struct QueueRing {
@@ -155,34 +158,40 @@ inline QueueSlot take_queue_slot(int dev, hipStream_t stream) {
   QueueSlot out;
   if (dev < 0 || dev >= kMaxDev) return out;
   QueueRing &r = queue_ring();
-  std::lock_guard<std::mutex> lock(r.mu);
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-  if (!r.mem[dev]) {
-    if (cap != hipStreamCaptureStatusNone) return out;                    // cannot allocate inside a capture
-    int *p = nullptr;
-    const size_t bytes = (size_t)(kSlots + kGraphSlots) * kSlotInts * sizeof(int);
-    if (hipMalloc(reinterpret_cast<void **>(&p), bytes) != hipSuccess) return out;
-    if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return out; }
-    r.mem[dev] = p;
-  }
-  out.dev = dev;
-  if (cap != hipStreamCaptureStatusNone) {
-    if (r.graph_taken[dev] >= kGraphSlots) return out;
-    out.counters = r.mem[dev] + (size_t)kSlotInts * (kSlots + r.graph_taken[dev]++);
-    return out;
-  }
-  const int i = (int)(r.seq[dev]++ % kSlots);
-  if (r.used[dev][i]) {
-    if (hipEventQuery(r.ev[dev][i]) != hipSuccess) {      // still in flight (or unknown): wait for that launch
-      (void)hipGetLastError();
-      if (hipEventSynchronize(r.ev[dev][i]) != hipSuccess) { (void)hipGetLastError(); return out; }
+  hipEvent_t wait_for = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(r.mu);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (!r.mem[dev]) {
+      if (cap != hipStreamCaptureStatusNone) return out;                    // cannot allocate inside a capture
+      int *p = nullptr;
+      const size_t bytes = (size_t)(kSlots + kGraphSlots) * kSlotInts * sizeof(int);
+      if (hipMalloc(reinterpret_cast<void **>(&p), bytes) != hipSuccess) return out;
+      if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return out; }
+      r.mem[dev] = p;
     }
-  } else if (!r.ev[dev][i]) {
-    if (hipEventCreateWithFlags(&r.ev[dev][i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return out; }
+    out.dev = dev;
+    if (cap != hipStreamCaptureStatusNone) {
+      if (r.graph_taken[dev] >= kGraphSlots) { out.graph_pool_empty = true; return out; }
+      out.counters = r.mem[dev] + (size_t)kSlotInts * (kSlots + r.graph_taken[dev]++);
+      return out;
+    }
+    // the ring index is this call's alone until the ring wraps again (kSlots launches later): the wait for the launch
+    // that used it last happens OUTSIDE the lock, so launches on other devices and threads are not held up behind it
+    const int i = (int)(r.seq[dev]++ % kSlots);
+    if (r.used[dev][i]) {
+      if (hipEventQuery(r.ev[dev][i]) != hipSuccess) { (void)hipGetLastError(); wait_for = r.ev[dev][i]; }
+    } else if (!r.ev[dev][i]) {
+      if (hipEventCreateWithFlags(&r.ev[dev][i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return out; }
+    }
+    out.counters = r.mem[dev] + (size_t)kSlotInts * i;
+    out.index = i;
   }
-  out.counters = r.mem[dev] + (size_t)kSlotInts * i;
-  out.index = i;
+  if (wait_for && hipEventSynchronize(wait_for) != hipSuccess) {      // still in flight (or unknown): wait for that launch
+    (void)hipGetLastError();
+    out.counters = nullptr;
+  }
   return out;
 }
 // behind the launch that uses the slot, on the launch's stream

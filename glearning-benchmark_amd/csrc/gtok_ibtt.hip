@@ -793,6 +793,19 @@ struct VocabTextArgs {
   int units, upb;
 };
 
+// Two tokens are the same token when their BYTES agree, not merely their 64-bit identity and length: every merge of an
+// occurrence into a slot compares the occurrence with the slot's recorded first occurrence, byte for byte, wherever that
+// one lies inside the blob of THIS launch (a `first` left by another shard's launch cannot be read here).  A mismatch -
+// a hash collision - raises status bit 2 (value 4): the table would have dropped a token silently.
+__device__ __forceinline__ bool vocab_text_same(const VocabTextArgs &a, unsigned long long p, unsigned long long q, unsigned int ln) {
+  const unsigned long long lo = (unsigned long long)a.base_offset, hi = lo + (unsigned long long)a.text_ptr[a.num_texts];
+  if (p == q || p < lo || p >= hi || q < lo || q >= hi) return true;
+  const uint8_t *x = a.bytes + (p - lo), *y = a.bytes + (q - lo);
+  for (unsigned int i = 0; i < ln; ++i)
+    if (x[i] != y[i]) return false;
+  return true;
+}
+
 __device__ __forceinline__ void vocab_text_global_add(const VocabTextArgs &a, unsigned long long k, unsigned int ln,
                                                       unsigned long long cnt, unsigned long long fst) {
   const unsigned int mask = (unsigned int)a.capacity - 1u;
@@ -810,7 +823,8 @@ __device__ __forceinline__ void vocab_text_global_add(const VocabTextArgs &a, un
       if (l2 == 0) { atomicOr(a.status, 2); return; }   // never seen in practice: the claimant's length did not arrive
       if (l2 == (int)ln) {
         atomicAdd(a.count + slot, cnt);
-        atomicMin(a.first + slot, fst);
+        const unsigned long long seen = atomicMin(a.first + slot, fst);
+        if (seen != ~0ull && seen != 0x7FFFFFFFFFFFFFFFull && !vocab_text_same(a, seen, fst, ln)) atomicOr(a.status, 4);
         return;
       }
     }
@@ -869,7 +883,12 @@ __global__ void __launch_bounds__(256) vocab_stats_text_kernel(const VocabTextAr
           if (old == k) {
             unsigned int l2 = __hip_atomic_load(llen + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             for (int spin = 0; l2 == 0u && spin < 100000; ++spin) l2 = __hip_atomic_load(llen + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (l2 == ln) { atomicAdd(lcount + slot, 1u); atomicMin(lfirst + slot, pos); placed = true; }
+            if (l2 == ln) {
+              atomicAdd(lcount + slot, 1u);
+              const unsigned long long seen = atomicMin(lfirst + slot, pos);
+              if (seen != ~0ull && !vocab_text_same(a, seen, pos, ln)) atomicOr(a.status, 4);
+              placed = true;
+            }
           }
         }
         if (!placed) vocab_text_global_add(a, k, ln, 1ull, pos);   // crowded neighbourhood of the small table: straight to the global one
@@ -1701,7 +1720,7 @@ extern "C" int gtok_ibtt_zinc(const gtok_csr *g, const int32_t *lut, int32_t lut
         if (nb > z.units) nb = z.units;
         const gtok::QueueSlot slot = gtok::take_queue_slot(dev, (hipStream_t)stream);
         z.queue = slot.counters;
-        if (!z.queue) return GTOK_E_LAUNCH;
+        if (!z.queue) return slot.graph_pool_empty ? GTOK_E_GRAPH_SLOTS : GTOK_E_LAUNCH;
         z.out = out_ids; z.ld = ld; z.out_len = out_len;
         hipLaunchKernelGGL(ibtt_zinc_lane_kernel, dim3(nb), dim3(64), (size_t)z.lds, (hipStream_t)stream, z);
         gtok::mark_queue_slot(slot, (hipStream_t)stream);

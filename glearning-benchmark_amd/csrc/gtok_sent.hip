@@ -267,7 +267,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     if (nb > a.units) nb = a.units;
     slot = take_queue_slot(dev, (hipStream_t)stream);
     a.queue = slot.counters;
-    if (!a.queue) return GTOK_E_LAUNCH;
+    if (!a.queue) return slot.graph_pool_empty ? GTOK_E_GRAPH_SLOTS : GTOK_E_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(nb), dim3(wpb * 64), lds, (hipStream_t)stream, a);
   mark_queue_slot(slot, (hipStream_t)stream);

@@ -111,6 +111,7 @@ def sent_safe_ld(batch: GraphBatch, labeled: bool, max_len: int, with_query: boo
     return (min(max_len, bound) + (3 if with_query else 0) + 15) // 16 * 16
 
 
+LANE_MIN_GRAPHS = 28000       # = GTOK_LANE_MIN_GRAPHS of gtok_sent.hip: from here on the molecule lane kernel takes small symmetric graphs
 ADJBITS_MIN_GRAPHS = 20000    # = GTOK_BLANE_MIN_GRAPHS of gtok_sent.hip: below it gtok_sent never picks the bit-matrix lane kernel
 
 
@@ -280,9 +281,19 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
         ld = sent_safe_ld(batch, labeled, max_len, query is not None)
     ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
     pack8(batch)
-    if not labeled and not remap_zinc and batch.num_graphs >= ADJBITS_MIN_GRAPHS or os.environ.get("GTOK_SENT_KERNEL") == "blane":
-        if adjbits(batch) and os.environ.get("GTOK_BLANE_ORDER", "1") != "0" and batch.lane_order_len != max(1, max_len):
-            batch.lane_order, batch.lane_order_len = _lane_order(batch, max(1, max_len)), max(1, max_len)   # once per (batch, max_len)
+    pin = os.environ.get("GTOK_SENT_KERNEL", "")
+    # the bit-matrix mirror is only built where gtok_sent would pick the kernel that reads it: unlabelled batches of
+    # >= ADJBITS_MIN_GRAPHS graphs that the molecule kernel (<= 64 nodes, simple symmetric, >= LANE_MIN_GRAPHS) does not
+    # take - and never again for a batch that turned out unusable (a closure degree above 255)
+    lane_takes = batch.max_nodes <= 64 and batch.max_edges <= 255 and bool(batch.flags & _lib.CSR_SIMPLE_SYMMETRIC) \
+        and batch.num_graphs >= LANE_MIN_GRAPHS
+    wants_blane = pin == "blane" or (not pin and not labeled and not remap_zinc and batch.num_graphs >= ADJBITS_MIN_GRAPHS and not lane_takes)
+    if wants_blane and not batch.adj_unusable:
+        if adjbits(batch):
+            if os.environ.get("GTOK_BLANE_ORDER", "1") != "0" and batch.lane_order_len != max(1, max_len):
+                batch.lane_order, batch.lane_order_len = _lane_order(batch, max(1, max_len)), max(1, max_len)   # once per (batch, max_len)
+        elif batch.col.device.type == "cuda" and batch.max_nodes <= 256 and os.environ.get("GTOK_NO_ADJBITS") != "1":
+            batch.adj_unusable = True
     p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc),
                        pad_id, 0 if pad else _lib.SENT_NO_PAD, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
                        None if query is None else query.data_ptr())
@@ -552,7 +563,10 @@ def vocab_stats_text(text_bytes: torch.Tensor, text_ptr: torch.Tensor, capacity:
     (trainer/train_ibtt.py:361-372) on the device.  Returns the open-addressing table as device tensors
     {key uint64-as-int64, count, first int64, len int32, status int32 [1]} of `capacity` slots; pass it back as `out`
     to accumulate further shards (base_offset = the shard's byte offset in the whole corpus).  text_stats_entries()
-    turns a finished table into (token, count, first) triples."""
+    turns a finished table into (token, count, first) triples.  Tokens are told apart by a 64-bit hash AND verified byte
+    for byte against the slot's first occurrence (status bit 2 = a collision; text_stats_entries raises) - within one
+    call; with shards accumulated over several calls a cross-shard collision is not seen, and text_stats_entries needs
+    the WHOLE corpus blob, since a slot's `first` may lie in any shard."""
     _need_gpu(text_bytes, "vocab_stats_text")
     dev = text_bytes.device
     text_ptr = text_ptr.to(dev, dtype=torch.int64).contiguous()
@@ -577,6 +591,9 @@ def text_stats_entries(table: Dict[str, torch.Tensor], text_bytes: torch.Tensor,
     descending, first appearance ascending).  The token strings are read back from the corpus blob at `first`
     (only the table and one byte range per DISTINCT token cross to the host).  Raises when the table overflowed."""
     st = int(table["status"].item())
+    if st & 4:
+        raise _lib.GtokError("vocab_stats_text: two different tokens share a 64-bit identity (hash collision): "
+                             "build this vocab with the host function (build_vocab_from_texts)")
     if st:
         raise _lib.GtokError(f"vocab_stats_text: table {'overflowed' if st & 1 else 'was not consistent'} (status {st}): use a larger capacity")
     used = (table["key"] != 0).nonzero(as_tuple=True)[0]

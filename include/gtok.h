@@ -78,6 +78,9 @@ extern "C" {
 #define GTOK_E_TOO_LARGE (-2) /* a graph exceeds the LDS-resident limits        */
 #define GTOK_E_LAUNCH (-3)    /* hipLaunchKernel reported an error              */
 #define GTOK_E_NO_DEVICE (-4) /* no gfx950 device visible                       */
+#define GTOK_E_GRAPH_SLOTS (-5) /* a launch captured into a hipGraph needed a reserved block of work-queue counters and all 64
+                                   per device are taken: the ticket-scheduled kernels ("sent_lds_kernel", "ibtt_zinc_lane_kernel")
+                                   keep one for the life of the process per CAPTURED launch - capture once and replay        */
 
 #define GTOK_MAX_NODES 512 /* SENT adjacency bit-matrix rows per wave (LDS)  */
 
@@ -343,7 +346,12 @@ int gtok_vocab_stats_synth(const gtok_csr *g, const int32_t *query_nodes,
  *   len[s]   token length in bytes  -> the token string is bytes[first - base_offset : .. + len]
  * The caller zeroes key / count / len and sets first to INT64_MAX; calls ACCUMULATE (shards: pass the shard's
  * offset in the whole corpus as base_offset so that `first` keeps ordering occurrences corpus-wide).  status
- * (zeroed by the caller) gets bit 0 when the table overflowed: enlarge and repeat.  Counter.most_common order =
+ * (zeroed by the caller) gets bit 0 when the table overflowed: enlarge and repeat; bit 2 (value 4) when two DIFFERENT
+ * tokens met in one slot (same 64-bit identity and length, different bytes: every merge compares the occurrence with
+ * the slot's first occurrence byte for byte) - the table is then not a token table and must be discarded.  The byte
+ * check reaches occurrences inside the blob of the call at hand only: when shards are accumulated by several calls,
+ * a collision between tokens of two different shards goes unseen, and reading the strings back needs the whole corpus
+ * (a slot's `first` may lie in another shard).  Counter.most_common order =
  * count descending, then `first` ascending.                                                                    */
 int gtok_vocab_stats_text(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts, int64_t base_offset,
                           int32_t capacity, uint64_t *key, int64_t *count, int64_t *first, int32_t *len,
