@@ -183,6 +183,11 @@ def boundary_section(d, G, dev, max_nodes, max_len):
 
 
 def main():
+    # ONE JSON line on stdout: native libraries write there too (RCCL prints its version banner at init), so file
+    # descriptor 1 points at stderr for the whole run and the line goes out through a private copy of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -272,6 +277,7 @@ def main():
                             args.steps, multi, per_launch_events=False)
         nopad_ms = float(np.mean(npm))
 
+    log(f"[bench] timed region done: {wall / args.steps * 1e3:.4f} ms per step")
     # sustained: >= 1 s of back-to-back launches (clocks, L2 / MALL state of a slab rewritten in place), one event pair around all
     sustained = None
     if not args.no_sustained:
@@ -401,6 +407,7 @@ def main():
         out["unpadded_rows"] = dict(ms_per_step=round(nopad_ms, 4), graphs_per_sec=round(G / nopad_ms * 1e3, 1),
                                     note="GTOK_SENT_NO_PAD: tokens only, pad tails of the slab not written")
 
+    log("[bench] headline assembled; secondary legs follow")
     # IBTT serialiser on the same corpus (second half of the metric; outside the timed region)
     if not args.no_ibtt:
         if zinc:
@@ -506,6 +513,7 @@ def main():
 
     # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
     if multi:
+        log("[bench] all-gather legs")
         gtok.dist.gather_tokens(ids, lens[-1], world * G, 5, force=True)
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
@@ -535,12 +543,20 @@ def main():
         sids = torch.empty((hi - lo, ld), dtype=torch.int32, device=dev)
         sln = torch.empty((hi - lo,), dtype=torch.int32, device=dev)
 
+        gstats = {}
+
         def sstep(k, gather):
             gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(sids, sln), **kws)
-            if gather:
-                return gtok.dist.gather_tokens(sids, sln, Gt, 5, force=True)
+            if gather == "padded":
+                return gtok.dist.gather_tokens(sids, sln, Gt, 5, force=True, stats=gstats.setdefault("padded", {}))
+            if gather == "compact":    # capacity = the first epoch's largest rank + 2 %: no size exchange, no host round trip
+                return gtok.dist.gather_tokens(sids, sln, Gt, 5, force=True, compact=True, capacity=gstats.get("cap"),
+                                               stats=gstats.setdefault("compact", {}))
         res = {}
-        for gather in (False, True):
+        for gather in (None, "padded", "compact"):
+            if gather == "compact":
+                sstep(0, gather)                              # sized by an all-reduce once ...
+                gstats["cap"] = int(gstats["compact"]["capacity"] * 1.02) + 64      # ... then a fixed bound
             for w in range(args.warmup):
                 sstep(w, gather)
             swall, _ = timed_loop(lambda k: sstep(args.warmup + k, gather), args.steps, True)
@@ -549,12 +565,22 @@ def main():
             res[gather] = float(tm.item())
         if int(sln.max().item()) > ld:
             raise SystemExit("strong-scaling leg: slab too narrow")
+        # the compact exchange must give the padded one's slab (checked on the last epoch's buffers)
+        p_ids, p_ln = sstep(args.warmup, "padded")
+        c_ids, c_ln = sstep(args.warmup, "compact")
+        same = bool(torch.equal(p_ids, c_ids) and torch.equal(p_ln, c_ln)) and int(gstats["compact"]["status"].item()) == 0
+        per_step = lambda t: round(t / args.steps * 1e3, 4)
         out["strong_scaling"] = dict(
             workload=f"one {Gt}-graph corpus block-sharded x{world} (graphs_per_gpu {hi - lo}), kernel {gtok.ops.sent_kernel_name(mine, max_nodes, max_len, labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True)}",
-            tokenize_graphs_per_sec=round(Gt * args.steps / res[False], 1), tokenize_ms_per_step=round(res[False] / args.steps * 1e3, 4),
-            tokenize_and_allgather_graphs_per_sec=round(Gt * args.steps / res[True], 1),
-            tokenize_and_allgather_ms_per_step=round(res[True] / args.steps * 1e3, 4),
-            gathered_slab_bytes=int(Gt) * (ld + 1) * 4)
+            tokenize_graphs_per_sec=round(Gt * args.steps / res[None], 1), tokenize_ms_per_step=per_step(res[None]),
+            tokenize_and_allgather_graphs_per_sec=round(Gt * args.steps / res["compact"], 1),
+            tokenize_and_allgather_ms_per_step=per_step(res["compact"]),
+            exchange="compact: packed 16-bit rows + lengths over RCCL, re-padded locally (dist.gather_tokens(compact=True))",
+            compact=dict(ms_per_step=per_step(res["compact"]), exchange_ms=per_step(res["compact"] - res[None]),
+                         bytes_sent_per_rank=gstats["compact"]["bytes_sent_per_rank"], bytes_gathered_per_rank=world * gstats["compact"]["bytes_sent_per_rank"]),
+            padded=dict(ms_per_step=per_step(res["padded"]), exchange_ms=per_step(res["padded"] - res[None]),
+                        bytes_sent_per_rank=gstats["padded"]["bytes_sent_per_rank"], bytes_gathered_per_rank=world * gstats["padded"]["bytes_sent_per_rank"]),
+            compact_equals_padded=same, gathered_slab_bytes=int(Gt) * (ld + 1) * 4)
         if args.scaling == "strong":      # make the configured workload the headline of this run
             out.update(value=out["strong_scaling"]["tokenize_and_allgather_graphs_per_sec"], scaling="strong",
                        ms_per_step=out["strong_scaling"]["tokenize_and_allgather_ms_per_step"])
@@ -616,8 +642,10 @@ def main():
                                                sample=f"first {S} graphs of the same corpus, oracle/gtok_oracle.c:oracle_ibtt_zinc "
                                                       f"(OpenMP, {cores} threads), {reps_i} passes",
                                                tokens_per_sec=round(float(irln.sum()) / icpu, 1), parity_with_gpu=bool(isame))
+    log("[bench] done")
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if multi:
         dist.destroy_process_group()
 

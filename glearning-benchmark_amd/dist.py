@@ -48,7 +48,8 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     compact=True moves the PACKED form over the links instead of the padded slab (include/gtok.h, "packed rows"): every
     rank packs its rows back to back at `elem_bytes` (2: every SENT / IBTT id fits 16 bits; 4 otherwise) per id
     (gtok_pack_rows), the packed buffers - sized to the largest rank's total, one all_reduce(MAX) of an int, or to
-    `capacity` elements when the caller knows a bound - and the lengths are gathered, and every rank re-pads locally at
+    `capacity` elements when the caller knows a bound (then nothing waits for the host; stats["status"] is a device tensor
+    that is nonzero when a rank's rows did not fit or an id needed more than 16 bits) - and the lengths are gathered, and every rank re-pads locally at
     HBM speed (gtok_unpack_rows).  More than half of a ZINC slab is padding and ids are 32 bits wide there: 208 MB per
     corpus become ~46 MB.  Same result as the padded path, bit for bit.  rows_impl: the module providing row_offsets /
     pack_rows / unpack_rows (default: ops, i.e. the HIP kernels; the CPU tests of the collective pass the oracle's).
@@ -74,10 +75,16 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     if rows_impl is None:
         from . import ops as rows_impl
     row_ptr = rows_impl.row_offsets(ln, ld)
+    status = None
     if capacity is None:
         capacity = all_reduce_max_int(int(row_ptr[-1]), ids.device)
-    capacity = max(8, -(-int(capacity) // 8) * 8)           # keeps every rank's segment 16-byte aligned
-    packed, _ = rows_impl.pack_rows(ids, ln, row_ptr, elem_bytes, capacity=capacity)
+        capacity = max(8, -(-int(capacity) // 8) * 8)       # keeps every rank's segment 16-byte aligned
+        packed, _ = rows_impl.pack_rows(ids, ln, row_ptr, elem_bytes, capacity=capacity)
+    else:
+        # a caller-given bound (e.g. last epoch's size plus a margin): no size exchange and no host round trip at all -
+        # a rank whose rows do not fit raises status bit 1 on the device; the caller reads stats["status"] when it likes
+        capacity = max(8, -(-int(capacity) // 8) * 8)
+        packed, _, status = rows_impl.pack_rows(ids, ln, row_ptr, elem_bytes, capacity=capacity, check_status=False)
     all_packed = torch.empty(world * capacity, dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(all_packed.view(torch.uint8), packed.view(torch.uint8))   # bytes: every backend moves uint8
     dist.all_gather_into_tensor(all_ln, ln)
@@ -85,7 +92,7 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     all_ids = rows_impl.unpack_rows(all_packed, all_ptr, all_ln, ld, pad_id, segment_rows=per, segment_stride=capacity)
     if stats is not None:
         stats.update(bytes_sent_per_rank=packed.numel() * packed.element_size() + ln.numel() * 4, compact=True,
-                     elem_bytes=elem_bytes, capacity=capacity)
+                     elem_bytes=elem_bytes, capacity=capacity, status=status)
     return all_ids[:num_graphs], all_ln[:num_graphs]
 
 

@@ -25,10 +25,11 @@ class _OracleRows:
         return torch.from_numpy(orc.row_offsets(ln.numpy(), ld, align))
 
     @staticmethod
-    def pack_rows(ids, ln, row_ptr, elem_bytes=2, capacity=None):
+    def pack_rows(ids, ln, row_ptr, elem_bytes=2, capacity=None, check_status=True):
         packed, ptr = orc.pack_rows(ids.numpy(), ln.numpy(), ids.shape[1], elem_bytes, capacity=capacity, fill=0x7ABC)
         assert np.array_equal(ptr, row_ptr.numpy())
-        return torch.from_numpy(packed.view(np.int16) if elem_bytes == 2 else packed), row_ptr
+        out = (torch.from_numpy(packed.view(np.int16) if elem_bytes == 2 else packed), row_ptr)
+        return out if check_status else out + (torch.zeros(1, dtype=torch.int32),)
 
     @staticmethod
     def unpack_rows(packed, row_ptr, ln, ld, pad_id, segment_rows=0, segment_stride=0):
@@ -59,6 +60,9 @@ def _worker(rank, world, port, G, q):
                                                   elem_bytes=eb, rows_impl=_OracleRows, stats=st)
             ok = ok and torch.equal(c_ids, full_ids) and torch.equal(c_ln, full_ln) and st["compact"] \
                 and st["bytes_sent_per_rank"] < ids.size * 4 * (0.4 if eb == 2 else 0.7)
+            k_ids, k_ln = gtok.dist.gather_tokens(torch.from_numpy(ids), torch.from_numpy(ln), G, 5, compact=True, elem_bytes=eb,
+                                                  capacity=st["capacity"] + 40, rows_impl=_OracleRows, stats=st)
+            ok = ok and torch.equal(k_ids, full_ids) and int(st["status"]) == 0
         # corpus-wide vocab statistics from per-rank tables (SUM / MIN all-reduce)
         s = gtok.synth.graph_token_like(G, seed=78, with_text=False)
         sc = orc.Coo(s["node_counts"], s["edge_counts"], s["src"], s["dst"])
