@@ -39,6 +39,8 @@ for wl in ("zinc_full", "synth_er", "synth_mix", "zinc_subset"):
         if leg:
             key = f"{leg}:{wl}:{G}:{mode}" if leg == "sent" else f"{leg}:{wl}:{G}"
             label = bench["roofline"]["kernel"] if leg == "sent" else bench.get("ibtt", {}).get("kernel")
+            if not label or label.split("<")[0] not in k:      # another kernel of the same leg (the no-mirror run, decode): not the one the line reports
+                continue
             traffic[key] = {"hbm_bytes_per_launch": c["hbm_bytes_per_launch"], "kernel": k.replace("void ", ""),
                             "kernel_label": label, "commit": commit, "source": f"{dst}/pmc_summary_{wl}_final.json"}
 json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
