@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None, help="graphs in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ibtt", action="store_true")
+    ap.add_argument("--rows", default="padded", choices=["padded", "unpadded"],
+                    help="unpadded: the timed step itself runs with GTOK_SENT_NO_PAD (counter passes of that flavour; the headline stays 'padded')")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 1 s back-to-back leg")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary section (call-site throughput through the Dataset classes)")
     ap.add_argument("--no-unpadded", action="store_true", help="skip the GTOK_SENT_NO_PAD leg (profiling runs: one launch flavour per kernel name)")
@@ -255,7 +257,7 @@ def main():
     scratch_len = torch.empty((G,), dtype=torch.int32, device=dev)
 
     def step(k, ln):
-        gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(ids, ln), **kw)
+        gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(ids, ln), pad=args.rows == "padded", **kw)
 
     for w in range(args.warmup):
         step(w, scratch_len)
@@ -271,12 +273,20 @@ def main():
     wall = float(tmax.item())
     # beside the headline: the same steps with GTOK_SENT_NO_PAD (rows written up to their length only - what
     # TokenizedGraphDataset uses, its readers go through `len`); not the headline because the C ABI's documented output is the padded slab
-    nopad_ms = None
+    nopad_ms = ragged = None
     if zinc and not args.no_unpadded:
         _, npm = timed_loop(lambda k: gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=args.warmup + k, ld=ld, out=(ids, scratch_len), pad=False, **kw),
                             args.steps, multi, per_launch_events=False)
         nopad_ms = float(np.mean(npm))
-
+        # ragged rows: tokens only (no pad tails) + one pass that packs them back to back (row_ptr + ids, 4 bytes each) -
+        # the form gtok_collate_packed / the compact all-gather / the D2H copy of an epoch read
+        def ragged_step(k):
+            gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=args.warmup + k, ld=ld, out=(ids, scratch_len), pad=False, **kw)
+            ptr = gtok.ops.row_offsets(scratch_len, ld)
+            return gtok.ops.pack_rows(ids, scratch_len, ptr, elem_bytes=4, capacity=G * ld, check_status=False)
+        ragged_step(0)
+        _, rgm = timed_loop(ragged_step, args.steps, multi, per_launch_events=False)
+        ragged = float(np.mean(rgm))
     log(f"[bench] timed region done: {wall / args.steps * 1e3:.4f} ms per step")
     # sustained: >= 1 s of back-to-back launches (clocks, L2 / MALL state of a slab rewritten in place), one event pair around all
     sustained = None
@@ -390,7 +400,7 @@ def main():
                steps=args.steps, warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 4),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
                tokens_per_sec=round(tokens_per_sec, 1),
-               config=dict(workload=f"{args.workload}: {wl['desc']}", graphs_per_gpu=G, max_len=max_len,
+               config=dict(workload=f"{args.workload}: {wl['desc']}" + ("" if args.rows == "padded" else " [GTOK_SENT_NO_PAD rows]"), graphs_per_gpu=G, max_len=max_len,
                            slab_width=ld, slab_width_mode=args.ld, avg_tokens_per_graph=round(tokens_per_step_rank / G, 2),
                            parallelism=f"graph-sharded x{world}, no data-path collective"),
                roofline=roofline)
@@ -406,6 +416,9 @@ def main():
     if nopad_ms is not None:
         out["unpadded_rows"] = dict(ms_per_step=round(nopad_ms, 4), graphs_per_sec=round(G / nopad_ms * 1e3, 1),
                                     note="GTOK_SENT_NO_PAD: tokens only, pad tails of the slab not written")
+        out["ragged_rows"] = dict(ms_per_step=round(ragged, 4), graphs_per_sec=round(G / ragged * 1e3, 1),
+                                  note="GTOK_SENT_NO_PAD + gtok_row_offsets + gtok_pack_rows (int32): rows back to back behind row_ptr, "
+                                       "what gtok_collate_packed reads")
 
     log("[bench] headline assembled; secondary legs follow")
     # IBTT serialiser on the same corpus (second half of the metric; outside the timed region)

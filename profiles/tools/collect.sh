@@ -26,6 +26,10 @@ for wl in zinc_full synth_er synth_mix zinc_subset; do
     step prof $out/pmc_${wl}_$name.log timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex gtok --output-format csv -d $out/pmc_${wl}_$name -o p -- python3 bench.py --steps 5 --warmup 1 --workload $wl --no-cpu-baseline --no-unpadded --no-boundary --no-sustained
   done
 done
+# the tokens-only flavour of the headline kernel (GTOK_SENT_NO_PAD): what reaches the L2's memory side when no pad tail is written
+for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+  step prof $out/pmc_nopad_$grp.log timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex sent_lane --output-format csv -d $out/pmc_nopad_$grp -o p -- python3 bench.py --steps 5 --warmup 1 --rows unpadded --no-cpu-baseline --no-unpadded --no-boundary --no-sustained --no-ibtt
+done
 # keep what collect_merge.py reads: our kernels' counter rows and the stats tables (gpurun returns <= 64 MiB)
 find $out -name '*_kernel_trace.csv' -delete; find $out -name '*_agent_info.csv' -delete
 python3 - $out <<'PY'
