@@ -36,24 +36,33 @@ struct __attribute__((aligned(4))) U32x2a4 { uint32_t lo, hi; };   // two dwords
 
 // k-th (0-based) set bit of w, per lane, k < popcount(w): branch-free halving on popcounts.  (A clear-lowest-bit
 // loop runs max-over-lanes(k) times for the whole wave; picks from `live` have k up to the molecule's size.)
-__device__ __forceinline__ int kth_bit64(uint64_t w, int k) {
-  uint32_t x = (uint32_t)w;
-  int base = 0, c = __popc(x);
-  if (k >= c) { k -= c; x = (uint32_t)(w >> 32); base = 32; }
-  c = __popc(x & 0xFFFFu); if (k >= c) { k -= c; x >>= 16; base += 16; }
-  c = __popc(x & 0xFFu);   if (k >= c) { k -= c; x >>= 8;  base += 8; }
-  c = __popc(x & 0xFu);    if (k >= c) { k -= c; x >>= 4;  base += 4; }
-  c = __popc(x & 0x3u);    if (k >= c) { k -= c; x >>= 2;  base += 2; }
-  return base + ((k >= (int)(x & 1u)) ? 1 : 0);
+// Binary search on prefix popcounts, five instructions per level and no compare: with nk = -k - 1,
+// v_bcnt_u32_b32(low `mid` bits of x, nk) = popcount - k - 1 is negative exactly when the k-th bit lies at or above `mid`;
+// its sign, spread over the word, ORs the level's bit into the answer.  (The halving version - mask, popcount, compare, two
+// selects, subtract per level - was 7 per level and serialised on VCC.)
+__device__ __forceinline__ int kth_bit32(uint32_t x, int k) {
+  const uint32_t nk = ~(uint32_t)k;                       // -k - 1
+  uint32_t base = 0;
+#pragma unroll
+  for (uint32_t half = 16; half >= 1; half >>= 1) {
+    // (written out: left to itself the compiler turns the sign trick back into compare + select, with VCC hazard nops)
+    uint32_t mid, t, d;
+    asm("v_or_b32 %0, %3, %4\n\t"
+        "v_bfe_u32 %1, %5, 0, %0\n\t"
+        "v_bcnt_u32_b32 %2, %1, %6\n\t"
+        "v_ashrrev_i32 %2, 31, %2\n\t"
+        "v_and_or_b32 %0, %2, %4, %3"
+        : "=&v"(mid), "=&v"(t), "=&v"(d) : "v"(base), "n"(half), "v"(x), "v"(nk));
+    base = mid;
+  }
+  return (int)base;
 }
 
-__device__ __forceinline__ int kth_bit32(uint32_t x, int k) {
-  int base = 0, c = __popc(x & 0xFFFFu);
-  if (k >= c) { k -= c; x >>= 16; base = 16; }
-  c = __popc(x & 0xFFu);   if (k >= c) { k -= c; x >>= 8;  base += 8; }
-  c = __popc(x & 0xFu);    if (k >= c) { k -= c; x >>= 4;  base += 4; }
-  c = __popc(x & 0x3u);    if (k >= c) { k -= c; x >>= 2;  base += 2; }
-  return base + ((k >= (int)(x & 1u)) ? 1 : 0);
+__device__ __forceinline__ int kth_bit64(uint64_t w, int k) {
+  const uint32_t lo = (uint32_t)w;
+  const int c = __popc(lo);
+  const bool up = k >= c;
+  return kth_bit32(up ? (uint32_t)(w >> 32) : lo, up ? k - c : k) + (up ? 32 : 0);
 }
 
 // 16-byte-vector staging of a byte array into LDS: lane_load16 issues the first U vectors of the lane, lane_commit16
@@ -515,7 +524,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
           const int pick = kth_bit_of(set, (int)below((uint32_t)popc_of(set)));
           uint32_t et = 0;
           if (LAB && kind == 0) et = find_et(rc, (uint32_t)pick);   // type of the listed entry cur -> pick
-          const Row rn = load_row(pick);
+          rc = load_row(pick);                                 // in place: the old row is not needed past find_et above
           const uint32_t xb = snat[nbase + pick];              // node type (first visit) or visit index (kind 1)
           const bool first = kind != 1;
           const uint32_t my = (uint32_t)nvis;
@@ -538,7 +547,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
           }
           // ---- first visit: neighbours lose an unvisited neighbour; already visited neighbours other than the
           // trail's predecessor are this node's bracket
-          const set_t S = first ? rn.mask : (set_t)0;
+          const set_t S = first ? rc.mask : (set_t)0;
           set_t M = S & vis & ~(kind == 0 ? bit_of((uint32_t)cur) : (set_t)0);
           {
             set_t b = S, nz = 0;
@@ -563,7 +572,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
               uint32_t lo = (uint32_t)(pos_base + bv), hi = 0;
               int cnt = 1;
               if (LAB) {
-                const uint32_t at = find_et(rn, (uint32_t)bu);
+                const uint32_t at = find_et(rc, (uint32_t)bu);
                 lo = (remap ? remap_edge_type_u(at, (uint32_t)edge_off) : (uint32_t)edge_off + at) | (lo << 16);
                 cnt = 2;
               }
@@ -573,7 +582,6 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
               append(val, cnt);
             } while (M);
           }
-          rc = rn;
           cur = pick;
         }
       }

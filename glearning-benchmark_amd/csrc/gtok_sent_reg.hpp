@@ -70,11 +70,12 @@ __device__ __forceinline__ int remap_edge_type(int at, int edge_off) { return at
 
 // unsigned forms (token fields are packed with 32-bit operations; a signed int would be sign-extended first)
 __device__ __forceinline__ uint32_t remap_node_type_u(uint32_t x, uint32_t node_off, uint32_t ntypes) {
-  const uint32_t b = x - ntypes;
-  uint32_t r = 22u + node_off + x;
-  r = (x < ntypes && x < 9u) ? 8u + x : r;
-  r = (x >= ntypes && b < 4u) ? 17u + b : r;
-  return r;
+  // x + offset of its range: atoms [0, min(ntypes, 9)) -> 8 + x, the next four ids (they read as bonds) -> 17 + (x - ntypes),
+  // everything else 22 + token.  One unsigned compare per range (x - ntypes wraps for x < ntypes), then one add.
+  uint32_t off = 22u + node_off;
+  off = (x - ntypes) < 4u ? 17u - ntypes : off;
+  off = x < (ntypes < 9u ? ntypes : 9u) ? 8u : off;
+  return x + off;
 }
 __device__ __forceinline__ uint32_t remap_edge_type_u(uint32_t at, uint32_t edge_off) { return at < 4u ? 17u + at : 22u + edge_off + at; }
 

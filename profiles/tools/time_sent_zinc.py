@@ -15,10 +15,10 @@ for nosort in ("1", "0"):
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for k in range(20): gtok.ops.sent(b, 37, 1024, 0, k, ld=208, out=(ids, ln), **kw)
+    for k in range(200): gtok.ops.sent(b, 37, 1024, 0, k, ld=208, out=(ids, ln), **kw)
     e.record(); torch.cuda.synchronize()
     sb = b.lane_sorted
-    print(f"sorted={nosort == '0'} units {sb.num_units if sb is not None else (b.num_graphs + 63) // 64} chunk {(sb or b).chunk_nodes}/{(sb or b).chunk_edges}: {s.elapsed_time(e)/20:.4f} ms", flush=True)
+    print(f"sorted={nosort == '0'} units {sb.num_units if sb is not None else (b.num_graphs + 63) // 64} chunk {(sb or b).chunk_nodes}/{(sb or b).chunk_edges}: {s.elapsed_time(e)/200:.4f} ms", flush=True)
     if ref is None: ref = (ids.clone(), ln.clone())
     else: assert torch.equal(ref[0], ids) and torch.equal(ref[1], ln), "sorted and unsorted runs differ"
 print("same tokens")
