@@ -454,7 +454,11 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     for (int j = 0; j < SG - 1; ++j) pg[j] = 0;
     auto tok_of = [](uint64_t w, int i) __attribute__((always_inline)) -> int { return (int)((w >> (i << 4)) & 0xFFFFu); };
     auto put4 = [&](int at, uint64_t w) __attribute__((always_inline)) {
+#ifndef GTOK_ABLATE_STORES   // (profiling builds, profiles/tools/lane_ablate.sh: a phase is cut out - wrong tokens - and the time it took shows)
       *reinterpret_cast<I32x4 *>(orow + at) = I32x4{tok_of(w, 0), tok_of(w, 1), tok_of(w, 2), (int)(w >> 48)};
+#else
+      if (w == 0x123456789ABCDEFull) orow[at] = 1;
+#endif
     };
     auto group_of = [&](int j, uint64_t w) __attribute__((always_inline)) -> uint64_t {   // group j of the open burst (j = SG-1: w)
       uint64_t r = w;
@@ -495,7 +499,11 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       const int w = uni(d) & 3;
       if (w == 0) {
         uint32_t o[4];
+#ifndef GTOK_ABLATE_PHILOX
         philox4x32_10((uint32_t)(d >> 2), epoch, gid_lo, gid_hi, k0, k1, o);
+#else
+        o[0] = (uint32_t)d * 2654435761u + gid_lo; o[1] = o[0] ^ k0; o[2] = o[0] + k1; o[3] = o[1] + epoch;
+#endif
         pw0 = o[0]; pw1 = o[1]; pw2 = o[2]; pw3 = o[3];
       }
       const uint32_t x = w == 0 ? pw0 : (w == 1 ? pw1 : (w == 2 ? pw2 : pw3));
@@ -521,7 +529,11 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
           const int kind = row ? 0 : (live ? 1 : 2);
           if (kind == 2 && nvis >= n) break;
           const set_t set = kind == 0 ? row : (kind == 1 ? live : (set_t)(~vis & nodes));
+#ifndef GTOK_ABLATE_PICK
           const int pick = kth_bit_of(set, (int)below((uint32_t)popc_of(set)));
+#else
+          const int pick = ctz_of(set) + (int)(below((uint32_t)popc_of(set)) >> 31);
+#endif
           uint32_t et = 0;
           if (LAB && kind == 0) et = find_et(rc, (uint32_t)pick);   // type of the listed entry cur -> pick
           rc = load_row(pick);                                 // in place: the old row is not needed past find_et above
@@ -557,6 +569,9 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
             live = vis & nz;
           }
           nvis += first;
+#ifdef GTOK_ABLATE_BRACKET
+          M = 0;
+#endif
           if (M) {   // LADJ, members by ascending visit index ([edge type] position), RADJ
             bool head = true;
             do {
