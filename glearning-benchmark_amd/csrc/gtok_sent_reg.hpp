@@ -189,7 +189,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       x = w == 0 ? o[0] : x;
       return x;
     };
+#ifdef GTOK_ABLATE_REG_PHILOX
+    uint32_t R = (uint32_t)lane * 2654435761u + gid_lo;
+#else
     uint32_t R = draws(0);
+#endif
     wave_sync();
     // ---- undirected=True: own row in a register, transposed bits through LDS atomics.  The adjacency is
     // never modified afterwards: for a visited node c the uncovered edges are exactly adj[c] & ~vis.
@@ -312,7 +316,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     };
 
     if (is0) tok[0] = GTOK_SENT_SOS;   // SOS -> <bos>: 0 either way
+#ifdef GTOK_ABLATE_REG_WALK   // (profiling builds: no walk - what is left is the per-molecule fixed cost)
+    if (n > 1000) {
+#else
     if (n > 0) {
+#endif
       start_at((int)below((uint32_t)n));
       for (;;) {
         // extend the trail while the current node has an uncovered edge (it always leads to an unvisited node)

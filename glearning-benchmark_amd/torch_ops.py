@@ -161,3 +161,51 @@ def _(ids, lens, max_num_nodes, labeled, num_node_types, edge_cap, node_cap):
     G = ids.shape[0]
     i32 = lambda *s: ids.new_empty(s, dtype=torch.int32)
     return i32(G), i32(G), i32(G), i32(G, edge_cap), i32(G, edge_cap), i32(G, edge_cap), i32(G, node_cap)
+
+
+# ---- packed (ragged) rows: include/gtok.h, "packed rows" -----------------------------------------------------------------
+@torch.library.custom_op("gtok::row_offsets", mutates_args=(), device_types="cuda")
+def row_offsets(lens: Tensor, ld: int, align: int) -> Tensor:
+    return _ops.row_offsets(lens, ld, align)
+
+
+@row_offsets.register_fake
+def _(lens, ld, align):
+    return lens.new_empty((lens.shape[0] + 1,), dtype=torch.int64)
+
+
+@torch.library.custom_op("gtok::pack_rows", mutates_args=(), device_types="cuda")
+def pack_rows(ids: Tensor, lens: Tensor, row_ptr: Tensor, elem_bytes: int, capacity: int) -> Tuple[Tensor, Tensor]:
+    """(packed int16 | int32 [capacity], status int32 [1]): gtok_pack_rows into a caller-sized buffer; nothing waits
+    for the host (status bit 0: an id needs more than 16 bits, bit 1: capacity too small)."""
+    packed, _, status = _ops.pack_rows(ids, lens, row_ptr, elem_bytes, capacity=capacity, check_status=False)
+    return packed, status
+
+
+@pack_rows.register_fake
+def _(ids, lens, row_ptr, elem_bytes, capacity):
+    return (ids.new_empty((max(capacity, 1),), dtype=torch.int16 if elem_bytes == 2 else torch.int32),
+            ids.new_empty((1,), dtype=torch.int32))
+
+
+@torch.library.custom_op("gtok::unpack_rows", mutates_args=(), device_types="cuda")
+def unpack_rows(packed: Tensor, row_ptr: Tensor, lens: Tensor, ld: int, pad_id: int, segment_rows: int,
+                segment_stride: int) -> Tensor:
+    return _ops.unpack_rows(packed, row_ptr, lens, ld, pad_id, segment_rows, segment_stride)
+
+
+@unpack_rows.register_fake
+def _(packed, row_ptr, lens, ld, pad_id, segment_rows, segment_stride):
+    return packed.new_empty((lens.shape[0], ld), dtype=torch.int32)
+
+
+@torch.library.custom_op("gtok::collate_packed", mutates_args=(), device_types="cuda")
+def collate_packed(packed: Tensor, row_ptr: Tensor, lens: Tensor, ld: int, index: Tensor, pad_id: int,
+                   out_ld: int) -> Tuple[Tensor, Tensor]:
+    return _ops.collate_packed(packed, row_ptr, lens, ld, index, pad_id, out_ld)
+
+
+@collate_packed.register_fake
+def _(packed, row_ptr, lens, ld, index, pad_id, out_ld):
+    B = index.shape[0]
+    return packed.new_empty((B, out_ld), dtype=torch.int64), packed.new_empty((B, out_ld), dtype=torch.bool)

@@ -129,3 +129,18 @@ def test_compact_gather_over_rccl_equals_padded_gather():
         assert torch.equal(k_ids, p_ids)
     finally:
         tdist.destroy_process_group()
+
+
+def test_packed_rows_as_torch_custom_ops():
+    ids, ln = _slab(500, 48, seed=21)
+    d_ids, d_ln = torch.from_numpy(ids).to(DEV), torch.from_numpy(ln).to(DEV)
+    ptr = torch.ops.gtok.row_offsets(d_ln, 48, 8)
+    cap = int(ptr[-1]) + 16
+    packed, st = torch.ops.gtok.pack_rows(d_ids, d_ln, ptr, 2, cap)
+    assert int(st) == 0 and packed.dtype == torch.int16 and packed.numel() == cap
+    back = torch.ops.gtok.unpack_rows(packed, ptr, d_ln, 48, 7, 0, 0)
+    keep = np.arange(48)[None, :] < ln[:, None]
+    assert np.array_equal(back.cpu().numpy(), np.where(keep, ids, 7))
+    idx = torch.arange(0, 500, 7, device=DEV)
+    X, A = torch.ops.gtok.collate_packed(packed, ptr, d_ln, 48, idx, 7, 48)
+    assert torch.equal(X.to(torch.int32), back[idx]) and torch.equal(A, torch.from_numpy(keep).to(DEV)[idx])

@@ -276,7 +276,7 @@ def test_product_has_no_cpu_path():
 
 def test_custom_ops_are_registered_cuda_only_and_have_meta_kernels():
     for name in ("sent", "ibtt_zinc", "ibtt_synth", "remap_zinc", "collate", "text_to_ids", "find_token",
-                 "vocab_stats_synth", "parse_graph_text", "sent_decode"):
+                 "vocab_stats_synth", "parse_graph_text", "sent_decode", "row_offsets", "pack_rows", "unpack_rows", "collate_packed"):
         assert hasattr(torch.ops.gtok, name), name
     x = torch.zeros((3, 7), dtype=torch.int64)
     with pytest.raises((NotImplementedError, RuntimeError)):
@@ -290,3 +290,9 @@ def test_custom_ops_are_registered_cuda_only_and_have_meta_kernels():
         torch.ops.gtok.remap_zinc(ids, ln, 6, 43, 52)
     out = torch.ops.gtok.remap_zinc(ids.to("meta"), ln.to("meta"), 6, 43, 52)   # shape inference without a GPU
     assert out.shape == (4, 8) and out.device.type == "meta"
+    ptr = torch.ops.gtok.row_offsets(ln.to("meta"), 8, 8)
+    packed, st = torch.ops.gtok.pack_rows(ids.to("meta"), ln.to("meta"), ptr, 2, 64)
+    assert ptr.shape == (5,) and packed.shape == (64,) and packed.dtype == torch.int16 and st.shape == (1,)
+    assert torch.ops.gtok.unpack_rows(packed, ptr, ln.to("meta"), 8, 5, 0, 0).shape == (4, 8)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.gtok.row_offsets(ln, 8, 8)
