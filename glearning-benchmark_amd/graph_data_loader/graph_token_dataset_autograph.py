@@ -143,6 +143,7 @@ class GraphTokenDatasetForAutoGraph:
     same directory is neither read nor written: each side only ever sees its own file."""
 
     CACHE_NAME = "data_gtok.pt"
+    DEVICE_PARSE_MIN = 256        # fewer text records than this: the host parsers are as fast as two launches
 
     def __init__(self, root: str, task: str = "cycle_check", algorithm=None, split: str = "train",
                  use_split_tasks_dirs: bool = True, seed: int = 0, num_graphs: Optional[int] = None,
@@ -287,17 +288,40 @@ class GraphTokenDatasetForAutoGraph:
         out: List[Data] = []
         rng = random.Random(self.seed)
         pairs_mode = self.task == "shortest_path" and self.num_pairs_per_graph is not None
+        # pass 1: read the files.  Records that carry their graph only as `text` (what the graph-token generator writes)
+        # are parsed in bulk on the device - one pair of launches instead of a Python loop over every token - when a GPU
+        # is there; explicit `edges` / `nodes` fields, texts outside the canonical grammar and GPU-less runs (host-side
+        # tests) go through the host parsers, which give the same tuples (tests/test_gpu_golden.py).
+        per_file: List[list] = []
+        bulk_texts: List[str] = []
         for fp in files:
             with open(fp, "r") as f:
                 content = json.load(f)
             recs = content if isinstance(content, list) else [content]
+            per_file.append(recs)
+            for r in recs:
+                if isinstance(r, dict) and not r.get("edges") and not r.get("nodes") and isinstance(r.get("text"), str) and r["text"]:
+                    bulk_texts.append(r["text"])
+        bulk = None
+        if len(bulk_texts) >= self.DEVICE_PARSE_MIN and torch.cuda.is_available() and all(t.isascii() for t in bulk_texts):
+            bulk = iter(parse_texts_on_device(bulk_texts, device=torch.device("cuda", torch.cuda.current_device())))
+        for recs in per_file:
             parsed = []
             for r in recs:
-                edges, n, label = parse_graph_from_json(r, task=self.task)
+                text = r.get("text", "")
+                in_bulk = isinstance(r, dict) and not r.get("edges") and not r.get("nodes") and isinstance(text, str) and text
+                if bulk is not None and in_bulk:
+                    edges, n, tlabel, q = next(bulk)
+                    label = r.get("label")
+                    if label is None:
+                        label = tlabel
+                    if self.task != "shortest_path":
+                        q = None
+                else:
+                    edges, n, label = parse_graph_from_json(r, task=self.task)
+                    q = parse_query_nodes_from_text(text) if (self.task == "shortest_path" and text) else None
                 if n == 0 or label is None:
                     continue
-                text = r.get("text", "")
-                q = parse_query_nodes_from_text(text) if (self.task == "shortest_path" and text) else None
                 if pairs_mode and q is None:
                     continue
                 parsed.append((edges, n, label, q))

@@ -154,3 +154,37 @@ def test_zinc_strings_rendered_on_the_device_equal_the_reference(max_len):
             got = [z[i] for i in range(len(z))]
             want = [z._item(i) for i in range(len(z))]
             assert z._texts is not None and got == want
+
+
+@pytest.mark.parametrize("task", ["cycle_check", "shortest_path"])
+def test_process_parses_text_records_on_the_device(task, tmp_path):
+    """GraphTokenDatasetForAutoGraph.process() (graph_token_dataset_autograph.py:259-408) with the text records of all
+    files parsed by one pair of launches: item for item what the host parsers give - including hand-edited texts outside
+    the canonical grammar, records with explicit fields, INF / unlabeled / empty ones and the per-file pair sampling."""
+    import json, os
+    tree = gtok.synth.graph_token_tree(90, seed=21, task=task, algorithms=("er", "ba", "sbm", "path"), splits=("train",),
+                                       pairs_per_graph=4 if task == "shortest_path" else 1)
+    keys = sorted(tree)
+    tree[keys[0]][0] = {"text": tree[keys[0]][0]["text"].replace("<n>", "<n> x"), "label": 1}        # not canonical: host fallback
+    tree[keys[1]][0] = {"edges": [[0, 1], [1, 2]], "nodes": [0, 1, 2], "label": 0, "text": tree[keys[1]][0]["text"]}
+    tree[keys[2]][0] = {"text": "<bos> <n> <q> has_cycle <p> yes <eos>"}                                # no nodes: skipped
+    tree[keys[3]][0] = {"text": tree[keys[3]][0]["text"].rsplit("<p>", 1)[0] + "<p> maybe <eos>"}      # no label: skipped
+    gtok.synth.write_tree(str(tmp_path), tree)
+    G = gdl.GraphTokenDatasetForAutoGraph
+    kw = dict(root=str(tmp_path), task=task, algorithm=["er", "ba", "sbm", "path"], split="train", use_cache=False,
+              num_pairs_per_graph=2 if task == "shortest_path" else None)
+    calls = []
+    real = gdl.graph_token_dataset_autograph.parse_texts_on_device
+    gdl.graph_token_dataset_autograph.parse_texts_on_device = lambda *a, **k: (calls.append(len(a[0])), real(*a, **k))[1]
+    try:
+        dev_ds = G(**kw)
+        G.DEVICE_PARSE_MIN = 10 ** 9
+        host_ds = G(**kw)
+    finally:
+        G.DEVICE_PARSE_MIN = 256
+        gdl.graph_token_dataset_autograph.parse_texts_on_device = real
+    assert len(calls) == 1 and calls[0] > 200, "the device parser took the text records of every file in one call"
+    assert len(dev_ds) == len(host_ds) > 100
+    for a, b in zip(dev_ds, host_ds):
+        assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.y, b.y) and a.num_nodes == b.num_nodes
+        assert (getattr(a, "query_u", None), getattr(a, "query_v", None)) == (getattr(b, "query_u", None), getattr(b, "query_v", None))
