@@ -534,13 +534,14 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
 #else
           const int pick = ctz_of(set) + (int)(below((uint32_t)popc_of(set)) >> 31);
 #endif
+          // the node's byte is asked for first: its round trip then runs beside the edge-type search and the row load
+          const uint32_t xb = snat[nbase + pick];              // node type (first visit) or visit index (kind 1)
           uint32_t et = 0;
           if (LAB && kind == 0) et = find_et(rc, (uint32_t)pick);   // type of the listed entry cur -> pick
           rc = load_row(pick);                                 // in place: the old row is not needed past find_et above
-          const uint32_t xb = snat[nbase + pick];              // node type (first visit) or visit index (kind 1)
           const bool first = kind != 1;
           const uint32_t my = (uint32_t)nvis;
-          if (first) snat[nbase + pick] = (uint8_t)my;         // from now on this byte is the node's visit index
+          snat[nbase + pick] = (uint8_t)(first ? my : xb);     // from now on this byte is the node's visit index (kind 1: it already is)
           // ---- the step's token group: [edge type | RESET] position [node type], 16 bits per token
           {
             const uint32_t tpos = (uint32_t)pos_base + (first ? my : xb);
