@@ -53,28 +53,33 @@ class EpochRows:
 # The reference's per-item loop is `data = self.pyg_dataset[idx]; tokens = self.tokenizer(data)` (train_agtt.py:247-250):
 # the tokenizer sees one graph and nothing else.  This package's dataset classes mark what they return with (dataset,
 # index), so that the tokenizer can tokenize the item's whole split in one launch and serve rows from it.
-_LAST = [None, -1, None]       # (weakref to the dataset, index, the object returned): fallback for objects that refuse attributes
+_OWNERS = weakref.WeakValueDictionary()      # id(dataset) -> dataset, for as long as the dataset lives
+_LAST = [0, -1, None]          # (dataset key, index, the object returned): fallback for objects that refuse attributes
 
 
 def tag_item(owner, idx: int, data):
-    ref = weakref.ref(owner)
+    """Mark `data` as item `idx` of `owner`.  The mark is a pair of plain ints (the dataset's key in a weak registry and the
+    index): it pickles with the object, means nothing in another process, and dies with the dataset."""
+    key = id(owner)
+    _OWNERS[key] = owner
     try:
-        data._gtok_src = (ref, int(idx))         # a private attribute: torch_geometric's Data keeps those out of its keys
+        data._gtok_src = (key, int(idx))         # a private attribute: torch_geometric's Data keeps those out of its keys
     except Exception:
         pass
-    _LAST[0], _LAST[1], _LAST[2] = ref, int(idx), data
+    _LAST[0], _LAST[1], _LAST[2] = key, int(idx), data
     return data
 
 
 def item_source(data) -> Optional[Tuple[object, int]]:
-    """(dataset, index) the item was fetched from, or None (an object built by the caller: tokenize it on its own)."""
+    """(dataset, index) the item was fetched from, or None (an object built by the caller, or one whose dataset is gone or
+    lives in another process: tokenize it on its own)."""
     try:
         src = getattr(data, "_gtok_src", None)
     except Exception:
         src = None
     if src is None and _LAST[2] is data:
         src = (_LAST[0], _LAST[1])
-    if src is None:
+    if not (isinstance(src, tuple) and len(src) == 2):
         return None
-    owner = src[0]()
+    owner = _OWNERS.get(src[0])
     return None if owner is None else (owner, src[1])

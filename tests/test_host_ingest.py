@@ -72,6 +72,15 @@ def test_items_carry_their_split():
     f = Frozen()
     gtok.rows.tag_item(ds, 3, f)
     assert gtok.rows.item_source(f) == (ds, 3) and gtok.rows.item_source(Frozen()) is None
+    # the mark is plain data: an item pickles (DataLoader workers, torch.save) and is a stranger once its dataset is gone
+    import pickle
+    clone = pickle.loads(pickle.dumps(it))
+    assert gtok.rows.item_source(clone) == (ds, 7)
+    other = gdl.ZINCDatasetForAutoGraph(split="val", zinc_dataset=gtok.synth.InMemoryLike(d))
+    orphan = other[2]
+    del other
+    import gc; gc.collect()
+    assert gtok.rows.item_source(orphan) is None
     _same(ds.graph_batch(), gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"]))
     ib = gdl.ZINCTokenizationDataset(split="train", zinc_dataset=gtok.synth.InMemoryLike(d))
     _same(ib.graph_batch(), ds.graph_batch())
