@@ -291,7 +291,7 @@ def main():
     # sustained: >= 1 s of back-to-back launches (clocks, L2 / MALL state of a slab rewritten in place), one event pair around all
     sustained = None
     if not args.no_sustained:
-        n_s = max(args.steps, int(1.2 / max(float(np.mean(kern_ms)) * 1e-3, 2e-5)))
+        n_s = max(args.steps, min(200000, int(1.2 / max(float(np.mean(kern_ms)) * 1e-3, 2e-5))))
         _, sm = timed_loop(lambda k: step(args.warmup + k, scratch_len), n_s, multi, per_launch_events=False)
         sustained = dict(launches=n_s, seconds=round(float(sm[0]) * n_s * 1e-3, 3), ms_per_step=round(float(sm[0]), 4),
                          graphs_per_sec=round(G / float(sm[0]) * 1e3, 1))
@@ -602,7 +602,12 @@ def main():
 
     # throughput through the Dataset classes the trainers call (not the kernels): rank 0, N=1, ZINC-shaped workloads
     if rank == 0 and world == 1 and zinc and not args.no_boundary:
-        out["boundary"] = boundary_section(d, G, dev, max_nodes, max_len)
+        try:                   # a secondary section must never cost the run its headline line
+            out["boundary"] = boundary_section(d, G, dev, max_nodes, max_len)
+        except Exception as ex:
+            import traceback
+            traceback.print_exc()
+            out["boundary"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     # CPU baseline: the oracle (a port, not the reference's Python) on a bounded sample, rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
