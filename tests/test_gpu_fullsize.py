@@ -110,3 +110,44 @@ def test_large_graphs_bit_exact():
     assert np.array_equal(ln2.cpu().numpy(), rln2) and np.array_equal(ids2.cpu().numpy(), ref2)
     want = np.minimum(600, 1 + 3 * d["edge_counts"] + 1 + d["node_counts"] + 1 + 1 + 1)
     assert np.array_equal(ln2.cpu().numpy(), want)
+
+
+def test_packed_rows_and_strings_at_zinc_full_size(zinc_full):
+    """Size-independent properties of round 3's formats on the full corpus: pack -> unpack is the identity on everything
+    inside the lengths (both widths, padded and GTOK_SENT_NO_PAD slabs), the packed form is the token count rounded per row,
+    the host view of an epoch serves exactly the slab's rows, and the device-rendered strings of the whole split equal the
+    per-item Python on a sample and re-tokenize (text -> ids) to the ids the string-free route gives."""
+    d, host, dev, coo = zinc_full
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ld = 192
+    ids, ln = gtok.ops.sent(dev, 37, 1024, 7, 3, ld=ld, **kw)
+    raw, rln = gtok.ops.sent(dev, 37, 1024, 7, 3, ld=ld, pad=False, **kw)
+    assert torch.equal(ln, rln)
+    ptr = gtok.ops.row_offsets(ln, ld)
+    assert int(ptr[-1]) == int(((ln.long() + 7) // 8 * 8).sum())
+    for eb in (2, 4):
+        a, _ = gtok.ops.pack_rows(ids, ln, ptr, elem_bytes=eb)
+        b, _ = gtok.ops.pack_rows(raw, ln, ptr, elem_bytes=eb)           # the unpadded slab packs to the same rows
+        assert torch.equal(gtok.ops.unpack_rows(a, ptr, ln, ld, 5), ids)
+        assert torch.equal(gtok.ops.unpack_rows(b, ptr, ln, ld, 5), ids)
+    rows = gtok.rows.EpochRows(raw, ln)
+    ids_h, ln_h = ids.cpu(), ln.cpu().tolist()
+    for i in list(range(0, ZINC_FULL, 997)) + [ZINC_FULL - 1]:
+        assert torch.equal(rows.row(i), ids_h[i, :ln_h[i]].long())
+    assert rows.take(5) is not None and rows.take(5) is None           # once per epoch
+    # strings of the whole split
+    gdl = gtok.graph_data_loader
+    ds = gdl.ZINCTokenizationDataset(split="train", max_len=1024, zinc_dataset=gtok.synth.InMemoryLike(d))
+    texts, labels = ds.render_all(DEV)
+    assert len(texts) == ZINC_FULL
+    for i in list(range(0, ZINC_FULL, 4999)) + [ZINC_FULL - 1]:
+        want = ds._item(i)
+        assert texts[i] == want["text"] and labels[i] == want["label"]
+    vocab = zinc_vocab(40)
+    S = 20000
+    td = gdl.TokenDataset([{"text": t, "label": y} for t, y in zip(texts[:S], labels[:S])], vocab, 1024, device=DEV)
+    direct, dln = ds.tokenize(vocab, 1024, device=DEV)
+    dl = dln.cpu().tolist()
+    dh = direct.cpu()
+    for i in range(0, S, 97):
+        assert torch.equal(td.seqs[i], dh[i, :dl[i]].long())
