@@ -1019,94 +1019,125 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
       const int64_t have = c0 + kTextRing;                       // bytes below this offset are in the ring
       const U8x16 nxt = load16(t0 + c0 + kTextRing + lane * 16);   // chunk +2: in flight while this one is split
       auto byte_at = [&](int64_t j) -> uint32_t { return j < have ? ring[j & (kTextRing - 1)] : s[j]; };
-      for (int sub = 0; sub < kTextChunk / kWave && count < a.max_len && !done; ++sub) {
-        const int64_t b0 = c0 + sub * kWave;
-        if (b0 >= n) break;
-        const int64_t i = b0 + lane;
-        const uint32_t c = (i < n) ? ring[i & (kTextRing - 1)] : 32u;
-        const bool sp = py_isspace(c);
-        const uint64_t spm = __ballot(sp);
-        const bool before = lane == 0 ? prev_sp : ((spm >> (lane - 1)) & 1ull);
-        const bool start = !sp && before;
-        const uint64_t sm = __ballot(start);
-        prev_sp = (spm >> 63) & 1ull;
-        if (sm == 0) continue;
-        int id = a.pad_id;
-        bool is_p = false;
-        const int t = count + __popcll(sm & lanemask_lt());
-        if (start && t < a.max_len) {
-          bool fast = false;
-          if (VLDS && i + 8 <= n) {
-            // tokens of up to 7 bytes: the 8 bytes at i (all in the ring and inside the text) as one 64-bit value, cut at
-            // their first whitespace - found with the zero-byte trick on "byte < 33" (ASCII: exact for the lowest flag) -
-            // and looked up in the short-key table.  Anything else (longer, a control character that is not whitespace,
-            // the last bytes of the text) takes the byte loops below.
-            const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(ring);
-            const uint32_t o = (uint32_t)i & (kTextRing - 1), sh = o & 3u;
-            const uint32_t w0 = ring32[o >> 2], w1 = ring32[((o >> 2) + 1) & (kTextRing / 4 - 1)], w2 = ring32[((o >> 2) + 2) & (kTextRing / 4 - 1)];
-            uint32_t klo = __builtin_amdgcn_alignbyte(w1, w0, sh), khi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            const uint32_t flo = (klo - 0x21212121u) & ~klo & 0x80808080u, fhi = (khi - 0x21212121u) & ~khi & 0x80808080u;
-            if (flo | fhi) {
-              const int len = flo ? (__builtin_ctz(flo) >> 3) : 4 + (__builtin_ctz(fhi) >> 3);
-              const uint32_t delim = (flo ? klo >> (8 * len) : khi >> (8 * (len - 4))) & 255u;
-              if (len >= 1 && py_isspace(delim)) {
-                klo = len >= 4 ? klo : klo & ((1u << (8 * len)) - 1u);
-                khi = len <= 4 ? 0u : khi & ((1u << (8 * (len - 4))) - 1u);
-                const U32x4a *stab = reinterpret_cast<const U32x4a *>(smem + a.off_short);
-                for (uint32_t slot = short_key_hash(klo, khi) & mask;; slot = (slot + 1) & mask) {
-                  const U32x4a e = stab[slot];
-                  if (e.w == 0u) break;                                   // not in the vocab: id stays pad_id, as below
-                  if (e.x == klo && e.y == khi) { id = (int)e.z; break; }
-                }
-                is_p = len == 3 && klo == 0x003E703Cu;                    // "<p>"
-                fast = true;
+      // one token: its id (pad_id when it is not in the vocab, as TokenDataset's vocab.get(tok, vocab['<pad>'])) and whether it is "<p>"
+      auto lookup = [&](const int64_t i, int &id, bool &is_p) __attribute__((always_inline)) {
+        id = a.pad_id; is_p = false;
+#ifdef GTOK_ABLATE_TEXT_LOOKUP   // (profiling builds: no vocab look-up - wrong ids, the time difference is the look-ups')
+        id = (int)(i & 7); return;
+#endif
+        bool fast = false;
+        if (VLDS && i + 8 <= n) {
+          // tokens of up to 7 bytes: the 8 bytes at i (all in the ring and inside the text) as one 64-bit value, cut at
+          // their first whitespace - found with the zero-byte trick on "byte < 33" (ASCII: exact for the lowest flag) -
+          // and looked up in the short-key table.  Anything else (longer, a control character that is not whitespace,
+          // the last bytes of the text) takes the byte loops below.
+          const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(ring);
+          const uint32_t o = (uint32_t)i & (kTextRing - 1), sh = o & 3u;
+          const uint32_t w0 = ring32[o >> 2], w1 = ring32[((o >> 2) + 1) & (kTextRing / 4 - 1)], w2 = ring32[((o >> 2) + 2) & (kTextRing / 4 - 1)];
+          uint32_t klo = __builtin_amdgcn_alignbyte(w1, w0, sh), khi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+          const uint32_t flo = (klo - 0x21212121u) & ~klo & 0x80808080u, fhi = (khi - 0x21212121u) & ~khi & 0x80808080u;
+          if (flo | fhi) {
+            const int len = flo ? (__builtin_ctz(flo) >> 3) : 4 + (__builtin_ctz(fhi) >> 3);
+            const uint32_t delim = (flo ? klo >> (8 * len) : khi >> (8 * (len - 4))) & 255u;
+            if (len >= 1 && py_isspace(delim)) {
+              klo = len >= 4 ? klo : klo & ((1u << (8 * len)) - 1u);
+              khi = len <= 4 ? 0u : khi & ((1u << (8 * (len - 4))) - 1u);
+              const U32x4a *stab = reinterpret_cast<const U32x4a *>(smem + a.off_short);
+              for (uint32_t slot = short_key_hash(klo, khi) & mask;; slot = (slot + 1) & mask) {
+                const U32x4a e = stab[slot];
+                if (e.w == 0u) break;                                   // not in the vocab: id stays pad_id, as below
+                if (e.x == klo && e.y == khi) { id = (int)e.z; break; }
               }
+              is_p = len == 3 && klo == 0x003E703Cu;                    // "<p>"
+              fast = true;
             }
           }
-          if (!fast) {
-          // hash the token (FNV-1a), then probe the open-addressing table
-          uint32_t h = 2166136261u;
-          int len = 0;
-          for (int64_t j = i; j < n; ++j) {
-            const uint32_t cj = byte_at(j);
-            if (py_isspace(cj)) break;
-            h = (h ^ cj) * 16777619u;
-            ++len;
-          }
-          is_p = (len == 3) && c == '<' && byte_at(i + 1) == 'p' && byte_at(i + 2) == '>';
-          for (uint32_t slot = h & mask, probes = 0; probes <= mask; slot = (slot + 1) & mask, ++probes) {
-            if (VLDS) {
-              const unsigned char *d = vs + (size_t)slot * kSlotBytes;
-              const int kl = d[4];
-              if (kl == 255) break;
-              if (kl != min(len, 254)) continue;
-              bool eq = true;
-              for (int j = 0; j < min(len, kSlotKey) && eq; ++j) eq = d[5 + j] == byte_at(i + j);
-              if (eq && len > kSlotKey) {   // long key: the rest (and keys of 254+ bytes: everything) from global
-                const int off = a.v.key_off[slot];
-                eq = a.v.key_len[slot] == len;
-                for (int j = kSlotKey; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == byte_at(i + j);
-              }
-              if (eq) { id = *reinterpret_cast<const int32_t *>(d); break; }
-            } else {
-              const int off = a.v.key_off[slot];
-              if (off < 0) break;
-              if (a.v.key_len[slot] != len) continue;
-              bool eq = true;
-              for (int j = 0; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == byte_at(i + j);
-              if (eq) { id = a.v.id[slot]; break; }
-            }
-          }
-          }
-          if (t < cap) tok[t] = id;
         }
-        uint64_t pm = a.strip_label ? (uint64_t)__ballot(start && is_p) : 0ull;
-        if (pm) {  // data_loader.py:479-481: keep up to and including the first <p>
-          const int first = __ffsll((unsigned long long)pm) - 1;
-          count += __popcll(sm & ((2ull << first) - 1ull));
+        if (!fast) {
+        // hash the token (FNV-1a), then probe the open-addressing table
+        uint32_t h = 2166136261u;
+        int len = 0;
+        for (int64_t j = i; j < n; ++j) {
+          const uint32_t cj = byte_at(j);
+          if (py_isspace(cj)) break;
+          h = (h ^ cj) * 16777619u;
+          ++len;
+        }
+        is_p = (len == 3) && byte_at(i) == '<' && byte_at(i + 1) == 'p' && byte_at(i + 2) == '>';
+        for (uint32_t slot = h & mask, probes = 0; probes <= mask; slot = (slot + 1) & mask, ++probes) {
+          if (VLDS) {
+            const unsigned char *d = vs + (size_t)slot * kSlotBytes;
+            const int kl = d[4];
+            if (kl == 255) break;
+            if (kl != min(len, 254)) continue;
+            bool eq = true;
+            for (int j = 0; j < min(len, kSlotKey) && eq; ++j) eq = d[5 + j] == byte_at(i + j);
+            if (eq && len > kSlotKey) {   // long key: the rest (and keys of 254+ bytes: everything) from global
+              const int off = a.v.key_off[slot];
+              eq = a.v.key_len[slot] == len;
+              for (int j = kSlotKey; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == byte_at(i + j);
+            }
+            if (eq) { id = *reinterpret_cast<const int32_t *>(d); break; }
+          } else {
+            const int off = a.v.key_off[slot];
+            if (off < 0) break;
+            if (a.v.key_len[slot] != len) continue;
+            bool eq = true;
+            for (int j = 0; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == byte_at(i + j);
+            if (eq) { id = a.v.id[slot]; break; }
+          }
+        }
+        }
+      };
+      // 256 bytes per step, FOUR per lane (one aligned dword of the ring): whitespace flags of the lane's bytes, token starts
+      // among them (a token is at least one byte and one separator: at most two starts per dword), token numbers from two
+      // ballots.  With a byte per lane a 64-byte piece of a molecule text holds ~13 token starts: four fifths of the lanes sat
+      // out the look-ups, which are what the kernel's time is made of.
+      const uint32_t *ring32w = reinterpret_cast<const uint32_t *>(ring);
+      for (int sub = 0; sub < kTextChunk / (4 * kWave) && count < a.max_len && !done; ++sub) {
+        const int64_t b0 = c0 + sub * (4 * kWave);
+        if (b0 >= n) break;
+        const int64_t i0 = b0 + 4 * lane;
+        uint32_t w = ring32w[((uint32_t)i0 & (kTextRing - 1)) >> 2];
+        const int64_t left = n - i0;                                  // bytes of the text in this dword; the rest reads as spaces
+        if (left < 4) w = left <= 0 ? 0x20202020u : ((w & ((1u << (8 * (int)left)) - 1u)) | (0x20202020u << (8 * (int)left)));
+        uint32_t sp4 = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) sp4 |= py_isspace((w >> (8 * b)) & 255u) ? 1u << b : 0u;
+        const uint64_t lastsp = __ballot((sp4 & 8u) != 0u);
+        const uint32_t before0 = lane == 0 ? (prev_sp ? 1u : 0u) : (uint32_t)((lastsp >> (lane - 1)) & 1ull);
+        prev_sp = (lastsp >> 63) & 1ull;
+        const uint32_t st4 = ~sp4 & ((sp4 << 1) | before0) & 15u;     // bit b: byte b starts a token
+        const int nst = __popc(st4);
+        const uint64_t m1 = __ballot(nst >= 1), m2 = __ballot(nst >= 2);
+        if (m1 == 0) continue;
+        const int pre = __popcll(m1 & lanemask_lt()) + __popcll(m2 & lanemask_lt());   // token starts in the lanes below
+        bool p0 = false, p1 = false;
+        {
+          const int t = count + pre;
+          if (nst >= 1 && t < a.max_len) {
+            int id; lookup(i0 + __builtin_ctz(st4), id, p0);
+            if (t < cap) tok[t] = id;
+          }
+        }
+        if (m2 != 0) {
+          const int t = count + pre + 1;
+          if (nst >= 2 && t < a.max_len) {
+            int id; lookup(i0 + __builtin_ctz(st4 & (st4 - 1u)), id, p1);
+            if (t < cap) tok[t] = id;
+          }
+        }
+        const uint64_t pm0 = a.strip_label ? (uint64_t)__ballot(p0) : 0ull, pm1 = a.strip_label ? (uint64_t)__ballot(p1) : 0ull;
+        if (pm0 | pm1) {  // data_loader.py:479-481: keep up to and including the first <p>
+          // ordinal (within this step) of the earliest "<p>": tokens of lower lanes come first, a lane's first before its second
+          auto upto = [&](int l) { const uint64_t below = (1ull << l) - 1ull; return __popcll(m1 & below) + __popcll(m2 & below); };
+          int best = 1 << 30;
+          if (pm0) best = upto(__ffsll((unsigned long long)pm0) - 1);
+          if (pm1) best = min(best, upto(__ffsll((unsigned long long)pm1) - 1) + 1);
+          count += best + 1;
           done = true;
         } else {
-          count += __popcll(sm);
+          count += __popcll(m1) + __popcll(m2);
         }
       }
       wave_sync();   // every lane is done with chunk c0: its half of the ring takes chunk +2
@@ -1115,7 +1146,9 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
     }
     wave_sync();
     const int len = min(count, a.max_len);
+#ifndef GTOK_ABLATE_TEXT_WRITE
     write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, cap), a.pad_id, [=](int i) -> int { return tok[i]; });
+#endif
     if (lane == 0) a.out_len[g] = len;
     wave_sync();
   }
