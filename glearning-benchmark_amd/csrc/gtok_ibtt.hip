@@ -908,6 +908,8 @@ struct TextArgs {
   int units, upb;
   int off_vocab, off_wave, ring_off, tok_off, wave_stride;   // LDS: [vocab slots (VLDS)] then per wave: text ring, tokens
   int off_short;   // VLDS: second table, the keys of up to 7 bytes as {key lo, key hi, id, used} (one 16-byte read per probe)
+  int sidx_off;    // per wave: the token starts of one 256-byte step, compacted (128 x int32)
+  int short_slots; // its size (a power of two, >= capacity: the sparser it is, the shorter the probe chains the 64 lanes wait for)
 };
 
 // The text of one graph is read ONCE, 16 bytes per lane and load, into a 2 KB LDS ring (the chunk being split and
@@ -919,7 +921,7 @@ struct TextArgs {
 constexpr int kTextChunk = 1024, kTextRing = 2 * kTextChunk, kSlotBytes = 24, kSlotKey = 19;
 
 struct __attribute__((aligned(16))) U32x4a { uint32_t x, y, z, w; };
-__device__ __forceinline__ uint32_t short_key_hash(uint32_t klo, uint32_t khi) {
+__device__ __forceinline__ uint32_t short_key_hash(uint32_t klo, uint32_t khi) {   // (the first 8 bytes: a key's third word only tells it apart in its slot)
   const uint32_t h = (klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu);
   return h ^ (h >> 15);
 }
@@ -937,20 +939,23 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
   const uint32_t mask = (uint32_t)a.v.capacity - 1u;
   const int64_t total = a.text_ptr[a.num_texts];
 
-  if (VLDS) {   // slot s: id (4 B), length (1 B; 255 = empty), key bytes (one unaligned 16-byte load + 3 bytes)
-    // bytes readable at key_bytes = the end of the last key (the ABI carries no length): found first, so that the
-    // vector loads below never leave the array
-    int *kb_end = reinterpret_cast<int *>(smem + a.off_short - 16);
-    if (threadIdx.x == 0) *kb_end = 0;
-    __syncthreads();
+  // three scratch words in front of the short-key table: [0] bytes readable at key_bytes (= the end of the last key: the ABI
+  // carries no length, and the vector loads below must not leave the array), [1] some short key was left OUT of the short-key
+  // table, [2] short keys placed so far
+  int *scratch = reinterpret_cast<int *>(smem + a.off_short - 16);
+  if (threadIdx.x == 0) { scratch[0] = 0; scratch[1] = 0; scratch[2] = 0; }
+  __syncthreads();
+  {
     int my_end = 0;
     for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
       const int off = a.v.key_off[sl];
       if (off >= 0) my_end = max(my_end, off + a.v.key_len[sl]);
     }
-    atomicMax(kb_end, my_end);
-    __syncthreads();
-    const int kb_total = *kb_end;
+    atomicMax(scratch, my_end);
+  }
+  __syncthreads();
+  const int kb_total = scratch[0];
+  if (VLDS) {   // slot s: id (4 B), length (1 B; 255 = empty), key bytes (one unaligned 16-byte load + 3 bytes)
     for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
       unsigned char *d = vs + (size_t)sl * kSlotBytes;
       const int off = a.v.key_off[sl], len = off < 0 ? 255 : min(a.v.key_len[sl], 254);
@@ -968,25 +973,33 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
       d[4] = (unsigned char)len;
       for (int j = 0; j < kSlotKey; ++j) d[5 + j] = (unsigned char)((j < len) ? (w[j >> 2] >> (8 * (j & 3))) & 255u : 0u);
     }
-    __syncthreads();
-    // the short-key table: most tokens of a graph-token or molecule text are a few bytes long (node ids, <e>, <bond>, yes / no)
-    // and are matched as one 64-bit value instead of a hash loop and a compare loop over their bytes
-    uint32_t *st = reinterpret_cast<uint32_t *>(smem + a.off_short);
-    for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) st[sl * 4 + 3] = 0u;
-    __syncthreads();
-    for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
-      const unsigned char *d = vs + (size_t)sl * kSlotBytes;
-      const int len = d[4];
-      if (len >= 1 && len <= 7) {
-        uint32_t klo = 0, khi = 0;
-        for (int j = 0; j < len; ++j) { if (j < 4) klo |= (uint32_t)d[5 + j] << (8 * j); else khi |= (uint32_t)d[5 + j] << (8 * (j - 4)); }
-        uint32_t idx = short_key_hash(klo, khi) & mask;
-        while (atomicCAS(&st[idx * 4 + 3], 0u, 1u) != 0u) idx = (idx + 1) & mask;
-        st[idx * 4 + 0] = klo; st[idx * 4 + 1] = khi; st[idx * 4 + 2] = (uint32_t)*reinterpret_cast<const int32_t *>(d);
-      }
-    }
-    __syncthreads();   // the last workgroup barrier: before any wave can leave
   }
+  // the short-key table (both modes: also a vocab too large for LDS - ZINC's, with its thousands of label tokens - has only a
+  // few dozen keys that ever occur in a text): the tokens of a graph-token or molecule text are a few bytes long (node ids,
+  // <e>, <bond>, aromatic, regression), so keys of up to 11 bytes are matched as ONE 96-bit value - slot = {lo, mid, hi, id + 1},
+  // 0 = empty - instead of a hash loop and a compare loop over their bytes.  Keys of up to 7 bytes go in first, then those of
+  // 8 .. 11, until the table is half full; whatever is left out (and a key whose id is -1) makes a miss non-final: such a
+  // token takes the byte loops.
+  uint32_t *st = reinterpret_cast<uint32_t *>(smem + a.off_short);
+  const uint32_t smask_b = (uint32_t)a.short_slots - 1u;
+  for (int sl = (int)threadIdx.x; sl < a.short_slots; sl += (int)blockDim.x) st[sl * 4 + 3] = 0u;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
+      const int off = a.v.key_off[sl];
+      const int len = off < 0 ? 0 : a.v.key_len[sl];
+      if (len < (pass ? 8 : 1) || len > (pass ? 11 : 7)) continue;
+      const uint32_t idp1 = (uint32_t)a.v.id[sl] + 1u;
+      if (idp1 == 0u || atomicAdd(&scratch[2], 1) >= a.short_slots / 2) { scratch[1] = 1; continue; }
+      uint32_t k[3] = {0u, 0u, 0u};
+      for (int j = 0; j < len && off + j < kb_total; ++j) k[j >> 2] |= (uint32_t)a.v.key_bytes[off + j] << (8 * (j & 3));
+      uint32_t idx = short_key_hash(k[0], k[1]) & smask_b;
+      while (atomicCAS(&st[idx * 4 + 3], 0u, idp1) != 0u) idx = (idx + 1) & smask_b;
+      st[idx * 4 + 0] = k[0]; st[idx * 4 + 1] = k[1]; st[idx * 4 + 2] = k[2];
+    }
+    __syncthreads();   // (the second one is the last workgroup barrier: before any wave can leave)
+  }
+  const bool has_m1 = scratch[1] != 0;   // a short-table miss is not final
   auto load16 = [&](int64_t abs) -> U8x16 {   // never touches bytes past the end of the blob
     if (abs + 16 <= total) return *reinterpret_cast<const U8x16 *>(a.bytes + abs);
     uint32_t w[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
@@ -1026,31 +1039,44 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
         id = (int)(i & 7); return;
 #endif
         bool fast = false;
-        if (VLDS && i + 8 <= n) {
-          // tokens of up to 7 bytes: the 8 bytes at i (all in the ring and inside the text) as one 64-bit value, cut at
+        if (i + 12 <= n) {
+          // tokens of up to 11 bytes: the 12 bytes at i (all in the ring and inside the text) as one 96-bit value, cut at
           // their first whitespace - found with the zero-byte trick on "byte < 33" (ASCII: exact for the lowest flag) -
           // and looked up in the short-key table.  Anything else (longer, a control character that is not whitespace,
-          // the last bytes of the text) takes the byte loops below.
+          // the last bytes of the text, a vocab id of -1) takes the byte loops below.
           const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(ring);
-          const uint32_t o = (uint32_t)i & (kTextRing - 1), sh = o & 3u;
-          const uint32_t w0 = ring32[o >> 2], w1 = ring32[((o >> 2) + 1) & (kTextRing / 4 - 1)], w2 = ring32[((o >> 2) + 2) & (kTextRing / 4 - 1)];
-          uint32_t klo = __builtin_amdgcn_alignbyte(w1, w0, sh), khi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+          const uint32_t o = (uint32_t)i & (kTextRing - 1), sh = o & 3u, q = o >> 2;
+          constexpr uint32_t RM = kTextRing / 4 - 1;
+          const uint32_t w0 = ring32[q], w1 = ring32[(q + 1) & RM], w2 = ring32[(q + 2) & RM];
+          uint32_t klo = __builtin_amdgcn_alignbyte(w1, w0, sh), khi = __builtin_amdgcn_alignbyte(w2, w1, sh), kx = 0u;
           const uint32_t flo = (klo - 0x21212121u) & ~klo & 0x80808080u, fhi = (khi - 0x21212121u) & ~khi & 0x80808080u;
-          if (flo | fhi) {
-            const int len = flo ? (__builtin_ctz(flo) >> 3) : 4 + (__builtin_ctz(fhi) >> 3);
-            const uint32_t delim = (flo ? klo >> (8 * len) : khi >> (8 * (len - 4))) & 255u;
-            if (len >= 1 && py_isspace(delim)) {
-              klo = len >= 4 ? klo : klo & ((1u << (8 * len)) - 1u);
-              khi = len <= 4 ? 0u : khi & ((1u << (8 * (len - 4))) - 1u);
-              const U32x4a *stab = reinterpret_cast<const U32x4a *>(smem + a.off_short);
-              for (uint32_t slot = short_key_hash(klo, khi) & mask;; slot = (slot + 1) & mask) {
-                const U32x4a e = stab[slot];
-                if (e.w == 0u) break;                                   // not in the vocab: id stays pad_id, as below
-                if (e.x == klo && e.y == khi) { id = (int)e.z; break; }
-              }
-              is_p = len == 3 && klo == 0x003E703Cu;                    // "<p>"
-              fast = true;
+          int len = -1;
+          uint32_t delim = 0u;
+          if (flo | fhi) {                                              // the token ends inside its first 8 bytes
+            len = flo ? (__builtin_ctz(flo) >> 3) : 4 + (__builtin_ctz(fhi) >> 3);
+            delim = ((flo ? klo : khi) >> (8 * (len & 3))) & 255u;
+            const uint32_t part = (1u << (8 * (len & 3))) - 1u;          // bytes of the token in its last, partial word
+            klo = len >= 4 ? klo : klo & part;
+            khi = len <= 4 ? 0u : khi & part;
+          } else {                                                      // 8 .. 11 bytes: one more word (few lanes, few steps)
+            kx = __builtin_amdgcn_alignbyte(ring32[(q + 3) & RM], w2, sh);
+            const uint32_t fx = (kx - 0x21212121u) & ~kx & 0x80808080u;
+            if (fx) {
+              len = 8 + (__builtin_ctz(fx) >> 3);
+              delim = (kx >> (8 * (len & 3))) & 255u;
+              kx = kx & ((1u << (8 * (len & 3))) - 1u);
             }
+          }
+          if (len >= 1 && py_isspace(delim)) {
+            const uint32_t smask = (uint32_t)a.short_slots - 1u;
+            const U32x4a *stab = reinterpret_cast<const U32x4a *>(smem + a.off_short);
+            for (uint32_t slot = short_key_hash(klo, khi) & smask;; slot = (slot + 1) & smask) {
+              const U32x4a e = stab[slot];
+              if (e.w == 0u) break;                                     // not among the short keys
+              if (e.x == klo && e.y == khi && e.z == kx) { id = (int)(e.w - 1u); break; }
+            }
+            is_p = len == 3 && klo == 0x003E703Cu;                      // "<p>"
+            fast = id != a.pad_id || !has_m1;                           // (a miss is final unless a key with id -1 was left out of the table)
           }
         }
         if (!fast) {
@@ -1094,6 +1120,7 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
       // ballots.  With a byte per lane a 64-byte piece of a molecule text holds ~13 token starts: four fifths of the lanes sat
       // out the look-ups, which are what the kernel's time is made of.
       const uint32_t *ring32w = reinterpret_cast<const uint32_t *>(ring);
+      int32_t *sidx = reinterpret_cast<int32_t *>(wbase + a.sidx_off);
       for (int sub = 0; sub < kTextChunk / (4 * kWave) && count < a.max_len && !done; ++sub) {
         const int64_t b0 = c0 + sub * (4 * kWave);
         if (b0 >= n) break;
@@ -1112,32 +1139,32 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
         const uint64_t m1 = __ballot(nst >= 1), m2 = __ballot(nst >= 2);
         if (m1 == 0) continue;
         const int pre = __popcll(m1 & lanemask_lt()) + __popcll(m2 & lanemask_lt());   // token starts in the lanes below
-        bool p0 = false, p1 = false;
-        {
-          const int t = count + pre;
-          if (nst >= 1 && t < a.max_len) {
-            int id; lookup(i0 + __builtin_ctz(st4), id, p0);
+        const int T = __popcll(m1) + __popcll(m2);                                     // token starts of this step (<= 128)
+        // the starts are compacted through LDS so that the look-ups - two dependent LDS round trips each - run on FULL lanes:
+        // one dense pass for a molecule text's ~52 tokens per step instead of a first-start pass and a sparse second-start pass
+        if (nst >= 1) sidx[pre] = (int32_t)(i0 - b0) + __builtin_ctz(st4);
+        if (nst >= 2) sidx[pre + 1] = (int32_t)(i0 - b0) + __builtin_ctz(st4 & (st4 - 1u));
+        wave_sync();
+        int first_p = 1 << 30;
+        for (int q0 = 0; q0 < T; q0 += kWave) {
+          const int q = q0 + lane, t = count + q;
+          bool isp = false;
+          if (q < T && t < a.max_len) {
+            int id; lookup(b0 + sidx[q], id, isp);
             if (t < cap) tok[t] = id;
           }
-        }
-        if (m2 != 0) {
-          const int t = count + pre + 1;
-          if (nst >= 2 && t < a.max_len) {
-            int id; lookup(i0 + __builtin_ctz(st4 & (st4 - 1u)), id, p1);
-            if (t < cap) tok[t] = id;
+          if (a.strip_label) {
+            const uint64_t pm = __ballot(isp);
+            if (pm && first_p == (1 << 30)) first_p = q0 + __ffsll((unsigned long long)pm) - 1;
           }
+          if (first_p != (1 << 30) || count + q0 + kWave >= a.max_len) break;
         }
-        const uint64_t pm0 = a.strip_label ? (uint64_t)__ballot(p0) : 0ull, pm1 = a.strip_label ? (uint64_t)__ballot(p1) : 0ull;
-        if (pm0 | pm1) {  // data_loader.py:479-481: keep up to and including the first <p>
-          // ordinal (within this step) of the earliest "<p>": tokens of lower lanes come first, a lane's first before its second
-          auto upto = [&](int l) { const uint64_t below = (1ull << l) - 1ull; return __popcll(m1 & below) + __popcll(m2 & below); };
-          int best = 1 << 30;
-          if (pm0) best = upto(__ffsll((unsigned long long)pm0) - 1);
-          if (pm1) best = min(best, upto(__ffsll((unsigned long long)pm1) - 1) + 1);
-          count += best + 1;
+        wave_sync();                                                  // sidx is rewritten by the next step
+        if (first_p != (1 << 30)) {  // data_loader.py:479-481: keep up to and including the first <p>
+          count += first_p + 1;
           done = true;
         } else {
-          count += __popcll(m1) + __popcll(m2);
+          count += T;
         }
       }
       wave_sync();   // every lane is done with chunk c0: its half of the ring takes chunk +2
@@ -1888,11 +1915,17 @@ extern "C" int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr, i
   a.cap = max_len < ld ? max_len : ld;
   const bool vlds = vocab->capacity <= 1024;   // 24 KB of slots per workgroup
   a.off_vocab = 0;
-  a.off_short = vlds ? align_up(vocab->capacity * kSlotBytes, 16) + 16 : 0;   // + one scratch word for the staging pass
-  a.off_wave = vlds ? a.off_short + vocab->capacity * 16 : 0;
+  a.off_short = (vlds ? align_up(vocab->capacity * kSlotBytes, 16) : 0) + 16;   // + scratch words for the staging passes
+  // the short-key table is made sparser than the vocab table while the workgroup's LDS stays under 40 KB of tables: a token's
+  // look-up is a chain of dependent LDS reads, and a wave waits for the longest chain among its lanes.  A vocab too large for
+  // LDS still gets a short-key table (2048 slots: its first thousand short keys)
+  a.short_slots = vlds ? vocab->capacity : 2048;
+  while (vlds && a.short_slots < 2048 && a.short_slots < 8 * vocab->capacity && a.off_short + 2 * a.short_slots * 16 <= 40 * 1024) a.short_slots *= 2;
+  a.off_wave = a.off_short + a.short_slots * 16;
   a.ring_off = 0;
   a.tok_off = kTextRing;
-  const int64_t wave_bytes = kTextRing + (int64_t)align_up((a.cap > 0 ? a.cap : 1) * 4, 16);
+  a.sidx_off = kTextRing + align_up((a.cap > 0 ? a.cap : 1) * 4, 16);
+  const int64_t wave_bytes = (int64_t)a.sidx_off + 512;
   if (wave_bytes + a.off_wave > 160 * 1024) return GTOK_E_TOO_LARGE;
   a.wave_stride = (int)wave_bytes;
   int wpb = vlds ? 8 : 4;   // the LDS vocab is per workgroup: more waves share one copy

@@ -30,3 +30,10 @@ t_tok, _ = ev(lambda: gtok.ops.text_to_ids(blob, ptr, table, 1024, True, ld=240,
 nbytes = int(blob.numel()); ntok = int(out[1].sum())
 print(f"{G} texts, {nbytes / 1e6:.0f} MB: ibtt_zinc(identity LUT) {t_ids:.3f} ms; ids_to_text (2 launches + host prep) {t_txt * 1e3:.1f} ms; "
       f"text_to_ids {t_tok:.3f} ms = {(nbytes + 4 * ntok) / t_tok / 1e6:.0f} GB/s ({(nbytes + 4 * ntok) / t_tok / 1e6 / 8000:.3f} of 8 TB/s), {ntok / G:.1f} tokens per text")
+
+# the vocab the ZINC trainer really builds: thousands of label tokens on top (capacity > 1024: the full table stays in global memory)
+big = dict(vocab)
+for k in range(3000): big.setdefault(f"val_{k}_{k % 100:02d}", len(big))
+tb = gtok.ops.VocabTable(big, dev)
+t_big, _ = ev(lambda: gtok.ops.text_to_ids(blob, ptr, tb, 1024, True, ld=240, out=out))
+print(f"same texts, vocab of {len(big)} keys (capacity {tb.capacity}): text_to_ids {t_big:.3f} ms = {(nbytes + 4 * ntok) / t_big / 1e6:.0f} GB/s")

@@ -188,3 +188,33 @@ def test_process_parses_text_records_on_the_device(task, tmp_path):
     for a, b in zip(dev_ds, host_ds):
         assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.y, b.y) and a.num_nodes == b.num_nodes
         assert (getattr(a, "query_u", None), getattr(a, "query_v", None)) == (getattr(b, "query_u", None), getattr(b, "query_v", None))
+
+
+def test_text_to_ids_with_a_vocab_too_large_for_lds():
+    """The vocab the ZINC trainer really builds (train_ibtt.py:361-372) carries one `val_x_xx` token per distinct label -
+    thousands of keys, none of which is ever emitted: too large for the workgroup's LDS copy, so the kernel probes the
+    global table for long tokens while the few dozen short keys that do occur are matched through the LDS short-key table
+    (filled shortest keys first until half full; a miss there is not final).  Rows == the oracle's, also with a vocab id of -1
+    and with tokens that are in no table."""
+    d = gtok.synth.zinc_like(4000, seed=77)
+    ds = gdl.ZINCTokenizationDataset(split="train", max_len=1024, zinc_dataset=gtok.synth.InMemoryLike(d))
+    texts = [ds[i]["text"] for i in range(len(ds))]
+    vocab, _ = gdl.build_fixed_zinc_vocab()
+    dyn = []
+    for t in texts:
+        for w in t.split():
+            if w not in vocab and w not in dyn[-50:]:
+                dyn.append(w)
+    vocab = gdl.extend_vocab_with_dynamic_tokens(vocab, dict.fromkeys(dyn))
+    for k in range(3000):                                   # far more label tokens than the texts at hand carry
+        vocab.setdefault(f"val_{k}_{k % 100:02d}", len(vocab))
+    vocab["7"] = -1                                          # an id of -1 stays out of the short-key table
+    vocab.pop("single")                                      # a frequent token that is in no table: pad id
+    assert len(vocab) > 3000
+    blob, ptr = gtok.ops.pack_texts(texts)
+    table = gtok.ops.VocabTable(vocab, DEV)
+    assert table.capacity > 1024
+    for max_len, strip in ((1024, True), (1024, False), (40, True)):
+        ids, ln = gtok.ops.text_to_ids(blob.to(DEV), ptr, table, max_len, strip, ld=256)
+        ref, rln = orc.text_to_ids(texts, vocab, max_len, 256, strip_label=strip, nthreads=8)
+        assert np.array_equal(ln.cpu().numpy(), rln) and np.array_equal(ids.cpu().numpy(), ref), (max_len, strip)
