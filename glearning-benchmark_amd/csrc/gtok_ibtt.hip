@@ -921,31 +921,31 @@ struct TextArgs {
 constexpr int kTextChunk = 1024, kTextRing = 2 * kTextChunk, kSlotBytes = 24, kSlotKey = 19;
 
 struct __attribute__((aligned(16))) U32x4a { uint32_t x, y, z, w; };
+constexpr uint32_t kSlotBusy = 0xFFFFFFFFu;   // short-key slot: claimed, its key not written yet (so a vocab id of -2 stays out of the table, like -1)
 __device__ __forceinline__ uint32_t short_key_hash(uint32_t klo, uint32_t khi) {   // (the first 8 bytes: a key's third word only tells it apart in its slot)
-  const uint32_t h = (klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu);
+  const uint32_t h = (klo ^ __builtin_amdgcn_alignbit(khi, khi, 19)) * 0x9E3779B1u;
   return h ^ (h >> 15);
 }
 
 template <bool VLDS>
-__global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
+__global__ void __launch_bounds__(512, 6) text_ids_kernel(const TextArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = wave_id(), wpb = (int)(blockDim.x >> 6);
   unsigned char *vs = smem + a.off_vocab;
   unsigned char *wbase = smem + a.off_wave + (size_t)wave * a.wave_stride;
   uint8_t *ring = wbase + a.ring_off;
-  int32_t *tok = reinterpret_cast<int32_t *>(wbase + a.tok_off);
   const int cap = a.cap;
   const uint32_t mask = (uint32_t)a.v.capacity - 1u;
   const int64_t total = a.text_ptr[a.num_texts];
 
-  // three scratch words in front of the short-key table: [0] bytes readable at key_bytes (= the end of the last key: the ABI
+  // four scratch words in front of the short-key table: [0] bytes readable at key_bytes (= the end of the last key: the ABI
   // carries no length, and the vector loads below must not leave the array), [1] some short key was left OUT of the short-key
-  // table, [2] short keys placed so far
+  // table, [2] short keys offered so far, [3] short keys in the table (it grows while the texts are split, see `adopt`)
   int *scratch = reinterpret_cast<int *>(smem + a.off_short - 16);
-  if (threadIdx.x == 0) { scratch[0] = 0; scratch[1] = 0; scratch[2] = 0; }
+  if (threadIdx.x == 0) { scratch[0] = 0; scratch[1] = 0; scratch[2] = 0; scratch[3] = 0; }
   __syncthreads();
-  {
+  if (VLDS) {   // (only the 16-byte loads of the slot copy below need it: a key's own bytes are inside the array by definition)
     int my_end = 0;
     for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
       const int off = a.v.key_off[sl];
@@ -954,7 +954,7 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
     atomicMax(scratch, my_end);
   }
   __syncthreads();
-  const int kb_total = scratch[0];
+  const int kb_total = VLDS ? scratch[0] : 0x7FFFFFFF;
   if (VLDS) {   // slot s: id (4 B), length (1 B; 255 = empty), key bytes (one unaligned 16-byte load + 3 bytes)
     for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
       unsigned char *d = vs + (size_t)sl * kSlotBytes;
@@ -978,11 +978,12 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
   // few dozen keys that ever occur in a text): the tokens of a graph-token or molecule text are a few bytes long (node ids,
   // <e>, <bond>, aromatic, regression), so keys of up to 11 bytes are matched as ONE 96-bit value - slot = {lo, mid, hi, id + 1},
   // 0 = empty - instead of a hash loop and a compare loop over their bytes.  Keys of up to 7 bytes go in first, then those of
-  // 8 .. 11, until the table is half full; whatever is left out (and a key whose id is -1) makes a miss non-final: such a
+  // 8 .. 11, while the table is less than a quarter full (they are label tokens, one per text at most: not worth longer probe chains for
+  // every other token); whatever is left out (and a key whose id is -1) makes a miss non-final: such a
   // token takes the byte loops.
   uint32_t *st = reinterpret_cast<uint32_t *>(smem + a.off_short);
   const uint32_t smask_b = (uint32_t)a.short_slots - 1u;
-  for (int sl = (int)threadIdx.x; sl < a.short_slots; sl += (int)blockDim.x) st[sl * 4 + 3] = 0u;
+  for (int sl = (int)threadIdx.x; sl < a.short_slots; sl += (int)blockDim.x) *reinterpret_cast<U32x4a *>(st + sl * 4) = U32x4a{0u, 0u, 0u, 0u};
   __syncthreads();
   for (int pass = 0; pass < 2; ++pass) {
     for (int sl = (int)threadIdx.x; sl < a.v.capacity; sl += (int)blockDim.x) {
@@ -990,7 +991,8 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
       const int len = off < 0 ? 0 : a.v.key_len[sl];
       if (len < (pass ? 8 : 1) || len > (pass ? 11 : 7)) continue;
       const uint32_t idp1 = (uint32_t)a.v.id[sl] + 1u;
-      if (idp1 == 0u || atomicAdd(&scratch[2], 1) >= a.short_slots / 2) { scratch[1] = 1; continue; }
+      if (idp1 == 0u || idp1 == kSlotBusy || atomicAdd(&scratch[2], 1) >= (pass ? a.short_slots / 4 : a.short_slots / 2)) { scratch[1] = 1; continue; }
+      atomicAdd(&scratch[3], 1);
       uint32_t k[3] = {0u, 0u, 0u};
       for (int j = 0; j < len && off + j < kb_total; ++j) k[j >> 2] |= (uint32_t)a.v.key_bytes[off + j] << (8 * (j & 3));
       uint32_t idx = short_key_hash(k[0], k[1]) & smask_b;
@@ -1025,6 +1027,7 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
       ring16[64 + lane] = U8x16a{x1.a, x1.b, x1.c, x1.d};
     }
     wave_sync();
+    int32_t *__restrict__ orow = a.out + (int64_t)g * a.ld;
     int count = 0;
     bool prev_sp = true;  // carry: was the byte before this chunk whitespace
     bool done = false;
@@ -1038,17 +1041,24 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
 #ifdef GTOK_ABLATE_TEXT_LOOKUP   // (profiling builds: no vocab look-up - wrong ids, the time difference is the look-ups')
         id = (int)(i & 7); return;
 #endif
-        bool fast = false;
-        if (i + 12 <= n) {
-          // tokens of up to 11 bytes: the 12 bytes at i (all in the ring and inside the text) as one 96-bit value, cut at
-          // their first whitespace - found with the zero-byte trick on "byte < 33" (ASCII: exact for the lowest flag) -
-          // and looked up in the short-key table.  Anything else (longer, a control character that is not whitespace,
-          // the last bytes of the text, a vocab id of -1) takes the byte loops below.
+        bool fast = false, keyed = false, hit = false;
+        uint32_t klo = 0u, khi = 0u, kx = 0u;
+        {
+          // tokens of up to 11 bytes: the 12 bytes at i (all in the ring; what lies behind the end of the text reads as
+          // spaces) as one 96-bit value, cut at their first whitespace - found with the zero-byte trick on "byte < 33"
+          // (ASCII: exact for the lowest flag) - and looked up in the short-key table.  Anything else (longer, a control
+          // character that is not whitespace, a vocab id of -1) takes the byte loops below.
           const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(ring);
           const uint32_t o = (uint32_t)i & (kTextRing - 1), sh = o & 3u, q = o >> 2;
           constexpr uint32_t RM = kTextRing / 4 - 1;
           const uint32_t w0 = ring32[q], w1 = ring32[(q + 1) & RM], w2 = ring32[(q + 2) & RM];
-          uint32_t klo = __builtin_amdgcn_alignbyte(w1, w0, sh), khi = __builtin_amdgcn_alignbyte(w2, w1, sh), kx = 0u;
+          klo = __builtin_amdgcn_alignbyte(w1, w0, sh); khi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+          const int rem = (int)min((int64_t)12, n - i);                 // bytes of the text at i (>= 1)
+          if (rem < 8) {                                                // (the last token or two of a text)
+            const uint32_t keep_lo = rem >= 4 ? ~0u : (1u << (8 * rem)) - 1u, keep_hi = rem <= 4 ? 0u : (1u << (8 * (rem - 4))) - 1u;
+            klo = (klo & keep_lo) | (0x20202020u & ~keep_lo);
+            khi = (khi & keep_hi) | (0x20202020u & ~keep_hi);
+          }
           const uint32_t flo = (klo - 0x21212121u) & ~klo & 0x80808080u, fhi = (khi - 0x21212121u) & ~khi & 0x80808080u;
           int len = -1;
           uint32_t delim = 0u;
@@ -1060,6 +1070,7 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
             khi = len <= 4 ? 0u : khi & part;
           } else {                                                      // 8 .. 11 bytes: one more word (few lanes, few steps)
             kx = __builtin_amdgcn_alignbyte(ring32[(q + 3) & RM], w2, sh);
+            if (rem < 12) { const uint32_t keep = (1u << (8 * (rem - 8))) - 1u; kx = (kx & keep) | (0x20202020u & ~keep); }
             const uint32_t fx = (kx - 0x21212121u) & ~kx & 0x80808080u;
             if (fx) {
               len = 8 + (__builtin_ctz(fx) >> 3);
@@ -1067,16 +1078,17 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
               kx = kx & ((1u << (8 * (len & 3))) - 1u);
             }
           }
-          if (len >= 1 && py_isspace(delim)) {
+          if (len >= 1 && (VLDS || klo != 0u) && py_isspace(delim)) {    // (klo != 0: a key can never look like a slot being written)
             const uint32_t smask = (uint32_t)a.short_slots - 1u;
             const U32x4a *stab = reinterpret_cast<const U32x4a *>(smem + a.off_short);
             for (uint32_t slot = short_key_hash(klo, khi) & smask;; slot = (slot + 1) & smask) {
               const U32x4a e = stab[slot];
-              if (e.w == 0u) break;                                     // not among the short keys
-              if (e.x == klo && e.y == khi && e.z == kx) { id = (int)(e.w - 1u); break; }
+              if (e.w == 0u || (!VLDS && e.w == kSlotBusy)) break;      // not among the short keys (yet)
+              if (e.x == klo && e.y == khi && e.z == kx) { id = (int)(e.w - 1u); hit = true; break; }
             }
             is_p = len == 3 && klo == 0x003E703Cu;                      // "<p>"
-            fast = id != a.pad_id || !has_m1;                           // (a miss is final unless a key with id -1 was left out of the table)
+            keyed = true;
+            fast = hit || !has_m1;                                      // (a miss is final when every short key of the vocab is in the table)
           }
         }
         if (!fast) {
@@ -1103,14 +1115,35 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
               eq = a.v.key_len[slot] == len;
               for (int j = kSlotKey; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == byte_at(i + j);
             }
-            if (eq) { id = *reinterpret_cast<const int32_t *>(d); break; }
+            if (eq) { id = *reinterpret_cast<const int32_t *>(d); hit = true; break; }
           } else {
             const int off = a.v.key_off[slot];
             if (off < 0) break;
             if (a.v.key_len[slot] != len) continue;
             bool eq = true;
             for (int j = 0; j < len && eq; ++j) eq = a.v.key_bytes[off + j] == byte_at(i + j);
-            if (eq) { id = a.v.id[slot]; break; }
+            if (eq) { id = a.v.id[slot]; hit = true; break; }
+          }
+        }
+        // a short key that was left out of the table at set-up and does occur in the texts ("regression" behind three
+        // thousand val_* label tokens) is ADOPTED: its next look-up is one LDS read instead of these byte loops over global
+        // memory (only there: a vocab small enough for LDS has its byte loops in LDS).  The slot is claimed (its id word -> busy), the key written, then the id: a reader that meets a busy slot,
+        // or the words of a slot mid-write (zeros: no key is zero), just misses and comes here.
+        if (!VLDS && keyed && hit) {
+          const uint32_t idp1 = (uint32_t)id + 1u, smask = (uint32_t)a.short_slots - 1u;
+          uint32_t *stw = reinterpret_cast<uint32_t *>(smem + a.off_short);
+          if (idp1 != 0u && idp1 != kSlotBusy && atomicAdd(&scratch[3], 1) < a.short_slots / 2) {
+            for (uint32_t slot = short_key_hash(klo, khi) & smask;; slot = (slot + 1) & smask) {
+              const uint32_t was = atomicCAS(&stw[slot * 4 + 3], 0u, kSlotBusy);
+              if (was == 0u) {
+                stw[slot * 4 + 0] = klo; stw[slot * 4 + 1] = khi; stw[slot * 4 + 2] = kx;
+                __threadfence_block();
+                __hip_atomic_store(&stw[slot * 4 + 3], idp1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                break;
+              }
+              if (was == kSlotBusy) break;                              // another wave is writing here - perhaps this very key
+              if (stw[slot * 4 + 0] == klo && stw[slot * 4 + 1] == khi && stw[slot * 4 + 2] == kx) break;   // adopted meanwhile
+            }
           }
         }
         }
@@ -1128,13 +1161,15 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
         uint32_t w = ring32w[((uint32_t)i0 & (kTextRing - 1)) >> 2];
         const int64_t left = n - i0;                                  // bytes of the text in this dword; the rest reads as spaces
         if (left < 4) w = left <= 0 ? 0x20202020u : ((w & ((1u << (8 * (int)left)) - 1u)) | (0x20202020u << (8 * (int)left)));
-        uint32_t sp4 = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) sp4 |= py_isspace((w >> (8 * b)) & 255u) ? 1u << b : 0u;
-        const uint64_t lastsp = __ballot((sp4 & 8u) != 0u);
-        const uint32_t before0 = lane == 0 ? (prev_sp ? 1u : 0u) : (uint32_t)((lastsp >> (lane - 1)) & 1ull);
+        // Python's ASCII whitespace - 9..13, 28..32 - for the four bytes at once, flags in bit 7 of each byte: "byte >= c" is bit 7
+        // of (byte & 0x7F) + (0x80 - c), exact per byte (no carry leaves a byte), bytes >= 0x80 are never whitespace
+        const uint32_t lo7 = w & 0x7F7F7F7Fu;
+        const uint32_t ge9 = lo7 + 0x77777777u, ge14 = lo7 + 0x72727272u, ge28 = lo7 + 0x64646464u, ge33 = lo7 + 0x5F5F5F5Fu;
+        const uint32_t sp4 = ((ge9 & ~ge14) | (ge28 & ~ge33)) & ~w & 0x80808080u;
+        const uint64_t lastsp = __ballot((sp4 >> 31) != 0u);
+        const uint32_t before0 = lane == 0 ? (prev_sp ? 0x80u : 0u) : (uint32_t)((lastsp >> (lane - 1)) & 1ull) << 7;
         prev_sp = (lastsp >> 63) & 1ull;
-        const uint32_t st4 = ~sp4 & ((sp4 << 1) | before0) & 15u;     // bit b: byte b starts a token
+        const uint32_t st4 = ~sp4 & ((sp4 << 8) | before0) & 0x80808080u;     // bit 7 of byte b: byte b starts a token
         const int nst = __popc(st4);
         const uint64_t m1 = __ballot(nst >= 1), m2 = __ballot(nst >= 2);
         if (m1 == 0) continue;
@@ -1142,21 +1177,33 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
         const int T = __popcll(m1) + __popcll(m2);                                     // token starts of this step (<= 128)
         // the starts are compacted through LDS so that the look-ups - two dependent LDS round trips each - run on FULL lanes:
         // one dense pass for a molecule text's ~52 tokens per step instead of a first-start pass and a sparse second-start pass
-        if (nst >= 1) sidx[pre] = (int32_t)(i0 - b0) + __builtin_ctz(st4);
-        if (nst >= 2) sidx[pre + 1] = (int32_t)(i0 - b0) + __builtin_ctz(st4 & (st4 - 1u));
+        if (nst >= 1) sidx[pre] = (int32_t)(i0 - b0) + (__builtin_ctz(st4) >> 3);
+        if (nst >= 2) sidx[pre + 1] = (int32_t)(i0 - b0) + (__builtin_ctz(st4 & (st4 - 1u)) >> 3);
         wave_sync();
         int first_p = 1 << 30;
         for (int q0 = 0; q0 < T; q0 += kWave) {
           const int q = q0 + lane, t = count + q;
           bool isp = false;
-          if (q < T && t < a.max_len) {
-            int id; lookup(b0 + sidx[q], id, isp);
-            if (t < cap) tok[t] = id;
-          }
+          int id = a.pad_id;
+          bool mine = q < T && t < a.max_len;
+          const int64_t ti = mine ? b0 + sidx[q] : 0;
           if (a.strip_label) {
+            // "<p>" is found BEFORE the look-ups: what follows it - the label, <eos> - is cut (data_loader.py:479-481), and a
+            // label token is the one kind a large vocab's short-key table may not hold (thousands of val_* keys)
+            if (mine && ti + 3 <= n) {
+              const uint32_t o = (uint32_t)ti & (kTextRing - 1), q4 = o >> 2;
+              const uint32_t k = __builtin_amdgcn_alignbyte(ring32w[(q4 + 1) & (kTextRing / 4 - 1)], ring32w[q4], o & 3u);
+              isp = (k & 0x00FFFFFFu) == 0x003E703Cu && (ti + 3 == n || py_isspace(k >> 24));
+            }
             const uint64_t pm = __ballot(isp);
-            if (pm && first_p == (1 << 30)) first_p = q0 + __ffsll((unsigned long long)pm) - 1;
+            if (pm) first_p = q0 + __ffsll((unsigned long long)pm) - 1;
+            mine = mine && q <= first_p;
           }
+          bool isp2;
+          if (mine) lookup(ti, id, isp2);
+          // ids go straight to the row: lane q holds token count + q, so a pass is one coalesced run of stores (no staging
+          // in LDS, no second pass over the row); nothing behind the first "<p>" is written
+          if (mine && t < cap && q <= first_p) orow[t] = id;
           if (first_p != (1 << 30) || count + q0 + kWave >= a.max_len) break;
         }
         wave_sync();                                                  // sidx is rewritten by the next step
@@ -1174,7 +1221,7 @@ __global__ void __launch_bounds__(512) text_ids_kernel(const TextArgs a) {
     wave_sync();
     const int len = min(count, a.max_len);
 #ifndef GTOK_ABLATE_TEXT_WRITE
-    write_row(a.out + (int64_t)g * a.ld, a.ld, min(len, cap), a.pad_id, [=](int i) -> int { return tok[i]; });
+    for (int i = min(len, cap) + lane; i < a.ld; i += kWave) orow[i] = a.pad_id;      // the tokens are in place: only the tail is left
 #endif
     if (lane == 0) a.out_len[g] = len;
     wave_sync();
@@ -1924,11 +1971,11 @@ extern "C" int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr, i
   a.off_wave = a.off_short + a.short_slots * 16;
   a.ring_off = 0;
   a.tok_off = kTextRing;
-  a.sidx_off = kTextRing + align_up((a.cap > 0 ? a.cap : 1) * 4, 16);
+  a.sidx_off = kTextRing;                     // (ids go straight to the output row: no token staging in LDS)
   const int64_t wave_bytes = (int64_t)a.sidx_off + 512;
   if (wave_bytes + a.off_wave > 160 * 1024) return GTOK_E_TOO_LARGE;
   a.wave_stride = (int)wave_bytes;
-  int wpb = vlds ? 8 : 4;   // the LDS vocab is per workgroup: more waves share one copy
+  int wpb = 8;              // the LDS tables are per workgroup: more waves share one copy (and one set-up)
   while (wpb > 1 && a.off_wave + wpb * a.wave_stride > 80 * 1024) wpb >>= 1;   // two workgroups per CU
   const size_t lds = (size_t)a.off_wave + (size_t)wpb * a.wave_stride;
   typedef void (*K)(const TextArgs);

@@ -218,3 +218,38 @@ def test_text_to_ids_with_a_vocab_too_large_for_lds():
         ids, ln = gtok.ops.text_to_ids(blob.to(DEV), ptr, table, max_len, strip, ld=256)
         ref, rln = orc.text_to_ids(texts, vocab, max_len, 256, strip_label=strip, nthreads=8)
         assert np.array_equal(ln.cpu().numpy(), rln) and np.array_equal(ids.cpu().numpy(), ref), (max_len, strip)
+
+
+def test_text_to_ids_adopts_left_out_short_keys_while_splitting():
+    """With a large vocab the short-key table of a workgroup is filled at set-up only part of the way (keys of up to 7 bytes
+    first, 8..11-byte ones while it is under a quarter full); a left-out key that does occur in the texts is adopted into the
+    table by the first look-up that finds it the slow way.  Texts that use MORE distinct 8..11-byte keys than the table can
+    ever hold, the same key many times per step, ids of -1 and -2 (never in the table: -2 + 1 is the busy mark), a token that
+    is a single NUL byte (an all-zero key - what a slot mid-write looks like), unknown tokens and labels at the very end of a
+    text (the last 12 bytes go through the same path now): rows == the oracle's."""
+    rng = np.random.default_rng(31)
+    vocab = {"<pad>": 0, "<bos>": 1, "<p>": 2, "<eos>": 3, "regression": 4, "aromatic": 5, "\0": 6}
+    for k in range(5000):
+        vocab.setdefault(f"key_{k:05d}", len(vocab))          # 9 bytes each: far more than 2048 slots take
+    for k in range(60):
+        vocab.setdefault(str(k), len(vocab))
+    vocab["key_00007"] = -1
+    vocab["key_00008"] = -2
+    vocab["11"] = -2
+    names = list(vocab)
+    texts = []
+    for t in range(3000):
+        hot = [names[int(j)] for j in rng.integers(0, len(names), 6)]
+        toks = ["<bos>"] + [hot[int(j)] if rng.random() < 0.7 else names[int(rng.integers(0, len(names)))]
+                            for j in rng.integers(0, 6, int(rng.integers(0, 160)))]
+        toks += ["regression", "nokey_123", "aromatic", "\0", "regression"]
+        toks += ["<p>", f"key_{t % 5000:05d}"] + (["<eos>"] if t % 3 else [])
+        texts.append(" ".join(toks) + (" " if t % 5 == 0 else ""))
+    texts += ["key_00009", "\0", "\0 \0", "<p>", "key_00008", ""]
+    blob, ptr = gtok.ops.pack_texts(texts)
+    table = gtok.ops.VocabTable(vocab, DEV)
+    assert table.capacity > 1024
+    for max_len, strip in ((256, False), (256, True), (33, False)):
+        ids, ln = gtok.ops.text_to_ids(blob.to(DEV), ptr, table, max_len, strip, ld=256)
+        ref, rln = orc.text_to_ids(texts, vocab, max_len, 256, strip_label=strip, nthreads=8)
+        assert np.array_equal(ln.cpu().numpy(), rln) and np.array_equal(ids.cpu().numpy(), ref), (max_len, strip)
