@@ -41,20 +41,26 @@ struct __attribute__((aligned(4))) U32x2a4 { uint32_t lo, hi; };   // two dwords
 // its sign, spread over the word, ORs the level's bit into the answer.  (The halving version - mask, popcount, compare, two
 // selects, subtract per level - was 7 per level and serialised on VCC.)
 __device__ __forceinline__ int kth_bit32(uint32_t x, int k) {
+  // Priced with profiles/tools/probes/valu_op_cost_probe.hip (SIMD cycles per wave64 instruction, 4 waves per SIMD: add / sub / and /
+  // or / xor / lshr / bitop3 ~2.2 - 2.6, everything else - lshl, bfe, bcnt, and_or, perm, ... - 4.2): the low `mid` bits of x
+  // are the TOP `mid` bits of its bit reversal, so a right shift (2.2) stands in for the bit-field extract (4.2); the sign
+  // of popcount - k - 1 is moved onto the level's bit with a right shift and merged with one bitop3 (was ashr + and_or).
   const uint32_t nk = ~(uint32_t)k;                       // -k - 1
+  const uint32_t y = __builtin_bitreverse32(x);
   uint32_t base = 0;
-#pragma unroll
-  for (uint32_t half = 16; half >= 1; half >>= 1) {
-    // (written out: left to itself the compiler turns the sign trick back into compare + select, with VCC hazard nops)
-    uint32_t mid, t, d;
-    asm("v_or_b32 %0, %3, %4\n\t"
-        "v_bfe_u32 %1, %5, 0, %0\n\t"
-        "v_bcnt_u32_b32 %2, %1, %6\n\t"
-        "v_ashrrev_i32 %2, 31, %2\n\t"
-        "v_and_or_b32 %0, %2, %4, %3"
-        : "=&v"(mid), "=&v"(t), "=&v"(d) : "v"(base), "n"(half), "v"(x), "v"(nk));
-    base = mid;
+#define GTOK_KTH_LEVEL(HALF, LOG)                                                                  \
+  {                                                                                                \
+    uint32_t mid, t, d;                                                                            \
+    asm("v_sub_u32 %0, %4, %3\n\t"         /* 32 - (base + half) */                               \
+        "v_lshrrev_b32 %1, %0, %5\n\t"     /* the low base + half bits of x */                    \
+        "v_bcnt_u32_b32 %2, %1, %6\n\t"    /* their popcount - k - 1: negative = bit k is above */ \
+        "v_lshrrev_b32 %2, %7, %2\n\t"     /* sign -> the level's bit */                          \
+        "v_bitop3_b32 %0, %2, %8, %3 bitop3:0xea"   /* base | (sign & half) */                      \
+        : "=&v"(mid), "=&v"(t), "=&v"(d) : "v"(base), "n"(32 - HALF), "v"(y), "v"(nk), "n"(31 - LOG), "n"(HALF)); \
+    base = mid;                                                                                    \
   }
+  GTOK_KTH_LEVEL(16, 4) GTOK_KTH_LEVEL(8, 3) GTOK_KTH_LEVEL(4, 2) GTOK_KTH_LEVEL(2, 1) GTOK_KTH_LEVEL(1, 0)
+#undef GTOK_KTH_LEVEL
   return (int)base;
 }
 
