@@ -20,7 +20,8 @@ prof() { local log=$1; shift; "$@" > $log 2>&1; local rc=$?; find $out -name '*_
 # counters are collected for OUR kernels only (--kernel-include-regex gtok): the corpora are sampled by thousands of torch
 # launches, which made counter collection of synth_mix impractical before
 for wl in zinc_full synth_er synth_mix zinc_subset; do
-  step prof $out/stats_$wl.log timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o s -- $B --workload $wl --no-cpu-baseline --no-unpadded --no-boundary --no-sustained
+  # (the sustained leg stays in: it is part of the command that prints the bench line, and its launches are the steady state the K steps run in)
+  step prof $out/stats_$wl.log timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o s -- $B --workload $wl --no-cpu-baseline --no-unpadded --no-boundary
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS"; do
     name=$(echo $grp | cut -d' ' -f1)
     step prof $out/pmc_${wl}_$name.log timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex gtok --output-format csv -d $out/pmc_${wl}_$name -o p -- python3 bench.py --steps 5 --warmup 1 --workload $wl --no-cpu-baseline --no-unpadded --no-boundary --no-sustained
