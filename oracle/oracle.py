@@ -327,6 +327,21 @@ def sent_decode(tokens, max_num_nodes, labeled=False, num_node_types=0):
     return nseen, edges, ntypes, etypes, i
 
 
+# ---- rows of ids -> texts (include/gtok.h, gtok_ids_to_text): the format itself, in Python ------------------------------
+def ids_to_text(ids, take, strings, suffixes=None):
+    """Row r = the strings of its first take[r] ids (ids outside the table: empty strings) joined by single spaces, then the
+    row's suffix bytes verbatim - what zinc_dataset_indexbase.py:143-227 builds with ' '.join(tokens) once the tokens are ids
+    of a string table.  Returns a list of bytes objects."""
+    ids = np.asarray(ids, np.int32)
+    enc = [t.encode("ascii") if isinstance(t, str) else bytes(t) for t in strings]
+    out = []
+    for r in range(ids.shape[0]):
+        k = min(max(int(take[r]), 0), ids.shape[1])
+        words = [enc[t] if 0 <= t < len(enc) else b"" for t in ids[r, :k].tolist()]
+        out.append(b" ".join(words) + (bytes(suffixes[r]) if suffixes is not None else b""))
+    return out
+
+
 # ---- packed rows (include/gtok.h, "packed (ragged) rows"): numpy restatement of the format itself ----------------
 def row_offsets(ln, ld, align=8):
     n = np.clip(np.asarray(ln, np.int64), 0, ld)

@@ -144,3 +144,31 @@ def test_packed_rows_as_torch_custom_ops():
     idx = torch.arange(0, 500, 7, device=DEV)
     X, A = torch.ops.gtok.collate_packed(packed, ptr, d_ln, 48, idx, 7, 48)
     assert torch.equal(X.to(torch.int32), back[idx]) and torch.equal(A, torch.from_numpy(keep).to(DEV)[idx])
+
+
+def test_ids_to_text_against_the_python_statement_of_the_format():
+    """gtok_ids_to_text (two passes: lengths, then bytes) on its own: empty rows, take of 0 / 1 / the whole row / beyond it,
+    ids outside the string table (empty strings, their separators stay), empty strings inside the table, with and without
+    suffixes (also empty ones), one row and thousands.  The ZINC strings as a whole are checked against the reference's golden
+    texts in test_gpu_boundary.py; this pins the format."""
+    rng = np.random.default_rng(17)
+    strings = ["<bos>", "", "C", "Cl", "aromatic", "x" * 37, "7"] + [str(i) for i in range(40)]
+    for rows, ld in ((1, 1), (1, 9), (5, 16), (3001, 70), (64, 257)):
+        ids = rng.integers(-2, len(strings) + 3, (rows, ld)).astype(np.int32)
+        take = rng.integers(0, ld + 1, rows).astype(np.int32)
+        take[rng.integers(0, rows, max(1, rows // 5))] = 0
+        take[rng.integers(0, rows, max(1, rows // 7))] = ld
+        if rows > 2:
+            take[1] = ld + 5                                   # clamped to the row
+        suf = [b"" if r % 3 == 0 else (b" val_%d_%02d <eos>" % (r, r % 100)) for r in range(rows)]
+        d_ids, d_take = torch.from_numpy(ids).to(DEV), torch.from_numpy(take).to(DEV)
+        for sfx in (suf, None):
+            blob, ptr = gtok.ops.ids_to_text(d_ids, d_take, strings, sfx)
+            want = orc.ids_to_text(ids, take, strings, sfx)
+            p, b = ptr.cpu().numpy(), blob.cpu().numpy().tobytes()
+            assert p[0] == 0 and p[-1] == len(b) == sum(map(len, want))
+            got = [b[p[r]:p[r + 1]] for r in range(rows)]
+            assert got == want, next((r, got[r], want[r]) for r in range(rows) if got[r] != want[r])
+    e_ids = torch.empty((0, 8), dtype=torch.int32, device=DEV)
+    blob, ptr = gtok.ops.ids_to_text(e_ids, torch.empty(0, dtype=torch.int32, device=DEV), strings, [])
+    assert blob.numel() == 0 and ptr.tolist() == [0]

@@ -29,6 +29,29 @@ def test_ibtt_zinc_matches_reference(max_len):
     assert unpad(ids, ln) == unpad(arr[f"zinc_L{max_len}_ids"], want_len)
 
 
+@pytest.mark.parametrize("max_len", [1024, 48])
+def test_ids_to_text_statement_renders_the_reference_strings(max_len):
+    """The oracle's statement of gtok_ids_to_text (rows of string-table positions joined by spaces + a per-row suffix), fed
+    with the serialiser's ids under the identity LUT and the label / cut rule of zinc_dataset_indexbase.py:192, :217-221, gives
+    the texts the reference itself produced for the golden molecules: the format the device renderer is compared with is
+    pinned by reference data, not only by its own definition."""
+    from importlib import import_module
+    zmod = import_module(gtok.__name__ + ".graph_data_loader.zinc_dataset_indexbase")
+    _, meta = golden()
+    d = golden_zinc_coo()
+    coo = orc.Coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+    strings = ["<bos>", "<eos>", "<atom>", "<bond>", "<q>", "regression", "<p>"] + list(gtok.ops.ZINC_ATOM_SYMBOLS) \
+        + list(gtok.ops.ZINC_BOND_NAMES) + [str(i) for i in range(int(d["node_counts"].max()))]
+    ids, ln = orc.ibtt_zinc(coo, np.arange(len(strings), dtype=np.int32), 1 << 30, 0, 6 + 6 * int(d["node_counts"].max()) + 8)
+    ln = ln.astype(np.int64)
+    cut = ln + 2 > max_len                                      # tokens = ids + [label, <eos>]
+    take = np.where(cut, max_len - 1, ln)
+    tail = [(b" <eos>" if k else b"<eos>") if c else (" " + zmod._label_token(float(v)) + " <eos>").encode("ascii")
+            for c, k, v in zip(cut.tolist(), take.tolist(), d["y"].tolist())]
+    texts = [t.decode("ascii") for t in orc.ids_to_text(ids, take, strings, tail)]
+    assert texts == meta[f"zinc_L{max_len}_texts"]
+
+
 @pytest.mark.parametrize("task", ["cycle_check", "shortest_path"])
 @pytest.mark.parametrize("vname,max_len", [("", 600), ("", 64), ("_v40", 600), ("_v40", 64)])
 def test_text_to_ids_matches_reference(task, vname, max_len):
