@@ -437,21 +437,32 @@ __global__ void __launch_bounds__(64) ibtt_zinc_quad_kernel(const ZincQuadArgs a
   };
   auto load_dat = [&](int unit, const Hdr &h) -> Dat {
     Dat d;
-    const int g = (unit < u1 && unit * NG + grp < G) ? unit * NG + grp : 0;   // idle groups read graph 0's first words
-    const int32_t *__restrict__ rp = a.g.rowptr + h.nb0 + g;
-    const uint8_t *__restrict__ rp8 = PK ? a.g.rowptr8 + h.nb0 + g : nullptr;
+    const bool live = unit < u1 && unit * NG + grp < G;
+    const int g = live ? unit * NG + grp : 0;                                  // idle groups read graph 0's first words
+    // every address is a wave-uniform base (scalar registers) + an unsigned 32-bit lane offset: one or two vector
+    // instructions per load instead of a 64-bit clamp and add (the unit's groups are consecutive graphs, so their
+    // entry ranges start within 2^31 of the first group's)
+    const uint32_t rb = (uint32_t)(h.nb0 + g);                                  // this group's row pointers (node_ptr + graph index)
+    const uint32_t nlast = (uint32_t)max(h.nb0 + h.n - 1, 0);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int i = ql + GS * j;
-      d.rs[j] = PK ? (int)rp8[min(i, h.n)] : rp[min(i, h.n)];
-      d.re[j] = PK ? (int)rp8[min(i + 1, h.n)] : rp[min(i + 1, h.n)];
-      d.x[j] = ld_na ? (int)a.g.nattr[min(max(h.nb0 + min(i, h.n - 1), 0), Ntot - 1)] : 255;
+      const uint32_t i0 = rb + (uint32_t)min(i, h.n), i1 = rb + (uint32_t)min(i + 1, h.n);
+      d.rs[j] = PK ? (int)a.g.rowptr8[i0] : a.g.rowptr[i0];
+      d.re[j] = PK ? (int)a.g.rowptr8[i1] : a.g.rowptr[i1];
+      d.x[j] = ld_na ? (int)a.g.nattr[min(min((uint32_t)h.nb0 + (uint32_t)i, nlast), (uint32_t)(Ntot - 1))] : 255;
     }
+    const int64_t ebase = max(min((int64_t)uni((uint64_t)h.e0), Etot - 1), (int64_t)0);   // group 0's first entry, inside the array (0 for an idle unit)
+    const uint32_t ehi = (uint32_t)min(Etot - 1 - ebase, (int64_t)0x7fffffff);  // last readable entry behind the base
+    const uint8_t *__restrict__ c8 = PK ? a.g.col8 + ebase : nullptr;
+    const int32_t *__restrict__ c32 = a.g.col + ebase;
+    const uint8_t *__restrict__ ea = a.g.eattr + ebase;
+    const int erel = live ? (int)(h.e0 - ebase) : 0;
 #pragma unroll
     for (int j = 0; j < EP; ++j) {
-      const int64_t k = min(max(h.e0 + min(ql + GS * j, h.e - 1), (int64_t)0), Etot - 1);
-      d.v[j] = ld_col ? (PK ? (int)a.g.col8[k] : a.g.col[k]) : 0;
-      d.at[j] = ld_ea ? (int)a.g.eattr[k] : 0;
+      const uint32_t k = min((uint32_t)max(erel + min(ql + GS * j, h.e - 1), 0), ehi);
+      d.v[j] = ld_col ? (PK ? (int)c8[k] : c32[k]) : 0;
+      d.at[j] = ld_ea ? (int)ea[k] : 0;
     }
     return d;
   };
