@@ -48,6 +48,22 @@ __device__ __forceinline__ int kth_bit_reg(uint64_t word, int k) {
   return __builtin_ctzll(eq & word);   // k < popcount(word): never empty
 }
 
+// Node sets as one 32-bit word when the graph has at most 32 nodes (nearly every ZINC molecule): a row read is one
+// v_readlane instead of two, the below-count one v_mbcnt instead of two, and the scalar set arithmetic 32-bit.
+template <typename S> __device__ __forceinline__ S readlane_set(S x, int l);
+template <> __device__ __forceinline__ uint64_t readlane_set<uint64_t>(uint64_t x, int l) { return readlane64(x, l); }
+template <> __device__ __forceinline__ uint32_t readlane_set<uint32_t>(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
+__device__ __forceinline__ int popc_set(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ int popc_set(uint32_t x) { return __popc(x); }
+__device__ __forceinline__ int ctz_set(uint64_t x) { return __builtin_ctzll(x); }
+__device__ __forceinline__ int ctz_set(uint32_t x) { return __builtin_ctz(x); }
+__device__ __forceinline__ int mbcnt_set(uint64_t m) { return mbcnt64(m); }
+__device__ __forceinline__ int mbcnt_set(uint32_t m) { return (int)__builtin_amdgcn_mbcnt_lo(m, 0u); }   // (lanes >= 32 count all of m: never equal to a k < popcount)
+template <typename S> __device__ __forceinline__ int kth_bit_set(S word, int k) {
+  const S eq = (S)__ballot(mbcnt_set(word) == k);
+  return ctz_set((S)(eq & word));   // k < popcount(word): never empty
+}
+
 // Wave-uniform reads of the read-only graph pointers as SCALAR loads (constant address space): the
 // compiler will not prove invariance through the by-value argument struct on its own.
 typedef const int32_t __attribute__((address_space(4))) *kptr32;
@@ -199,7 +215,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     // never modified afterwards: for a visited node c the uncovered edges are exactly adj[c] & ~vis.
     // Edge types: et[a][b] = type of the first listed entry a->b, else of the first b->a — reverse cells
     // first, forward cells on top, each lane walking its row backwards so the earliest entry wins.
-    uint64_t adj = 0;
+    int pos = 0;
+    auto walk_body = [&](auto set_tag) __attribute__((always_inline)) {
+    using set_t = decltype(set_tag);
+    constexpr int kSetBits = (int)sizeof(set_t) * 8;
+    set_t adj = 0;
     if (a.g.flags & GTOK_CSR_SIMPLE_SYMMETRIC) {
       // host-verified simple undirected graphs listed in both directions: a node's row IS its neighbour set and the
       // type of (a,b) is the type of the listed entry a->b - one pass over the own row, no transposed bits, no atomics
@@ -214,7 +234,7 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (k0 + j < re && (unsigned)v[j] < (unsigned)n) {
-            adj |= 1ull << v[j];
+            adj |= (set_t)1 << v[j];
             if (LAB) et[lane * S + v[j]] = (uint8_t)at[j];
           }
         }
@@ -231,7 +251,7 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
 #pragma unroll
       for (int j = 3; j >= 0; --j) {
         if (k0 + j < re && (unsigned)v[j] < (unsigned)n) {
-          adj |= 1ull << v[j];
+          adj |= (set_t)1 << v[j];
           atomicOr(reinterpret_cast<unsigned long long *>(&adjT[v[j]]), 1ull << lane);
           if (LAB) et[v[j] * S + lane] = (uint8_t)at[j];            // reverse cell
         }
@@ -252,7 +272,7 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
           if (k0 + j < re && (unsigned)v[j] < (unsigned)n) et[lane * S + v[j]] = (uint8_t)at[j];   // forward cell on top
       }
     }
-    adj |= adjT[lane];
+    adj |= (set_t)adjT[lane];
     }
 
     // ---- walk.  The kernel is bound by SCALAR issue (measured: ~1000 SALU vs ~900 VALU per molecule, scalar
@@ -266,7 +286,7 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
 #define GTOK_TOK_ORDER() asm volatile("" ::: "memory")
     int vz;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-    uint64_t vis = 0, bcur = 0;
+    set_t vis = 0, bcur = 0;
     int d = 0, cur = 0, ord = 0;
     uint16_t *tokp = tok + 1 + lane;          // slot of this lane at the running position (pos = 1 after SOS)
     int vptok = vz + pos_base;                // position token of the next new node
@@ -284,10 +304,10 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       return __umulhi(x, nchoices);
     };
     // neighbourhood bracket of the node just visited: LADJ [edge ref] position ... RADJ   (uncommon path)
-    auto bracket = [&](int v, uint64_t A) {
-      const int nv = __popcll(vis);
+    auto bracket = [&](int v, set_t A) {
+      const int nv = popc_set(vis);
       const int pos = (int)(__builtin_amdgcn_readfirstlane((int)(uintptr_t)tokp) - (int)(uintptr_t)tok) >> 1;
-      const bool member = (lane < nv) && ((A >> ord) & 1ull);     // lane = visit index: ascending order for free
+      const bool member = (lane < nv) && ((A >> ord) & (set_t)1);     // lane = visit index: ascending order for free
       const uint64_t M = __ballot(member);
       const int cnt = __popcll(M);
       if (is0) { tok[pos] = (uint16_t)T_LADJ; tok[pos + 1 + per * cnt] = (uint16_t)T_RADJ; }
@@ -302,7 +322,7 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     // first visit of v as a start / restart node (no incoming trail edge): position [type]
     auto start_at = [&](int v) {
       ord = (lane == vnv) ? v : ord;
-      const uint64_t bv = 1ull << v;
+      const set_t bv = (set_t)1 << v;
       vis |= bv;
       int t = LAB ? __builtin_amdgcn_readlane(nat, v) : vptok;
       t = is0 ? vptok : t;
@@ -310,7 +330,7 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       GTOK_TOK_ORDER();
       tokp += per;
       vptok += 1; vnv += 1;
-      const uint64_t A = readlane64(adj, v) & vis;   // only a self loop can be in there
+      const set_t A = readlane_set<set_t>(adj, v) & vis;   // only a self loop can be in there
       if (A) bracket(v, A);
       cur = v; bcur = bv; vcur6 = ((vz + v) << 6) | kEdgeRef;
     };
@@ -324,15 +344,15 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
       start_at((int)below((uint32_t)n));
       for (;;) {
         // extend the trail while the current node has an uncovered edge (it always leads to an unvisited node)
-        uint64_t row = readlane64(adj, cur) & ~vis;
+        set_t row = readlane_set<set_t>(adj, cur) & ~vis;
         while (row) {
           if (!NOLIM) {
             const int pos = (int)(__builtin_amdgcn_readfirstlane((int)(uintptr_t)tokp) - (int)(uintptr_t)tok) >> 1;
             if (pos >= lim) break;
           }
-          const int nxt = kth_bit_reg(row, (int)below((uint32_t)__popcll(row)));
+          const int nxt = kth_bit_set<set_t>(row, (int)below((uint32_t)popc_set(row)));
           ord = (lane == vnv) ? nxt : ord;
-          const uint64_t bn = 1ull << nxt;
+          const set_t bn = (set_t)1 << nxt;
           vis |= bn;
           if (LAB) {   // [edge ref] position type in ONE store from lanes 0..2
             int t = __builtin_amdgcn_readlane(nat, nxt);
@@ -348,8 +368,8 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
           }
           vptok += 1; vnv += 1;
           // uncovered edges back to visited nodes (nxt included: self loop), minus the trail edge just taken
-          const uint64_t adjn = readlane64(adj, nxt);
-          const uint64_t A = adjn & vis & ~bcur;
+          const set_t adjn = readlane_set<set_t>(adj, nxt);
+          const set_t A = adjn & vis & ~bcur;
           if (A) bracket(nxt, A);
           cur = nxt; bcur = bn; vcur6 = ((vz + nxt) << 6) | kEdgeRef;
           row = adjn & ~vis;
@@ -359,20 +379,20 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
           if (pos >= lim) break;
         }
         // dead end: visited nodes that still own uncovered edges
-        const uint64_t live = (uint64_t)__ballot((adj & ~vis) != 0) & vis;
-        const int nv = __popcll(vis);
+        const set_t live = (set_t)__ballot((adj & ~vis) != 0) & vis;
+        const int nv = popc_set(vis);
         if (live) {
-          const int c = kth_bit_reg(live, (int)below((uint32_t)__popcll(live)));
+          const int c = kth_bit_set<set_t>(live, (int)below((uint32_t)popc_set(live)));
           const int k = __builtin_ctzll((uint64_t)__ballot(lane < nv && ord == c));   // its visit index
           *tokp = (uint16_t)(is0 ? T_RESET : pos_base + k);
           GTOK_TOK_ORDER();
           tokp += 2;
-          cur = c; bcur = 1ull << c; vcur6 = ((vz + c) << 6) | kEdgeRef;
+          cur = c; bcur = (set_t)1 << c; vcur6 = ((vz + c) << 6) | kEdgeRef;
           continue;
         }
         if (nv < n) {  // another component or an isolated node
-          const uint64_t un = ~vis & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
-          const int c = kth_bit_reg(un, (int)below((uint32_t)(n - nv)));
+          const set_t un = ~vis & (n >= kSetBits ? (set_t)~(set_t)0 : (set_t)(((set_t)1 << n) - (set_t)1));
+          const int c = kth_bit_set<set_t>(un, (int)below((uint32_t)(n - nv)));
           *tokp = (uint16_t)T_RESET;
           GTOK_TOK_ORDER();
           tokp += 1;
@@ -384,7 +404,9 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     }
     *tokp = (uint16_t)T_EOS;
     GTOK_TOK_ORDER();
-    const int pos = ((int)(__builtin_amdgcn_readfirstlane((int)(uintptr_t)tokp) - (int)(uintptr_t)tok) >> 1) + 1;
+    pos = ((int)(__builtin_amdgcn_readfirstlane((int)(uintptr_t)tokp) - (int)(uintptr_t)tok) >> 1) + 1;
+    };
+    if (n <= 32) walk_body((uint32_t)0); else walk_body((uint64_t)0);
 #undef GTOK_TOK_ORDER
 
     // ---- row out: resolve edge-type placeholders, append the query, pad
