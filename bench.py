@@ -48,6 +48,27 @@ def event_ms(pairs):
     return [s.elapsed_time(e) for s, e in pairs]
 
 
+def host_cores(limit):
+    """Threads the cpu_baseline leg may really run on: the affinity mask, cut to the cgroup's CPU quota (a GPU box hands
+    out 16 CPUs' worth of time on a 256-thread host: 128 OpenMP threads under that quota are throttled, and the figure
+    moved by 2.5 x between runs), cut to what the oracle's OpenMP runtime offers."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, limit))
+
+
 def timed_loop(fn, steps, multi, per_launch_events=True):
     """barrier + synchronize on both sides, K launches between, HIP events recorded on the stream the kernels run on.
     per_launch_events=True: an event pair around EVERY launch (the kernel's own duration; each pair costs a few
@@ -626,7 +647,7 @@ def main():
             coo = orc.Coo(d["node_counts"][:S], d["edge_counts"][:S], d["src"][:int(host.edge_ptr[S])],
                           d["dst"][:int(host.edge_ptr[S])], sl("x", int(host.node_ptr[S])) if zinc else None,
                           sl("edge_attr", int(host.edge_ptr[S])) if zinc else None)
-            cores = orc.num_threads()
+            cores = host_cores(orc.num_threads())
             okw = dict(labeled=zinc, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=zinc, ld=ld, nthreads=cores)
             orc.sent(coo.slice(0, min(S, 2000)), max_nodes, max_len, 0, 0, **okw)
             reps, t0 = 0, time.perf_counter()
