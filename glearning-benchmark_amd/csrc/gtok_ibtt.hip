@@ -635,12 +635,18 @@ __global__ void __launch_bounds__(256) ibtt_synth_kernel(const SynthArgs a) {
     const int g = (unit < u1 && unit * wpb + wave < G) ? unit * wpb + wave : 0;   // past the end: graph 0's first words
     const int32_t *__restrict__ rpg = a.g.rowptr + h.nb0 + g;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) d.rp[j] = rpg[min(lane + kWave * j, h.n)];
+    for (int j = 0; j < 5; ++j) d.rp[j] = rpg[(uint32_t)min(lane + kWave * j, h.n)];
+    // a graph's entries are [e0, e0 + e) of the arrays, so the clamp is needed only where there are none (an empty graph, a unit
+    // past the end: entry 0 of the array then): the base is wave-uniform - scalar registers - and the lane adds an unsigned
+    // 32-bit offset, two vector instructions per load instead of a 64-bit add and two 64-bit clamps
+    const int64_t ebase = h.e > 0 ? h.e0 : 0;
+    const int32_t *__restrict__ cb = a.g.col + ebase;
+    const int32_t *__restrict__ ob = has_order ? a.g.eorder + ebase : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t k = min(max(h.e0 + min(lane + kWave * j, h.elim - 1), (int64_t)0), Etot - 1);
-      d.col[j] = Etot > 0 ? a.g.col[k] : 0;
-      d.ord[j] = (has_order && Etot > 0) ? a.g.eorder[k] : lane + kWave * j;
+      const uint32_t k = (uint32_t)max(min(lane + kWave * j, h.elim - 1), 0);
+      d.col[j] = Etot > 0 ? cb[k] : 0;
+      d.ord[j] = (has_order && Etot > 0) ? ob[k] : lane + kWave * j;
     }
     return d;
   };
