@@ -8,6 +8,7 @@ import json
 import os
 import random
 from collections import Counter
+from collections.abc import Sequence
 from glob import glob
 from typing import Any, Dict, Iterator, List, Optional, Tuple
 
@@ -308,11 +309,46 @@ def build_vocab_from_graphs(batch, num_ids: int, task: Optional[str] = None, lab
 
 
 # ------------------------------------------------------------------------------------------------ dataset
+class _Rows(Sequence):
+    """`seqs` / `labels` of a TokenDataset: the reference keeps a Python list of tensors (:483-484); a quarter of a million
+    tensor objects cost more to create than the whole corpus costs to tokenize, so this sequence makes row i - a view of
+    the one host buffer - when it is asked for (in the DataLoader worker that asks, not up front in the parent)."""
+
+    def __init__(self, buf: torch.Tensor, start, count):
+        self._buf, self._start, self._count = buf, start, count
+
+    def __len__(self):
+        return len(self._count)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self._count)
+        s = self._start[i]
+        return self._buf[s:s + self._count[i]]
+
+
+class _Scalars(Sequence):
+    """One 0-dim view per element of a 1-D tensor, made on access (`labels` of a TokenDataset)."""
+
+    def __init__(self, t: torch.Tensor):
+        self._t = t
+
+    def __len__(self):
+        return int(self._t.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return list(self._t[i].unbind(0))
+        return self._t[i]
+
+
 class TokenDataset(Dataset):
     """Eager text -> ids, like the reference (:465-486): the whole corpus goes through ONE gtok_text_to_ids
     launch in `__init__`.  Two copies of the result are kept: the int32 slab on the device (`ids`, `lens`, read by
     `device_batches`, the no-copy path) and, copied back once right after the launch, `seqs` / `labels` as CPU
-    int64 tensors — what the reference stores.  `__getitem__` only touches the CPU copies, so the object can be
+    int64 tensors — what the reference stores, as sequences that make element i (a view of ONE host buffer) on access.  `__getitem__` only touches the CPU copies, so the object can be
     handed to `DataLoader(num_workers=2)` workers (trainer/train_ibtt.py:395-402, configs/ibtt_*.yaml): forked
     workers never see a device tensor, and pickling (spawned workers) drops the device members."""
 
@@ -335,7 +371,7 @@ class TokenDataset(Dataset):
             texts.append(text)
             labels.append(int(label) if label is not None else 0)       # int() truncates ZINC's float labels
         self._y = torch.tensor(labels, dtype=torch.long)
-        self.labels = list(self._y.unbind(0)) if labels else []          # 0-dim views of one tensor
+        self.labels = _Scalars(self._y)                                    # 0-dim views of one tensor, made on access
         if texts:
             blob, ptr = _ops.pack_texts(texts)
             self._table = _ops.VocabTable(vocab, self.device)
@@ -344,13 +380,13 @@ class TokenDataset(Dataset):
             # to the host, row i is a view of it cut at its length - what the reference stores as one tensor per example
             rows = _root().rows.EpochRows(self.ids, self.lens, pin=False)   # pageable: forked DataLoader workers read it
             self._lens_h = torch.tensor(rows.count, dtype=torch.int32)
-            self.seqs: List[torch.Tensor] = [rows.row(i) for i in range(len(rows))]
+            self.seqs = _Rows(rows.tokens, rows.start, rows.count)
         else:
             self._table = None
             self.ids = torch.empty((0, 4), dtype=torch.int32, device=self.device)
             self.lens = torch.empty((0,), dtype=torch.int32, device=self.device)
             self._lens_h = torch.empty((0,), dtype=torch.int32)
-            self.seqs = []
+            self.seqs = _Rows(torch.empty(0, dtype=torch.int64), [], [])
 
     def __getstate__(self):
         state = dict(self.__dict__)

@@ -653,13 +653,12 @@ def pack_texts(texts: Sequence[str]) -> Tuple[torch.Tensor, torch.Tensor]:
     """Concatenate texts into (bytes uint8 [total], text_ptr int64 [G+1]); ASCII only (str.split() on
     non-ASCII whitespace is not reproduced on the device)."""
     try:
-        enc = [t.encode("ascii") for t in texts]
+        blob = "".join(texts).encode("ascii")        # one join + one encode: ASCII, so a text's length in bytes is len(text)
     except UnicodeEncodeError:
         raise ValueError("gtok text path handles ASCII text only") from None
-    ptr = np.zeros(len(enc) + 1, np.int64)
-    np.cumsum(np.fromiter(map(len, enc), np.int64, len(enc)), out=ptr[1:])
-    blob = b"".join(enc) or b"\0"
-    return torch.frombuffer(bytearray(blob), dtype=torch.uint8), torch.from_numpy(ptr)
+    ptr = np.zeros(len(texts) + 1, np.int64)
+    np.cumsum(np.fromiter(map(len, texts), np.int64, len(texts)), out=ptr[1:])
+    return torch.frombuffer(bytearray(blob or b"\0"), dtype=torch.uint8), torch.from_numpy(ptr)
 
 
 def text_to_ids(text_bytes: torch.Tensor, text_ptr: torch.Tensor, table: VocabTable, max_len: int,
