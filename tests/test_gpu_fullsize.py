@@ -151,3 +151,16 @@ def test_packed_rows_and_strings_at_zinc_full_size(zinc_full):
     dh = direct.cpu()
     for i in range(0, S, 97):
         assert torch.equal(td.seqs[i], dh[i, :dl[i]].long())
+    # every text of the split through the text kernel with the vocab the trainer really builds (fixed table + node ids + one
+    # val_x_xx token per distinct label: too large for the LDS copy, so the short-key table is filled in part and adopts the
+    # rest on use) == the string-free route over the same molecules, row for row
+    vocab_dyn = gdl.build_zinc_vocab_on_device(texts, device=DEV)
+    assert len(vocab_dyn) > 700, len(vocab_dyn)
+    td_all = gdl.TokenDataset([{"text": t, "label": y} for t, y in zip(texts, labels)], vocab_dyn, 1024, device=DEV)
+    g_ids, g_len = ds.tokenize(vocab_dyn, 1024, device=DEV)
+    assert torch.equal(td_all.lens, g_len)
+    w = min(int(td_all.ids.shape[1]), int(g_ids.shape[1]))
+    assert int(g_len.max()) <= w
+    keep = torch.arange(w, device=g_len.device)[None, :] < g_len[:, None]
+    assert torch.equal(td_all.ids[:, :w][keep], g_ids[:, :w][keep])
+    assert torch.equal(td_all.seqs[ZINC_FULL - 1], g_ids[ZINC_FULL - 1, :int(g_len[-1])].long().cpu())
