@@ -40,6 +40,7 @@ class GtokCsr(ctypes.Structure):
 
 CSR_SIMPLE_SYMMETRIC = 1
 SENT_NO_PAD = 1
+SENT_U16 = 2
 
 
 class GtokVocabTable(ctypes.Structure):
@@ -58,6 +59,7 @@ class GtokSentParams(ctypes.Structure):
         ("pad_id", ctypes.c_int32), ("flags", ctypes.c_int32),
         ("seed", ctypes.c_uint64), ("epoch", ctypes.c_uint64),
         ("graph_base", ctypes.c_int64), ("query", ctypes.c_void_p),
+        ("epoch_count", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -82,6 +84,8 @@ SYMBOLS = {
     "gtok_pack_rows": (_I, [_P, _I, _P, ctypes.c_int64, _P, _I, _P, ctypes.c_int64, _P, _P]),
     "gtok_unpack_rows": (_I, [_P, _I, _P, _P, ctypes.c_int64, _I, ctypes.c_int64, _I, _P, _I, _P]),
     "gtok_collate_packed": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _P]),
+    "gtok_unpack_rows_checked": (_I, [_P, _I, _P, _P, ctypes.c_int64, _I, ctypes.c_int64, ctypes.c_int64, _I, _P, _I, _P, _P]),
+    "gtok_pack_rows_u16": (_I, [_P, _I, _P, ctypes.c_int64, _P, _I, _P, ctypes.c_int64, _P, _P]),
     "gtok_ids_to_text": (_I, [_P, _I, _P, ctypes.c_int64, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "gtok_sent_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(GtokCsr), ctypes.POINTER(GtokSentParams)]),
     "gtok_ibtt_zinc_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(GtokCsr)]),
@@ -145,7 +149,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 _lib = None
 
 
-ABI_VERSION = 3     # include/gtok.h: GTOK_ABI_VERSION
+ABI_VERSION = 4     # include/gtok.h: GTOK_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:
@@ -157,10 +161,15 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         h = ctypes.CDLL(LIB_PATH)
+        # GTOK_LIB (A/B timing against the build of an earlier git ref, profiles/tools/ab_build.sh): an ABI v3 library reads a
+        # prefix of today's structs and lacks the newer entry points - accepted for the calls both have, nothing else
+        older_ok = bool(os.environ.get("GTOK_LIB")) and 3 <= h.gtok_version() < ABI_VERSION
         for name, (res, args) in SYMBOLS.items():
+            if older_ok and not hasattr(h, name):
+                continue
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        if h.gtok_version() != ABI_VERSION:      # struct layouts below would not match the library's
+        if h.gtok_version() != ABI_VERSION and not older_ok:      # struct layouts below would not match the library's
             raise GtokError(f"{LIB_PATH} has ABI version {h.gtok_version()}, this binding needs {ABI_VERSION}: rebuild it "
                             "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         _lib = h

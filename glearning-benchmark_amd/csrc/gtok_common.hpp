@@ -321,5 +321,28 @@ __device__ __forceinline__ void write_row_tok16(int32_t *__restrict__ row, int l
     for (int i = lane; i < ld; i += kWave) row[i] = (i < lw) ? f((int)tok[i], i) : pad;
   }
 }
+// ... into a row of 16-bit ids (GTOK_SENT_U16): four ids per 8-byte store
+template <typename F>
+__device__ __forceinline__ void write_row_tok16(uint16_t *__restrict__ row, int ld, int lw, int pad,
+                                                const uint16_t *tok, F f) {
+  const int lane = lane_id();
+  if (((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(row) & 7u) == 0)) {
+    for (int i = lane * 4; i < ld; i += kWave * 4) {
+      uint32_t a = (uint32_t)pad & 0xFFFFu, b = a, c = a, d = a;
+      if (i < lw) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(tok + i);
+        a = (uint32_t)f((int)(w.x & 0xFFFFu), i) & 0xFFFFu;
+        if (i + 1 < lw) b = (uint32_t)f((int)(w.x >> 16), i + 1) & 0xFFFFu;
+        if (i + 2 < lw) c = (uint32_t)f((int)(w.y & 0xFFFFu), i + 2) & 0xFFFFu;
+        if (i + 3 < lw) d = (uint32_t)f((int)(w.y >> 16), i + 3) & 0xFFFFu;
+      }
+      uint2 o;
+      o.x = a | (b << 16); o.y = c | (d << 16);
+      *reinterpret_cast<uint2 *>(row + i) = o;
+    }
+  } else {
+    for (int i = lane; i < ld; i += kWave) row[i] = (uint16_t)((i < lw) ? f((int)tok[i], i) : pad);
+  }
+}
 
 }  // namespace gtok

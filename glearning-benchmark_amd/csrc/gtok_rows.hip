@@ -105,14 +105,15 @@ __global__ void __launch_bounds__(kScanBlock) row_tile_fill_kernel(const int32_t
 // a row's start in the packed buffer: segments (the blocks the ranks of an all-gather contributed) restart at
 // multiples of segment_stride elements
 __device__ __forceinline__ int64_t packed_start(const int64_t *__restrict__ row_ptr, int64_t r, int segment_rows,
-                                                int64_t segment_stride) {
+                                                int64_t segment_stride, int ld) {
+  if (!row_ptr) return r * (int64_t)ld;            // the strided form: a [rows, ld] slab (GTOK_SENT_U16) read in place
   if (segment_rows <= 0) return row_ptr[r];
   const int64_t seg = r / segment_rows;
   return seg * segment_stride + (row_ptr[r] - row_ptr[seg * (int64_t)segment_rows]);
 }
 
 struct RowsArgs {
-  const int32_t *ids;      // pack: source slab; unpack: unused
+  const void *ids;         // pack: source slab (int32, or uint16 for gtok_pack_rows_u16); unpack: unused
   int32_t *out_ids;        // unpack: destination slab
   const int32_t *len;
   const int64_t *row_ptr;
@@ -120,20 +121,21 @@ struct RowsArgs {
   int32_t *status;
   int64_t rows;
   int ld, pad_id, segment_rows, tpr_shift;   // threads per row = 1 << tpr_shift
-  int64_t segment_stride, capacity;   // pack: elements `packed` can hold
+  int64_t segment_stride, capacity;   // pack: elements `packed` can hold; unpack: elements it holds (0 = unknown)
 };
 
-// E = uint16_t or int32_t.  A thread owns pieces of 8 consecutive ids of one row: two 16-byte loads, one (or two)
-// 16-byte stores; 1 << tpr_shift threads share a row, 256 >> tpr_shift rows a workgroup.
-template <typename E>
+// S = source id type (int32_t slab, or uint16_t: a GTOK_SENT_U16 slab), E = packed id type (uint16_t, int32_t or
+// int64_t).  A thread owns pieces of 8 consecutive ids of one row: 16-byte loads and stores; 1 << tpr_shift threads
+// share a row, 256 >> tpr_shift rows a workgroup.
+template <typename S, typename E>
 __global__ void __launch_bounds__(256) pack_rows_kernel(const RowsArgs a) {
   const int tpr = 1 << a.tpr_shift, sub = (int)threadIdx.x & (tpr - 1);
   const int64_t r = (int64_t)blockIdx.x * (256 >> a.tpr_shift) + ((int)threadIdx.x >> a.tpr_shift);
   if (r >= a.rows) return;
   int n = a.len[r];
   n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
-  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride);
-  const int32_t *__restrict__ row = a.ids + r * (int64_t)a.ld;
+  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride, a.ld);
+  const S *__restrict__ row = reinterpret_cast<const S *>(a.ids) + r * (int64_t)a.ld;
   if (start + n > a.capacity) {                      // a caller-sized buffer that turned out too small: skip, flag
     if (sub == 0) atomicOr(a.status, 2);
     return;
@@ -143,28 +145,50 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const RowsArgs a) {
   uint32_t wide = 0;
   for (int i = sub * 8; i < n; i += tpr * 8) {
     if (vec && i + 8 <= n) {
-      const int4 lo = *reinterpret_cast<const int4 *>(row + i), hi = *reinterpret_cast<const int4 *>(row + i + 4);
-      if (sizeof(E) == 2) {
-        wide |= (uint32_t)(lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w);
-        uint4 o;
-        o.x = ((uint32_t)lo.x & 0xFFFFu) | ((uint32_t)lo.y << 16); o.y = ((uint32_t)lo.z & 0xFFFFu) | ((uint32_t)lo.w << 16);
-        o.z = ((uint32_t)hi.x & 0xFFFFu) | ((uint32_t)hi.y << 16); o.w = ((uint32_t)hi.z & 0xFFFFu) | ((uint32_t)hi.w << 16);
-        *reinterpret_cast<uint4 *>(dst + i) = o;
+      uint32_t t[8];
+      if (sizeof(S) == 4) {
+        const int4 lo = *reinterpret_cast<const int4 *>(row + i), hi = *reinterpret_cast<const int4 *>(row + i + 4);
+        t[0] = (uint32_t)lo.x; t[1] = (uint32_t)lo.y; t[2] = (uint32_t)lo.z; t[3] = (uint32_t)lo.w;
+        t[4] = (uint32_t)hi.x; t[5] = (uint32_t)hi.y; t[6] = (uint32_t)hi.z; t[7] = (uint32_t)hi.w;
+        wide |= t[0] | t[1] | t[2] | t[3] | t[4] | t[5] | t[6] | t[7];
       } else {
-        *reinterpret_cast<int4 *>(dst + i) = lo;
-        *reinterpret_cast<int4 *>(dst + i + 4) = hi;
+        const uint4 p = *reinterpret_cast<const uint4 *>(row + i);
+        t[0] = p.x & 0xFFFFu; t[1] = p.x >> 16; t[2] = p.y & 0xFFFFu; t[3] = p.y >> 16;
+        t[4] = p.z & 0xFFFFu; t[5] = p.z >> 16; t[6] = p.w & 0xFFFFu; t[7] = p.w >> 16;
+      }
+      if (sizeof(E) == 2) {
+        uint4 o;
+        if (sizeof(S) == 2) {
+          o = *reinterpret_cast<const uint4 *>(row + i);
+        } else {
+          o.x = (t[0] & 0xFFFFu) | (t[1] << 16); o.y = (t[2] & 0xFFFFu) | (t[3] << 16);
+          o.z = (t[4] & 0xFFFFu) | (t[5] << 16); o.w = (t[6] & 0xFFFFu) | (t[7] << 16);
+        }
+        *reinterpret_cast<uint4 *>(dst + i) = o;
+      } else if (sizeof(E) == 4) {
+        *reinterpret_cast<uint4 *>(dst + i) = make_uint4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<uint4 *>(dst + i + 4) = make_uint4(t[4], t[5], t[6], t[7]);
+      } else {                                        // int64 ids: ids are never negative on this path (a slab of 16-bit ids, or sign-extended int32)
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const int64_t a0 = sizeof(S) == 4 ? (int64_t)(int32_t)t[k] : (int64_t)t[k], a1 = sizeof(S) == 4 ? (int64_t)(int32_t)t[k + 1] : (int64_t)t[k + 1];
+          *reinterpret_cast<longlong2 *>(dst + i + k) = longlong2{a0, a1};
+        }
       }
     } else {
       for (int k = i; k < n && k < i + 8; ++k) {
-        const int32_t t = row[k];
-        wide |= (uint32_t)t;
+        const S t = row[k];
+        if (sizeof(S) == 4) wide |= (uint32_t)t;
         dst[k] = (E)t;
       }
     }
   }
-  if (sizeof(E) == 2 && (wide & 0xFFFF0000u)) atomicOr(a.status, 1);     // an id that does not fit 16 bits
+  if (sizeof(E) == 2 && sizeof(S) == 4 && (wide & 0xFFFF0000u)) atomicOr(a.status, 1);     // an id that does not fit 16 bits
 }
 
+// Never reads beyond what the row's owner wrote: a row whose ids would end past its segment (segment_stride: a rank
+// whose rows did not fit the caller-given capacity skipped them, gtok_pack_rows status bit 1, while the gathered lengths
+// still carry them) or past the buffer (`capacity` elements, 0 = unknown) comes out as all pad and raises status bit 1.
 template <typename E>
 __global__ void __launch_bounds__(256) unpack_rows_kernel(const RowsArgs a) {
   const int tpr = 1 << a.tpr_shift, sub = (int)threadIdx.x & (tpr - 1);
@@ -172,9 +196,18 @@ __global__ void __launch_bounds__(256) unpack_rows_kernel(const RowsArgs a) {
   if (r >= a.rows) return;
   int n = a.len[r];
   n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
-  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride);
+  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride, a.ld);
+  bool fits = start >= 0 && (a.capacity <= 0 || start + n <= a.capacity);
+  if (a.row_ptr && a.segment_rows > 0) {
+    const int64_t seg = r / a.segment_rows;
+    fits = fits && (start - seg * a.segment_stride) + n <= a.segment_stride;
+  }
+  if (!fits) {
+    if (sub == 0 && n > 0 && a.status) atomicOr(a.status, 2);
+    n = 0;
+  }
   int32_t *__restrict__ row = a.out_ids + r * (int64_t)a.ld;
-  const E *__restrict__ src = reinterpret_cast<const E *>(a.packed) + start;
+  const E *__restrict__ src = reinterpret_cast<const E *>(a.packed) + (fits ? start : 0);
   const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
   const int pad = a.pad_id;
   for (int i = sub * 8; i < a.ld; i += tpr * 8) {
@@ -216,7 +249,7 @@ __global__ void __launch_bounds__(256) collate_packed_kernel(const void *__restr
   const int64_t src = index[b];
   int n = len[src];
   n = n < 0 ? 0 : (n > ld ? ld : n);
-  const E *__restrict__ row = reinterpret_cast<const E *>(packed) + row_ptr[src];
+  const E *__restrict__ row = reinterpret_cast<const E *>(packed) + (row_ptr ? row_ptr[src] : src * (int64_t)ld);
   for (int i = lane; i < out_ld; i += kWave) {
     const bool in = i < n;
     out_x[(int64_t)b * out_ld + i] = in ? (int64_t)row[i] : (int64_t)pad_id;
@@ -301,14 +334,16 @@ extern "C" int gtok_row_offsets(const int32_t *len, int64_t num_rows, int32_t ld
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 
-static int rows_launch(bool pack, const int32_t *ids, int32_t *out_ids, int32_t ld, const int32_t *len, int64_t num_rows,
+static int rows_launch(bool pack, const void *ids, int src_bytes, int32_t *out_ids, int32_t ld, const int32_t *len, int64_t num_rows,
                        const int64_t *row_ptr, int32_t segment_rows, int64_t segment_stride, int32_t elem_bytes,
                        void *packed, int64_t capacity, int32_t pad_id, int32_t *status, void *stream) {
   DeviceScope device_scope((hipStream_t)stream);
   if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
-  if (num_rows < 0 || ld <= 0 || (elem_bytes != 2 && elem_bytes != 4) || segment_stride < 0) return GTOK_E_INVAL;
+  const bool eb_ok = elem_bytes == 2 || elem_bytes == 4 || (pack && src_bytes == 2 && elem_bytes == 8);
+  if (num_rows < 0 || ld <= 0 || !eb_ok || segment_stride < 0 || segment_rows < 0) return GTOK_E_INVAL;
   if (num_rows == 0) return GTOK_OK;
-  if (!len || !row_ptr || !packed || (pack ? !ids : !out_ids) || (pack && !status) || capacity < 0) return GTOK_E_INVAL;
+  if (!len || !packed || (pack ? (!ids || !row_ptr) : !out_ids) || (pack && !status) || capacity < 0) return GTOK_E_INVAL;
+  if (!pack && !row_ptr && segment_rows > 0) return GTOK_E_INVAL;   // the strided form has no segments
   RowsArgs a;
   a.ids = ids; a.out_ids = out_ids; a.len = len; a.row_ptr = row_ptr; a.packed = packed; a.status = status;
   a.rows = num_rows; a.ld = ld; a.pad_id = pad_id; a.segment_rows = segment_rows; a.segment_stride = segment_stride; a.capacity = capacity;
@@ -317,9 +352,13 @@ static int rows_launch(bool pack, const int32_t *ids, int32_t *out_ids, int32_t 
   const int64_t nb = (num_rows + rpb - 1) / rpb;
   if (nb > 0x7FFFFFFF) return GTOK_E_TOO_LARGE;
   hipStream_t s = (hipStream_t)stream;
-  if (pack) {
-    if (elem_bytes == 2) hipLaunchKernelGGL(pack_rows_kernel<uint16_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(pack_rows_kernel<int32_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
+  if (pack && src_bytes == 2) {
+    if (elem_bytes == 2) hipLaunchKernelGGL((pack_rows_kernel<uint16_t, uint16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else if (elem_bytes == 4) hipLaunchKernelGGL((pack_rows_kernel<uint16_t, int32_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pack_rows_kernel<uint16_t, int64_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+  } else if (pack) {
+    if (elem_bytes == 2) hipLaunchKernelGGL((pack_rows_kernel<int32_t, uint16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pack_rows_kernel<int32_t, int32_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
   } else {
     if (elem_bytes == 2) hipLaunchKernelGGL(unpack_rows_kernel<uint16_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(unpack_rows_kernel<int32_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
@@ -329,14 +368,26 @@ static int rows_launch(bool pack, const int32_t *ids, int32_t *out_ids, int32_t 
 
 extern "C" int gtok_pack_rows(const int32_t *ids, int32_t ld, const int32_t *len, int64_t num_rows, const int64_t *row_ptr,
                               int32_t elem_bytes, void *packed, int64_t capacity, int32_t *status, void *stream) {
-  return rows_launch(true, ids, nullptr, ld, len, num_rows, row_ptr, 0, 0, elem_bytes, packed, capacity, 0, status, stream);
+  return rows_launch(true, ids, 4, nullptr, ld, len, num_rows, row_ptr, 0, 0, elem_bytes, packed, capacity, 0, status, stream);
+}
+
+extern "C" int gtok_pack_rows_u16(const uint16_t *ids16, int32_t ld, const int32_t *len, int64_t num_rows, const int64_t *row_ptr,
+                                  int32_t elem_bytes, void *packed, int64_t capacity, int32_t *status, void *stream) {
+  return rows_launch(true, ids16, 2, nullptr, ld, len, num_rows, row_ptr, 0, 0, elem_bytes, packed, capacity, 0, status, stream);
 }
 
 extern "C" int gtok_unpack_rows(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
                                 int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int32_t pad_id,
                                 int32_t *out_ids, int32_t ld, void *stream) {
-  return rows_launch(false, nullptr, out_ids, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
+  return rows_launch(false, nullptr, 4, out_ids, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
                      const_cast<void *>(packed), 0, pad_id, nullptr, stream);
+}
+
+extern "C" int gtok_unpack_rows_checked(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
+                                        int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int64_t packed_elems,
+                                        int32_t pad_id, int32_t *out_ids, int32_t ld, int32_t *status, void *stream) {
+  return rows_launch(false, nullptr, 4, out_ids, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
+                     const_cast<void *>(packed), packed_elems, pad_id, status, stream);
 }
 
 extern "C" int gtok_collate_packed(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
@@ -344,8 +395,8 @@ extern "C" int gtok_collate_packed(const void *packed, int32_t elem_bytes, const
                                    uint8_t *out_attn, int32_t out_ld, void *stream) {
   DeviceScope device_scope((hipStream_t)stream);
   if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
-  if (!packed || !row_ptr || !len || !index || ld <= 0 || batch < 0 || out_ld < 0 || (elem_bytes != 2 && elem_bytes != 4))
-    return GTOK_E_INVAL;
+  if (!packed || !len || !index || ld <= 0 || batch < 0 || out_ld < 0 || (elem_bytes != 2 && elem_bytes != 4))
+    return GTOK_E_INVAL;      // (row_ptr == NULL: the strided form)
   if (batch == 0 || out_ld == 0) return GTOK_OK;
   if (!out_x || !out_attn) return GTOK_E_INVAL;
   hipStream_t s = (hipStream_t)stream;

@@ -37,8 +37,12 @@ constexpr int GTOK_BLANE_MIN_GRAPHS = 20000;
 
 // 0 = lane-per-graph, 1 = register-resident wave-per-graph, 2 = LDS bit matrix, 3 = lane-per-graph over the adjacency
 // bit-matrix mirror.  GTOK_SENT_KERNEL=lane|reg|lds|blane pins a kernel where it is applicable (tests run every path).
+static inline int sent_epochs(const gtok_sent_params *p) { return p->epoch_count > 1 ? p->epoch_count : 1; }
+
 static int choose_sent_kernel(const gtok_csr *g, const gtok_sent_params *p) {
   const int maxn = g->max_nodes > 0 ? g->max_nodes : 1;
+  // the lane-per-graph kernels need enough WALKS to fill the chip: K epochs of a small split count like one epoch of a big one
+  const int64_t walks = (int64_t)g->num_graphs * sent_epochs(p);
   const char *pin = std::getenv("GTOK_SENT_KERNEL");
   const bool pin_lane = pin && pin[0] == 'l' && pin[1] == 'a', pin_reg = pin && pin[0] == 'r';
   const bool pin_lds = pin && pin[0] == 'l' && pin[1] == 'd', pin_blane = pin && pin[0] == 'b';
@@ -58,8 +62,8 @@ static int choose_sent_kernel(const gtok_csr *g, const gtok_sent_params *p) {
   if (pin_lds) return 2;
   if (pin_lane && lane_ok) return 0;
   if (pin_reg && reg_ok) return 1;
-  if (lane_ok && !pin_reg && g->num_graphs >= GTOK_LANE_MIN_GRAPHS) return 0;
-  if (blane_ok && !pin_reg && !pin_lane && g->num_graphs >= GTOK_BLANE_MIN_GRAPHS) return 3;
+  if (lane_ok && !pin_reg && walks >= GTOK_LANE_MIN_GRAPHS) return 0;
+  if (blane_ok && !pin_reg && !pin_lane && walks >= GTOK_BLANE_MIN_GRAPHS) return 3;
   return reg_ok ? 1 : 2;
 }
 
@@ -75,7 +79,12 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   if (g->num_graphs == 0) return GTOK_OK;   // an empty batch is a no-op
   if (!out_ids || !out_len) return GTOK_E_INVAL;
   if (!g->node_ptr || !g->edge_ptr || !g->rowptr || (g->max_edges > 0 && !g->col)) return GTOK_E_INVAL;
-  if (p->max_len < 0 || p->max_num_nodes < 0) return GTOK_E_INVAL;
+  if (p->max_len < 0 || p->max_num_nodes < 0 || p->epoch_count < 0 || p->reserved != 0) return GTOK_E_INVAL;
+  if (p->flags & ~(GTOK_SENT_NO_PAD | GTOK_SENT_U16)) return GTOK_E_INVAL;
+  const bool u16 = (p->flags & GTOK_SENT_U16) != 0;
+  if (u16 && (p->pad_id < 0 || p->pad_id > 65535)) return GTOK_E_INVAL;   // (the id space itself is checked below: tokens are 16 bits inside the kernels anyway)
+  const int K = sent_epochs(p);
+  if ((int64_t)g->num_graphs * K > 0x7FFFFFFF / 2) return GTOK_E_TOO_LARGE;   // rows of the [K, G, ld] slab are counted in 32 bits
   if (p->labeled && (!g->nattr || !g->eattr)) return GTOK_E_INVAL;
   if (g->max_nodes > GTOK_MAX_NODES) return GTOK_E_TOO_LARGE;
   if (g->max_edges > 60000) return GTOK_E_TOO_LARGE;   // neighbour lists are staged as uint16 in LDS
@@ -89,18 +98,26 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   const int maxe = g->max_edges > 0 ? g->max_edges : 1;
   const int which = choose_sent_kernel(g, p);
   if (which < 0) return GTOK_E_INVAL;       // a reordered batch the lane-per-graph kernel cannot take
+  // padding with non-temporal stores once the slab outgrows the memory-side cache (256 MB on MI355X): gtok_sent_lane.hpp
+  int pad_nt = (int64_t)g->num_graphs * K * ld * (u16 ? 2 : 4) > ((int64_t)256 << 20);
+  if (const char *cs = std::getenv("GTOK_PAD_NT")) pad_nt = cs[0] != '0';   // tuning knob
   const bool lane_path = which == 0, reg_path = which == 1;
   if (which == 3) {
     SentBLaneArgs a;
     a.g = *g; a.p = *p; a.out = out_ids; a.ld = ld; a.out_len = out_len;
     a.units = (g->num_graphs + 63) / 64;
+    a.epochs = K;
+    a.pad_nt = pad_nt;
     a.prio = 1;
     if (const char *cs = std::getenv("GTOK_BLANE_PRIO")) a.prio = cs[0] != '0';   // tuning knob
     const bool p4 = g->adj_max_degree <= 15;
-    typedef void (*K)(const SentBLaneArgs);
-    K kern = W == 1 ? (p4 ? (K)sent_blane_kernel<1, 4> : (K)sent_blane_kernel<1, 8>)
-           : W == 2 ? (p4 ? (K)sent_blane_kernel<2, 4> : (K)sent_blane_kernel<2, 8>)
-                    : (p4 ? (K)sent_blane_kernel<4, 4> : (K)sent_blane_kernel<4, 8>);
+    typedef void (*KF)(const SentBLaneArgs);
+#define GTOK_BLANE_K(U)                                                                                 \
+  (W == 1 ? (p4 ? (KF)sent_blane_kernel<1, 4, U> : (KF)sent_blane_kernel<1, 8, U>)                     \
+   : W == 2 ? (p4 ? (KF)sent_blane_kernel<2, 4, U> : (KF)sent_blane_kernel<2, 8, U>)                   \
+            : (p4 ? (KF)sent_blane_kernel<4, 4, U> : (KF)sent_blane_kernel<4, 8, U>))
+    KF kern = u16 ? GTOK_BLANE_K(true) : GTOK_BLANE_K(false);
+#undef GTOK_BLANE_K
     const size_t lds = (size_t)4608 * W;   // 18 W dwords per lane (gtok_sent_blane.hpp)
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
@@ -109,7 +126,8 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     int nw = W == 4 ? 8 : 16;
     if (const char *cs = std::getenv("GTOK_BLANE_WAVES")) { const int c = std::atoi(cs); if (c == 4 || c == 8 || c == 16) nw = c < nw ? c : nw; }   // tuning knob
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    const int nb = a.units < ncu ? a.units : ncu;   // every CU, also when some of its waves stay without a unit
+    const int vun = a.units * K;
+    const int nb = vun < ncu ? vun : ncu;   // every CU, also when some of its waves stay without a unit
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * nw), lds * nw, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
   }
@@ -134,13 +152,15 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     if (a.lds > 64 * 1024) return GTOK_E_TOO_LARGE;
     // counter planes: degree < 2^P; an unknown max_degree is covered by P = 6 (a node of a simple graph with <= 64 nodes has < 64 neighbours)
     const bool p3 = g->max_degree > 0 && g->max_degree <= 15;
-    typedef void (*K)(const SentLaneArgs);
+    typedef void (*KF)(const SentLaneArgs);
     const bool pk = g->rowptr8 && g->col8;
-#define GTOK_LANE_K(LAB, REMAP)                                                                                       \
-  (pk ? (p3 ? (K)sent_lane_kernel<LAB, 4, REMAP, true> : (K)sent_lane_kernel<LAB, 6, REMAP, true>)                    \
-      : (p3 ? (K)sent_lane_kernel<LAB, 4, REMAP, false> : (K)sent_lane_kernel<LAB, 6, REMAP, false>))
-    K kern = !p->labeled ? GTOK_LANE_K(false, false) : p->remap_zinc ? GTOK_LANE_K(true, true) : GTOK_LANE_K(true, false);
+#define GTOK_LANE_K2(LAB, REMAP, U)                                                                                   \
+  (pk ? (p3 ? (KF)sent_lane_kernel<LAB, 4, REMAP, true, U> : (KF)sent_lane_kernel<LAB, 6, REMAP, true, U>)            \
+      : (p3 ? (KF)sent_lane_kernel<LAB, 4, REMAP, false, U> : (KF)sent_lane_kernel<LAB, 6, REMAP, false, U>))
+#define GTOK_LANE_K(LAB, REMAP) (u16 ? GTOK_LANE_K2(LAB, REMAP, true) : GTOK_LANE_K2(LAB, REMAP, false))
+    KF kern = !p->labeled ? GTOK_LANE_K(false, false) : p->remap_zinc ? GTOK_LANE_K(true, true) : GTOK_LANE_K(true, false);
 #undef GTOK_LANE_K
+#undef GTOK_LANE_K2
     int dev = 0, ncu = 256, occ = 1;
     if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -152,37 +172,45 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
       if (c >= 1 && c < occ) occ = c;
     }
     a.units = g->unit_ptr ? g->num_units : (g->num_graphs + 63) / 64;
+    a.epochs = K;
+    a.pad_nt = pad_nt;
+    if ((int64_t)a.units * K > 0x7FFFFFFF / 64) return GTOK_E_TOO_LARGE;
+    const int vunits = a.units * K;               // (unit, epoch) pairs the launch walks
     a.unit_mul = 0;
     a.prio_cut[0] = 16; a.prio_cut[1] = 32; a.prio_cut[2] = 48;   // quartiles (profiles/tools/lane_prio_sweep.sh)
     if (const char *pc = std::getenv("GTOK_LANE_PRIO_CUTS")) std::sscanf(pc, "%d,%d,%d", &a.prio_cut[0], &a.prio_cut[1], &a.prio_cut[2]);   // tuning knob
     // a reordered batch: one 16-wave workgroup per CU (the kernel pairs long units with short ones on every SIMD) when a
     // wave's share of the CU's 160 KB is enough and the batch fills the chip; else one-wave workgroups with the units spread
     const char *wg = std::getenv("GTOK_LANE_PER_CU");   // tuning knob: 0 = never
-    if (g->unit_ptr && a.lds * 16 <= 160 * 1024 && a.units >= 4 * ncu && !(wg && wg[0] == '0')) {
+    // (+ 16 bytes: the workgroup's ticket counter, from which its waves draw their units after the first round)
+    if (g->unit_ptr && a.lds * 16 + 16 <= 160 * 1024 && vunits >= 4 * ncu && !(wg && wg[0] == '0')) {
       // (the opt-in to more than 64 KB of dynamic LDS is per kernel and per device: a host-side call of a microsecond)
       const bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       int occ16 = 0;
       const char *ww = std::getenv("GTOK_LANE_WG_WAVES");   // tuning knob: 8 = two 8-wave workgroups per CU
       const int wgw = (ww && ww[0] == '8') ? 8 : 16;
-      if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 64 * wgw, (size_t)a.lds * wgw) == hipSuccess && occ16 >= 16 / wgw) {
-        hipLaunchKernelGGL(kern, dim3(ncu * (16 / wgw)), dim3(64 * wgw), (size_t)a.lds * wgw, (hipStream_t)stream, a);
+      const size_t wg_lds = (size_t)a.lds * wgw + (wgw == 16 ? 16 : 8);
+      if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 64 * wgw, wg_lds) == hipSuccess && occ16 >= 16 / wgw) {
+        hipLaunchKernelGGL(kern, dim3(ncu * (16 / wgw)), dim3(64 * wgw), wg_lds, (hipStream_t)stream, a);
         return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
       }
       (void)hipGetLastError();
     }
-    if (g->unit_ptr && a.units > 16) {
+    if (g->unit_ptr && vunits > 16) {
       auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
-      int m = (int)(a.units * 0.6180339887498949);
-      while (gcd(m, a.units) != 1) ++m;
+      int m = (int)(vunits * 0.6180339887498949);
+      while (gcd(m, vunits) != 1) ++m;
       a.unit_mul = m;
     }
     int nb = ncu * occ;
-    if (nb > a.units) nb = a.units;
+    if (nb > vunits) nb = vunits;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64), (size_t)a.lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
   }
   SentArgs a;
   a.g = *g; a.p = *p; a.cap = cap; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
+  a.epochs = K;
+  const int pairs = g->num_graphs * K;          // (epoch, graph) pairs the launch walks
   int off = 0;
   if (reg_path) {
     a.l.adj = off; off += 64 * 8;
@@ -227,9 +255,9 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     // no truncation test in the walk when max_len can hold the longest possible trail of this batch
     const int64_t bound = p->labeled ? 2 + 7 * (int64_t)maxn + 2 * (int64_t)maxe : 2 + 5 * (int64_t)maxn + (int64_t)maxe;
     const bool nolim = bound <= p->max_len;
-    typedef void (*K)(const SentArgs);
-    kern = p->labeled ? (nolim ? (K)sent_reg_kernel<true, true> : (K)sent_reg_kernel<true, false>)
-                      : (nolim ? (K)sent_reg_kernel<false, true> : (K)sent_reg_kernel<false, false>);
+    typedef void (*KF)(const SentArgs);
+    kern = p->labeled ? (nolim ? (KF)sent_reg_kernel<true, true> : (KF)sent_reg_kernel<true, false>)
+                      : (nolim ? (KF)sent_reg_kernel<false, true> : (KF)sent_reg_kernel<false, false>);
   } else {
     switch (W) {
       case 1: PICK(1); break;
@@ -255,14 +283,14 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   int nb;
   if (reg_path) {
     occ = gtok::resident_blocks(occ);
-    a.units = (g->num_graphs + wpb - 1) / wpb;
+    a.units = (pairs + wpb - 1) / wpb;
     nb = ncu * occ;
     if (nb > a.units) nb = a.units;
     a.upb = (a.units + nb - 1) / nb;
     nb = (a.units + a.upb - 1) / a.upb;
   } else {
     occ = gtok::resident_waves(occ);     // one-wave workgroups
-    a.units = g->num_graphs; a.upb = 0;
+    a.units = pairs; a.upb = 0;
     nb = ncu * occ;
     if (nb > a.units) nb = a.units;
     slot = take_queue_slot(dev, (hipStream_t)stream);
@@ -348,9 +376,13 @@ __global__ void __launch_bounds__(256) sent_decode_kernel(const DecodeArgs a) {
   const int L = min(a.len[g], a.ld);
   int32_t *ea = a.edge_a + (int64_t)g * a.ecap, *eb = a.edge_b + (int64_t)g * a.ecap, *et = a.edge_t + (int64_t)g * a.ecap;
   int32_t *nt = a.node_type + (int64_t)g * a.ncap;
+  // a full output array does not stop the parse (include/gtok.h: with status 2 "counts are still right"): what does not
+  // fit is dropped, the row is read to its end, and only a row that is otherwise fine (0 or 3) reports 2 - so edge_cap =
+  // node_cap = 0 is a count-only pass (bench.py: nodes a truncated walk reached)
   int st = 3, prev = -1, nseen = 0, pending = -1, m = 0, i = 1;
+  bool over = false;
   auto add = [&](int from, int to, int type) {
-    if (m < a.ecap) { ea[m] = from; eb[m] = to; et[m] = type; } else st = 2;
+    if (m < a.ecap) { ea[m] = from; eb[m] = to; et[m] = type; } else over = true;
     ++m;
   };
   if (L < 1 || t[0] != GTOK_SENT_SOS) st = 1;
@@ -384,18 +416,19 @@ __global__ void __launch_bounds__(256) sent_decode_kernel(const DecodeArgs a) {
     if (k == nseen) {                         // first visit
       int type = -1;
       if (a.labeled) {
-        if (i >= L) { if (nseen < a.ncap) nt[nseen] = -1; else st = 2; ++nseen; break; }   // cut between the position and its type
+        if (i >= L) { if (nseen < a.ncap) nt[nseen] = -1; else over = true; ++nseen; break; }   // cut between the position and its type
         type = t[i] - a.node_off;
         if (type < 0) { st = 1; break; }      // (a type beyond num_node_types aliases the edge range: the grammar decides)
         ++i;
       }
-      if (nseen < a.ncap) nt[nseen] = type; else st = 2;
+      if (nseen < a.ncap) nt[nseen] = type; else over = true;
       ++nseen;
     } else if (k > nseen) { st = 1; break; }
     if (prev >= 0) add(prev, k, pending);
     pending = -1;
     prev = k;
   }
+  if (over && st != 1) st = 2;
   a.num_nodes[g] = nseen; a.num_edges[g] = m; a.status[g] = st;
 }
 
@@ -407,7 +440,8 @@ extern "C" int gtok_sent_decode(const int32_t *ids, int32_t ld, const int32_t *l
   if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (num_rows < 0 || ld <= 0 || edge_cap < 0 || node_cap < 0 || max_num_nodes < 0) return GTOK_E_INVAL;
   if (num_rows == 0) return GTOK_OK;
-  if (!ids || !len || !num_nodes || !num_edges || !edge_a || !edge_b || !edge_type || !node_type || !status) return GTOK_E_INVAL;
+  if (!ids || !len || !num_nodes || !num_edges || !status) return GTOK_E_INVAL;
+  if ((edge_cap > 0 && (!edge_a || !edge_b || !edge_type)) || (node_cap > 0 && !node_type)) return GTOK_E_INVAL;   // (a capacity of 0: count only, no array)
   DecodeArgs a;
   a.ids = ids; a.ld = ld; a.len = len; a.rows = num_rows; a.labeled = labeled;
   a.idx_off = GTOK_SENT_IDX_OFFSET; a.node_off = a.idx_off + max_num_nodes; a.edge_off = a.node_off + num_node_types;

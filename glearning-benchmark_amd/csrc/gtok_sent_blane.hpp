@@ -28,14 +28,20 @@ struct SentBLaneArgs {
   int32_t *out;
   int ld;
   int32_t *out_len;
-  int units;   // ceil(G / 64)
+  int units;   // ceil(G / 64): units of ONE epoch
+  int epochs;  // K >= 1 (gtok_sent_params.epoch_count): the launch walks units x K (unit, epoch) pairs, unit-major
   int prio;    // long units at a higher issue priority than the short ones they share a SIMD with
+  int pad_nt;  // padding leaves with non-temporal stores (slabs larger than the memory-side cache: gtok_sent_lane.hpp)
 };
 
 struct __attribute__((aligned(16))) U64x2 { uint64_t a, b; };
 
-template <int W, int P>
+// U16: the GTOK_SENT_U16 slab - rows of 16-bit ids, the token windows stored as they stand
+template <int W, int P, bool U16>
 __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const SentBLaneArgs a) {
+  using out_t = typename std::conditional<U16, uint16_t, int32_t>::type;
+  constexpr int EV = U16 ? 8 : 4;            // ids per 16-byte store
+  out_t *const out_base = reinterpret_cast<out_t *>(a.out);
   // LDS, all of it lane-private and laid out [dword][lane] (bank = lane): 16 W dwords node -> visit index (u8 each),
   // 2 W dwords bracket members in visit-index space (zero between brackets)
   // one workgroup per CU (8 waves at W = 4, else 16), each wave with its own 18 W x 256 bytes of the workgroup's LDS;
@@ -53,10 +59,10 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
   uint32_t k0, k1;   // Philox key in vector registers (gtok_sent_lane.hpp)
   asm volatile("v_mov_b32 %0, %1" : "=v"(k0) : "s"((uint32_t)a.p.seed));
   asm volatile("v_mov_b32 %0, %1" : "=v"(k1) : "s"((uint32_t)(a.p.seed >> 32)));
-  const uint32_t epoch = (uint32_t)a.p.epoch;
+  const uint32_t epoch0 = (uint32_t)a.p.epoch;
   const uint64_t T_RESET = GTOK_SENT_RESET, T_LADJ = GTOK_SENT_LADJ, T_RADJ = GTOK_SENT_RADJ, T_EOS = GTOK_SENT_EOS;
   const int G = a.g.num_graphs, pad = a.p.pad_id;
-  const bool no_pad = (a.p.flags & GTOK_SENT_NO_PAD) != 0;
+  const bool no_pad = (a.p.flags & GTOK_SENT_NO_PAD) != 0, pad_nt = a.pad_nt != 0;
 
   // Units are stored by descending expected length (lane_order), and the waves w, w + 4, w + 8, ... of a workgroup share a
   // SIMD (observed on gfx950, profiles/tools/probes/wave_simd_probe.hip; speed only): per round of gridDim x waves units,
@@ -72,9 +78,14 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
   } else if (nwaves > 4 && grp == 0) {
     __builtin_amdgcn_s_setprio(1);
   }
-  for (int idx = 0; idx < a.units; idx += (int)gridDim.x * nwaves) {
-    const int unit = idx + grp * qsize + ((grp & 1) ? qsize - 1 - jq : jq);
-    if (unit >= a.units) continue;
+  const int K = a.epochs, vunits = a.units * K;
+  for (int idx = 0; idx < vunits; idx += (int)gridDim.x * nwaves) {
+    const int vu = idx + grp * qsize + ((grp & 1) ? qsize - 1 - jq : jq);
+    if (vu >= vunits) continue;
+    int unit = vu, ep = 0;
+    if (K > 1) { unit = vu / K; ep = vu - unit * K; }
+    const uint32_t epoch = epoch0 + (uint32_t)ep;
+    const int64_t row0 = (int64_t)ep * G;          // first row of the epoch's [G, ld] slice
     const int slot = unit * 64 + lane;
     const bool valid = slot < G;
     const int g = valid ? (a.g.lane_order ? a.g.lane_order[slot] : slot) : 0;
@@ -114,7 +125,7 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
 
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
     const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
-    int32_t *__restrict__ orow = a.out + (int64_t)g * ld;
+    out_t *__restrict__ orow = out_base + (row0 + g) * ld;
     uint64_t vis[W], rowc[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) { vis[w] = 0; rowc[w] = 0; }
@@ -133,9 +144,7 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
 #pragma unroll
     for (int j = 0; j < SG - 1; ++j) pg[j] = 0;
     auto tok_of = [](uint64_t w, int i) __attribute__((always_inline)) -> int { return (int)((w >> (i << 4)) & 0xFFFFu); };
-    auto put4 = [&](int at, uint64_t w) __attribute__((always_inline)) {
-      *reinterpret_cast<I32x4 *>(orow + at) = I32x4{tok_of(w, 0), tok_of(w, 1), tok_of(w, 2), (int)(w >> 48)};
-    };
+    auto put4 = [&](int at, uint64_t w) __attribute__((always_inline)) { store_win(orow + at, w); };
     auto group_of = [&](int j, uint64_t w) __attribute__((always_inline)) -> uint64_t {
       uint64_t r = w;
 #pragma unroll
@@ -153,7 +162,7 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
           for (int k = 0; k < SG - 1; ++k) put4(sb + 4 * k, pg[k]);
           put4(fl, w);
         } else {
-          for (int j = 0; j < 4 * SG && sb + j < cap; ++j) orow[sb + j] = tok_of(group_of(j >> 2, w), j & 3);
+          for (int j = 0; j < 4 * SG && sb + j < cap; ++j) orow[sb + j] = (out_t)tok_of(group_of(j >> 2, w), j & 3);
         }
       }
     };
@@ -409,7 +418,7 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
     }
     int padfrom = 0;
     if (valid) {
-      a.out_len[g] = tot;
+      a.out_len[row0 + g] = tot;
       const int sb = fl & ~(4 * SG - 1);
       if (!a.p.query && pos <= cap && (ld & 3) == 0) {
         const int s16 = fl & ~15;
@@ -419,14 +428,12 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
           const int at = s16 + 4 * k;
           if (at >= sb && at < padfrom) {
             const uint64_t w = at == fl ? wlo : (at > fl ? 0ull : group_of((at - sb) >> 2, 0));
-            I32x4 v;
-            v.x = at + 0 < len ? tok_of(w, 0) : pad; v.y = at + 1 < len ? tok_of(w, 1) : pad;
-            v.z = at + 2 < len ? tok_of(w, 2) : pad; v.w = at + 3 < len ? tok_of(w, 3) : pad;
-            *reinterpret_cast<I32x4 *>(orow + at) = v;
+            store_tok4(orow + at, at + 0 < len ? tok_of(w, 0) : pad, at + 1 < len ? tok_of(w, 1) : pad,
+                       at + 2 < len ? tok_of(w, 2) : pad, at + 3 < len ? tok_of(w, 3) : pad);
           }
         }
       } else {
-        padfrom = min(ld, (tot + 3) & ~3);
+        padfrom = min(ld, (tot + EV - 1) & ~(EV - 1));
         for (int i = min(sb, len); i < padfrom; ++i) {
           int v = pad;
           if (i < len) {
@@ -435,7 +442,7 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
           } else if (i < tot) {
             v = i == len ? q0 : (i == len + 1 ? q1 : q2);
           }
-          orow[i] = v;
+          orow[i] = (out_t)v;
         }
       }
     }
@@ -445,22 +452,22 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
       for (int it = 0; it < 16; ++it) {
         const int r = it * 4 + (lane >> 4);
         const int lr = __builtin_amdgcn_ds_bpermute(r << 2, padfrom);
-        const int gr = __builtin_amdgcn_ds_bpermute(r << 2, valid ? g : -1);
+        const int gr = __builtin_amdgcn_ds_bpermute(r << 2, valid ? (int)(row0 + g) : -1);
         if (unit * 64 + it * 4 >= G) break;
         if (gr >= 0) {
-          int32_t *__restrict__ rowp = a.out + (int64_t)gr * ld + lr;
-          const int nrem = ld - lr, nvec = nrem >> 2;
+          out_t *__restrict__ rowp = out_base + (int64_t)gr * ld + lr;
+          const int nrem = ld - lr, nvec = nrem / EV;
           _Pragma("clang loop vectorize(disable) unroll(disable)")
-          for (int t = q; t < nvec; t += 16) store_pad16(rowp + 4 * t, pad);
-          if (q < (nrem & 3)) rowp[(nvec << 2) + q] = pad;
+          for (int t = q; t < nvec; t += 16) store_pad16(rowp + EV * t, pad, pad_nt);
+          if (q < (nrem & (EV - 1))) rowp[nvec * EV + q] = (out_t)pad;
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
 #ifdef GTOK_PHASE_TIMING
     GTOK_PT(4)
-    if (lane == 0 && ld >= 16) {
-      int32_t *row = a.out + (int64_t)g * ld + ld - 8;
+    if (!U16 && lane == 0 && ld >= 16) {
+      int32_t *row = a.out + (row0 + g) * ld + ld - 8;
       row[0] = (int32_t)pt[0]; row[1] = (int32_t)pt[1]; row[2] = (int32_t)pt[2]; row[3] = (int32_t)pt[3]; row[4] = (int32_t)pt[4];
       row[5] = (int32_t)uni(pt_steps); row[6] = (int32_t)((uni(pt_it1) << 16) | uni(pt_it2));
       row[7] = (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - pt_rt0);

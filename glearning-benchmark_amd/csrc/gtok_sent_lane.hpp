@@ -31,6 +31,9 @@ namespace gtok {
 #ifndef GTOK_LANE_SECTOR_GROUPS
 #define GTOK_LANE_SECTOR_GROUPS 2
 #endif
+#ifndef GTOK_LANE_SECTOR_GROUPS_U16
+#define GTOK_LANE_SECTOR_GROUPS_U16 2      // 16-bit slab: 2 windows = 8 ids = ONE 16-byte store per burst (4: 32 bytes, two stores)
+#endif
 
 struct __attribute__((aligned(4))) U32x2a4 { uint32_t lo, hi; };   // two dwords at a 4-byte aligned LDS address: ds_read2_b32
 
@@ -96,14 +99,34 @@ __device__ __forceinline__ void lane_commit16(const uint8_t *__restrict__ src, i
 // Padding store.  (-DGTOK_SC1_PAD_STORES: `sc1` stores, written through and dropped from the XCD's L2 - tried to keep
 // the padding, 56 % of a ZINC slab, from pushing half-written token lines out of L2: the counted write traffic did not
 // move (359 vs 353 MB) and the walks got slower behind the write-through stores, 0.120 vs 0.1175 ms.)
-__device__ __forceinline__ void store_pad16(int32_t *p, int pad) {
-#ifndef GTOK_SC1_PAD_STORES
-  *reinterpret_cast<I32x4 *>(p) = I32x4{pad, pad, pad, pad};
-#else
+// nt: non-temporal stores - for slabs beyond the 256 MB of the memory-side cache the padding (more than half of a molecule
+// slab) otherwise pushes the half-written token lines out ahead of their time: 31 k molecules x 21 epochs 0.289 -> 0.190 ms,
+// 1 M molecules 0.378 -> 0.345 ms; a slab that fits (ZINC-full: 208 MB) is 1.5 % slower with them, so the launcher decides
+__device__ __forceinline__ void store_pad16_raw(void *p, int pp, bool nt) {
   typedef int v4i __attribute__((ext_vector_type(4)));
-  const v4i v = {pad, pad, pad, pad};
+  const v4i v = {pp, pp, pp, pp};
+#if defined(GTOK_SC1_PAD_STORES)
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  else *reinterpret_cast<I32x4 *>(p) = I32x4{pp, pp, pp, pp};
 #endif
+}
+__device__ __forceinline__ void store_pad16(int32_t *p, int pad, bool nt) { store_pad16_raw(p, pad, nt); }
+// (GTOK_SENT_U16 slab: eight 16-bit ids per 16-byte store)
+__device__ __forceinline__ void store_pad16(uint16_t *p, int pad, bool nt) { store_pad16_raw(p, (int)(((uint32_t)pad & 0xFFFFu) * 0x00010001u), nt); }
+// four tokens of a row at once: a 16-byte store into the int32 slab, an 8-byte store into the 16-bit slab
+__device__ __forceinline__ void store_tok4(int32_t *p, int t0, int t1, int t2, int t3) { *reinterpret_cast<I32x4 *>(p) = I32x4{t0, t1, t2, t3}; }
+__device__ __forceinline__ void store_tok4(uint16_t *p, int t0, int t1, int t2, int t3) {
+  *reinterpret_cast<I32x2 *>(p) = I32x2{(int)(((uint32_t)t0 & 0xFFFFu) | ((uint32_t)t1 << 16)), (int)(((uint32_t)t2 & 0xFFFFu) | ((uint32_t)t3 << 16))};
+}
+// a window of four 16-bit tokens as it stands (the 16-bit slab stores it unchanged: no unpacking)
+__device__ __forceinline__ void store_win(int32_t *p, uint64_t w) {
+  *reinterpret_cast<I32x4 *>(p) = I32x4{(int)(w & 0xFFFFu), (int)((w >> 16) & 0xFFFFu), (int)((w >> 32) & 0xFFFFu), (int)(w >> 48)};
+}
+__device__ __forceinline__ void store_win(uint16_t *p, uint64_t w) { *reinterpret_cast<I32x2 *>(p) = I32x2{(int)(uint32_t)w, (int)(uint32_t)(w >> 32)}; }
+__device__ __forceinline__ void store_win2(uint16_t *p, uint64_t w0, uint64_t w1) {   // two windows = eight ids = one 16-byte store
+  *reinterpret_cast<I32x4 *>(p) = I32x4{(int)(uint32_t)w0, (int)(uint32_t)(w0 >> 32), (int)(uint32_t)w1, (int)(uint32_t)(w1 >> 32)};
 }
 
 struct SentLaneArgs {
@@ -116,15 +139,21 @@ struct SentLaneArgs {
   int32_t *out;
   int ld;
   int32_t *out_len;
-  int units;
+  int units;      // units of ONE epoch (64-graph groups, or the unit table of a reordered batch)
+  int epochs;     // K >= 1 (gtok_sent_params.epoch_count): the launch walks units x K (unit, epoch) pairs, unit-major
   int unit_mul;   // 0: units in order
-  int prio_cut[3];   // reordered batch: units below these ranks (in 64ths of the stored order) run at priority 3 / 2 / 1                               // 64-graph units in the batch
+  int prio_cut[3];   // reordered batch: units below these ranks (in 64ths of the stored order) run at priority 3 / 2 / 1
+  int pad_nt;        // padding leaves with non-temporal stores (slabs larger than the memory-side cache)
 };
 
 // PK: the batch carries the byte-packed rowptr / col mirror (gtok_csr.rowptr8 / col8): a unit is staged with 12
 // 16-byte loads per lane, all in flight at once, and no packing instructions
-template <bool LAB, int P, bool REMAP, bool PK>
+// U16: the GTOK_SENT_U16 slab - rows of 16-bit ids, the token windows stored as they stand
+template <bool LAB, int P, bool REMAP, bool PK, bool U16>
 __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
+  using out_t = typename std::conditional<U16, uint16_t, int32_t>::type;
+  constexpr int EV = U16 ? 8 : 4;            // ids per 16-byte store
+  out_t *const out_base = reinterpret_cast<out_t *>(a.out);
   // one-wave workgroups (batch in dataset order), or ONE 16-wave workgroup per CU (reordered batch: see the unit loop);
   // waves never cooperate either way, each owns a.lds bytes of the workgroup's LDS
   extern __shared__ __align__(16) unsigned char smem_all[];
@@ -141,7 +170,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   uint32_t k0, k1;
   asm volatile("v_mov_b32 %0, %1" : "=v"(k0) : "s"((uint32_t)a.p.seed));
   asm volatile("v_mov_b32 %0, %1" : "=v"(k1) : "s"((uint32_t)(a.p.seed >> 32)));
-  const uint32_t epoch = (uint32_t)a.p.epoch;
+  const uint32_t epoch0 = (uint32_t)a.p.epoch;
   constexpr bool remap = REMAP;             // folded into the emission constants (host guarantees maxn <= max_num_nodes)
   const int pos_base = remap ? 22 : idx_off;
   const uint64_t T_RESET = remap ? 2 : GTOK_SENT_RESET, T_LADJ = remap ? 2 : GTOK_SENT_LADJ;
@@ -241,7 +270,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   const int stride = (int)gridDim.x;
   int lw = 0, done_row = -1, done_cnt = 0;  // pad start of this lane's finished row, that row (-1: none), rows of the finished unit
   // pad the tails of a finished unit's 64 rows: four rows per pass, 16 lanes x 16-byte stores on each
-  const bool no_pad = (a.p.flags & GTOK_SENT_NO_PAD) != 0;
+  const bool no_pad = (a.p.flags & GTOK_SENT_NO_PAD) != 0, pad_nt = a.pad_nt != 0;
   auto pad_rows = [&]() __attribute__((always_inline)) {
     if (no_pad) return;
     const int q = lane & 15;
@@ -251,11 +280,11 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       const int gr = __builtin_amdgcn_ds_bpermute(r << 2, done_row);   // (rows of a reordered batch are not neighbours)
       if (it * 4 >= done_cnt) break;
       if (gr >= 0) {
-        int32_t *__restrict__ rowp = a.out + (int64_t)gr * ld + lr;
-        const int nrem = ld - lr, nvec = nrem >> 2;
+        out_t *__restrict__ rowp = out_base + (int64_t)gr * ld + lr;
+        const int nrem = ld - lr, nvec = nrem / EV;
         _Pragma("clang loop vectorize(disable) unroll(disable)")
-        for (int t = q; t < nvec; t += 16) store_pad16(rowp + 4 * t, pad);
-        if (q < (nrem & 3)) rowp[(nvec << 2) + q] = pad;
+        for (int t = q; t < nvec; t += 16) store_pad16(rowp + EV * t, pad, pad_nt);
+        if (q < (nrem & (EV - 1))) rowp[nvec * EV + q] = (out_t)pad;
       }
     }
   };
@@ -263,7 +292,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   uint64_t ts[5] = {0, 0, 0, 0, 0};
   uint32_t rt0 = 0, iters = 0;
   auto stamps_out = [&]() __attribute__((always_inline)) {
-    if (lane == 0 && ld >= 16 && done_row >= 0) {
+    if (!U16 && lane == 0 && ld >= 16 && done_row >= 0) {
       int32_t *row = a.out + (int64_t)done_row * ld + ld - 8;
       row[0] = (int32_t)(ts[1] - ts[0]); row[1] = (int32_t)(ts[2] - ts[1]); row[2] = (int32_t)(ts[3] - ts[2]);
       row[3] = (int32_t)(ts[4] - ts[3]); row[4] = (int32_t)rt0; row[5] = (int32_t)__builtin_amdgcn_s_memrealtime();
@@ -285,14 +314,36 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   const int nslots = cus * 16, qsize = cus * 4;
   const int quarter = wg_waves == 8 ? (wg_type == 0 ? ((wave >> 2) ? 3 : 0) : ((wave >> 2) ? 2 : 1)) : wave >> 2;
   const int jq = (wave & 3) * cus + wg_cu;
-  for (int idx = percu ? 0 : (a.unit_mul ? (int)blockIdx.x : virtual_block()); idx < a.units; idx += percu ? nslots : stride) {
-    int unit = idx;
-    if (percu) {
-      unit = idx + quarter * qsize + ((quarter & 1) ? qsize - 1 - jq : jq);
-      if (unit >= a.units) continue;
-    } else if (a.unit_mul) {
-      unit = (int)(((uint64_t)(uint32_t)idx * (uint32_t)a.unit_mul) % (uint32_t)a.units);
-    }
+  // K epochs in one launch: the launch walks (unit, epoch) pairs, unit-major - the K walks of a unit are neighbours in the
+  // order (same CSR chunk: L2 hits; same length class)
+  const int K = a.epochs, vunits = a.units * K;
+  // Beyond the first round of resident waves (more than nslots pairs: corpora of > 260 k molecules, or K epochs of a
+  // smaller one) the pairs are handed out DYNAMICALLY: workgroup b owns the pairs nslots + t * gridDim + b, t = 0, 1, ...
+  // (every CU the same mix of lengths, longest first), and a wave that has finished a unit draws the next t from a ticket
+  // counter in the workgroup's LDS.  (With the static split of round 3 - every wave one unit of every round, priorities
+  // by quarter - the low-priority waves of a SIMD ran their later units alone at half the issue rate: 1 M molecules took
+  // 6.5 x the time of 249 k.)
+  int *wg_ticket = reinterpret_cast<int *>(smem_all + (size_t)wg_waves * a.lds);
+  if (percu) {
+    if (threadIdx.x == 0) *wg_ticket = 0;
+    __syncthreads();
+  }
+  // first unit: the static deal of the first round (per-CU workgroups), or the one-wave workgroup's own index
+  int cursor = percu ? 0 : (a.unit_mul ? (int)blockIdx.x : virtual_block());
+  auto spread = [&](int i) -> int { return (a.unit_mul && i < vunits) ? (int)(((uint64_t)(uint32_t)i * (uint32_t)a.unit_mul) % (uint32_t)vunits) : i; };
+  int vu = percu ? quarter * qsize + ((quarter & 1) ? qsize - 1 - jq : jq) : spread(cursor);
+#ifndef GTOK_LANE_NO_PRIO
+  if (percu) {   // the quarter is also the wave's issue priority in the first round
+    if (quarter == 0) __builtin_amdgcn_s_setprio(3);
+    else if (quarter == 1) __builtin_amdgcn_s_setprio(2);
+    else if (quarter == 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+#endif
+  while (vu < vunits) {
+    int unit = vu;
+    uint32_t epoch = epoch0;
+    if (K > 1) { unit = vu / K; epoch += (uint32_t)(vu - unit * K); }
     // ---- stage this unit; the loads of phase A go out ahead of the previous unit's padding stores
 #ifdef GTOK_PHASE_TIMING
     const uint64_t ts0_new = __builtin_amdgcn_s_memtime();
@@ -337,10 +388,6 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     // higher issue priority than the waves they share a SIMD with, which have slack.  A reordered batch stores its units
     // by descending walk length (the first eighth are the stragglers); otherwise the unit's largest graph predicts it.
     if (percu) {
-      if (quarter == 0) __builtin_amdgcn_s_setprio(3);
-      else if (quarter == 1) __builtin_amdgcn_s_setprio(2);
-      else if (quarter == 2) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
     } else if (a.g.unit_ptr) {
       const int rank = (int)(((int64_t)unit << 6) / a.units);   // 0..63
       if (rank < a.prio_cut[0]) __builtin_amdgcn_s_setprio(3);
@@ -444,7 +491,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     // ---- walk (per lane; mirrors oracle_sent step for step)
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
     const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
-    int32_t *__restrict__ orow = a.out + (int64_t)g * ld;
+    out_t *__restrict__ orow = out_base + ((int64_t)(epoch - epoch0) * G + g) * ld;
     set_t vis = 0, live = 0;
     uint64_t wlo = 0;
     int nvis = 0, pos = 0, fl = 0, d = 0, cur = 0;
@@ -454,14 +501,14 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     // four back-to-back 16-byte stores, so every 64-byte piece of a row reaches the L2 complete and within one burst.
     // (One 16-byte store per window left each row line half written for ~15 us at a time, and the open lines of all
     // resident lanes - 32 MB - are the whole L2: 2.8 bytes were counted at the L2's memory side per token byte.)
-    constexpr int SG = GTOK_LANE_SECTOR_GROUPS;   // windows per store burst: 4 = 64-byte sectors, 2 = 32 bytes, 1 = every window on its own
+    constexpr int SG = U16 ? GTOK_LANE_SECTOR_GROUPS_U16 : GTOK_LANE_SECTOR_GROUPS;   // windows per store burst: 4 = 16 tokens, 2 = 8, 1 = every window on its own
     uint64_t pg[SG > 1 ? SG - 1 : 1];
 #pragma unroll
     for (int j = 0; j < SG - 1; ++j) pg[j] = 0;
     auto tok_of = [](uint64_t w, int i) __attribute__((always_inline)) -> int { return (int)((w >> (i << 4)) & 0xFFFFu); };
     auto put4 = [&](int at, uint64_t w) __attribute__((always_inline)) {
 #ifndef GTOK_ABLATE_STORES   // (profiling builds, profiles/tools/lane_ablate.sh: a phase is cut out - wrong tokens - and the time it took shows)
-      *reinterpret_cast<I32x4 *>(orow + at) = I32x4{tok_of(w, 0), tok_of(w, 1), tok_of(w, 2), (int)(w >> 48)};
+      store_win(orow + at, w);
 #else
       if (w == 0x123456789ABCDEFull) orow[at] = 1;
 #endif
@@ -479,11 +526,21 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       if (gi == SG - 1) {
         const int sb = fl - 4 * (SG - 1);
         if (fl + 4 <= cap) {
+          if constexpr (U16 && (SG & 1) == 0) {      // 16-bit slab: two windows per 16-byte store, nothing to unpack
+#ifndef GTOK_ABLATE_STORES
+            auto win = [&](int j) __attribute__((always_inline)) -> uint64_t { return j < SG - 1 ? pg[j < SG - 1 ? j : 0] : w; };
 #pragma unroll
-          for (int k = 0; k < SG - 1; ++k) put4(sb + 4 * k, pg[k]);
-          put4(fl, w);
+            for (int k = 0; k < SG; k += 2) store_win2(orow + sb + 4 * k, win(k), win(k + 1));
+#else
+            if (w == 0x123456789ABCDEFull) orow[sb] = 1;
+#endif
+          } else {
+#pragma unroll
+            for (int k = 0; k < SG - 1; ++k) put4(sb + 4 * k, pg[k]);
+            put4(fl, w);
+          }
         } else {                                 // the row's cut (max_len or a narrow slab) falls inside this burst
-          for (int j = 0; j < 4 * SG && sb + j < cap; ++j) orow[sb + j] = tok_of(group_of(j >> 2, w), j & 3);
+          for (int j = 0; j < 4 * SG && sb + j < cap; ++j) orow[sb + j] = (out_t)tok_of(group_of(j >> 2, w), j & 3);
         }
       }
     };
@@ -622,8 +679,9 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       tot = len + 3;
     }
     int padfrom = 0;                             // where the cooperative padding of this lane's row starts
+    const int orow_idx = (int)(epoch - epoch0) * G + g;   // row of the [K, G, ld] slab (K * G < 2^30: checked by the launcher)
     if (valid) {
-      a.out_len[g] = tot;
+      a.out_len[orow_idx] = tot;
       const int sb = fl & ~(4 * SG - 1);         // [sb, fl): groups of the open burst, [fl, pos): the window
       if (!a.p.query && pos <= cap && (ld & 3) == 0) {
         // common case (row not cut, no query tail): the open burst, the window and the padding up to the next 16-token
@@ -635,14 +693,12 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
           const int at = s16 + 4 * k;
           if (at >= sb && at < padfrom) {
             const uint64_t w = at == fl ? wlo : (at > fl ? 0ull : group_of((at - sb) >> 2, 0));
-            I32x4 v;
-            v.x = at + 0 < len ? tok_of(w, 0) : pad; v.y = at + 1 < len ? tok_of(w, 1) : pad;
-            v.z = at + 2 < len ? tok_of(w, 2) : pad; v.w = at + 3 < len ? tok_of(w, 3) : pad;
-            *reinterpret_cast<I32x4 *>(orow + at) = v;
+            store_tok4(orow + at, at + 0 < len ? tok_of(w, 0) : pad, at + 1 < len ? tok_of(w, 1) : pad,
+                       at + 2 < len ? tok_of(w, 2) : pad, at + 3 < len ? tok_of(w, 3) : pad);
           }
         }
       } else {
-        padfrom = min(ld, (tot + 3) & ~3);
+        padfrom = min(ld, (tot + EV - 1) & ~(EV - 1));
         for (int i = min(sb, len); i < padfrom; ++i) {
           int v = pad;
           if (i < len) {
@@ -651,13 +707,13 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
           } else if (i < tot) {
             v = i == len ? q0 : (i == len + 1 ? q1 : q2);
           }
-          orow[i] = v;
+          orow[i] = (out_t)v;
         }
       }
     }
 
     lw = padfrom;
-    done_row = valid ? g : -1;
+    done_row = valid ? orow_idx : -1;
     done_cnt = h.gl - h.g0;
 #ifdef GTOK_PHASE_TIMING
     ts[4] = __builtin_amdgcn_s_memtime();
@@ -665,6 +721,18 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     };
     if (__ballot(valid && n > 32) == 0) unit_body(std::true_type{});
     else unit_body(std::false_type{});
+    // ---- the next unit
+    if (percu) {
+      int t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add(wg_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      vu = (int)gridDim.x * (16 / wgs_per_cu) + uni(t) * (int)gridDim.x + (int)blockIdx.x;
+#ifndef GTOK_LANE_NO_PRIO
+      __builtin_amdgcn_s_setprio(0);   // dynamic rounds: whoever is free takes the longest unit left
+#endif
+    } else {
+      cursor += stride;
+      vu = spread(cursor);
+    }
   }
   if (done_cnt > 0) pad_rows();
 #ifdef GTOK_PHASE_TIMING

@@ -31,19 +31,25 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
   const int idx_off = GTOK_SENT_IDX_OFFSET;
   const int node_off = idx_off + a.p.max_num_nodes;
   const int edge_off = node_off + a.p.num_node_types;
-  const uint32_t k0 = (uint32_t)a.p.seed, k1 = (uint32_t)(a.p.seed >> 32), epoch = (uint32_t)a.p.epoch;
+  const uint32_t k0 = (uint32_t)a.p.seed, k1 = (uint32_t)(a.p.seed >> 32), epoch0 = (uint32_t)a.p.epoch;
   const bool remap = a.p.remap_zinc != 0;
+  const bool u16 = (a.p.flags & GTOK_SENT_U16) != 0;               // rows of 16-bit ids (include/gtok.h)
   constexpr int per = LAB ? 2 : 1;
   const bool is0 = lane == 0, is1 = lane == 1;
 #define GTOK_TOK_ORDER() asm volatile("" ::: "memory")
 
   // graphs are drawn one at a time (gtok_common.hpp: Tickets): 10..256-node graphs differ >10x in walk length
-  const int G = a.g.num_graphs, nwaves = (int)(gridDim.x * wpb), wave_index = (int)(blockIdx.x * wpb + wave);
+  // (K epochs in one launch: tickets run over the G x K (epoch, graph) pairs, epoch-major - pair gv is graph gv mod G in
+  // epoch gv / G and row gv of the [K, G, ld] slab)
+  const int G = a.g.num_graphs, K = a.epochs, GV = G * K;
+  const int nwaves = (int)(gridDim.x * wpb), wave_index = (int)(blockIdx.x * wpb + wave);
   Tickets tickets;
-  tickets.init(a.queue, wave_index, nwaves, G);
-  int g = wave_index;
-  while (g < G) {
+  tickets.init(a.queue, wave_index, nwaves, GV);
+  int gv = wave_index;
+  while (gv < GV) {
     const int ticket = tickets.draw(is0);
+    const int g = K > 1 ? gv % G : gv;
+    const uint32_t epoch = epoch0 + (uint32_t)(K > 1 ? gv / G : 0);
 #ifdef GTOK_PHASE_TIMING   // profiling build only: cycle stamps per phase, left in the row's last columns
     const uint64_t ts0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -301,19 +307,19 @@ __global__ void __launch_bounds__(256) sent_lds_kernel(const SentArgs a) {
       len = ltrail + 3;
     }
     wave_sync();
-    write_row_tok16(a.out + (int64_t)g * a.ld, a.ld, min(len, a.ld), a.p.pad_id, tok, [=](int t, int i) -> int {
-      return (remap && i < ltrail) ? remap_zinc_token(t, idx_off, node_off, edge_off) : t;
-    });
-    if (is0) a.out_len[g] = len;
+    auto final_id = [=](int t, int i) -> int { return (remap && i < ltrail) ? remap_zinc_token(t, idx_off, node_off, edge_off) : t; };
+    if (u16) write_row_tok16(reinterpret_cast<uint16_t *>(a.out) + (int64_t)gv * a.ld, a.ld, min(len, a.ld), a.p.pad_id, tok, final_id);
+    else write_row_tok16(a.out + (int64_t)gv * a.ld, a.ld, min(len, a.ld), a.p.pad_id, tok, final_id);
+    if (is0) a.out_len[gv] = len;
     wave_sync();
 #ifdef GTOK_PHASE_TIMING
     if (is0 && a.ld >= 8) {
       const uint64_t ts4 = __builtin_amdgcn_s_memtime();
-      int32_t *row = a.out + (int64_t)g * a.ld + a.ld - 4;
+      int32_t *row = a.out + (int64_t)gv * a.ld + a.ld - 4;
       row[0] = (int32_t)(ts1 - ts0); row[1] = (int32_t)(ts2 - ts1); row[2] = (int32_t)(ts3 - ts2); row[3] = (int32_t)(ts4 - ts3);
     }
 #endif
-    g = tickets.settle(ticket, is0);
+    gv = tickets.settle(ticket, is0);
   }
   tickets.retire(is0, lane, nwaves);
 #undef GTOK_TOK_ORDER

@@ -25,7 +25,8 @@ struct SentArgs {
   int32_t *out;
   int ld;
   int32_t *out_len;
-  int units;      // ceil(G / waves_per_block)
+  int epochs;     // K >= 1 (gtok_sent_params.epoch_count): the launch walks G x K (epoch, graph) pairs, epoch-major
+  int units;      // ceil(G * K / waves_per_block)
   int upb;        // units per block
   int *queue;     // sent_lds_kernel: ticket counter block (gtok_common.hpp: Tickets)
 };
@@ -124,8 +125,9 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
   const int idx_off = GTOK_SENT_IDX_OFFSET;
   const int node_off = idx_off + a.p.max_num_nodes;
   const int edge_off = node_off + a.p.num_node_types;
-  const uint32_t k0 = (uint32_t)a.p.seed, k1 = (uint32_t)(a.p.seed >> 32), epoch = (uint32_t)a.p.epoch;
+  const uint32_t k0 = (uint32_t)a.p.seed, k1 = (uint32_t)(a.p.seed >> 32), epoch0 = (uint32_t)a.p.epoch;
   const bool remap = a.p.remap_zinc != 0;
+  const bool u16 = (a.p.flags & GTOK_SENT_U16) != 0;               // rows of 16-bit ids (include/gtok.h)
   const int pos_base = remap ? 22 : idx_off;                       // 22 + (t - idx_off)
   const int T_RESET = remap ? 2 : GTOK_SENT_RESET, T_LADJ = remap ? 2 : GTOK_SENT_LADJ;
   const int T_RADJ = remap ? 2 : GTOK_SENT_RADJ, T_EOS = remap ? 1 : GTOK_SENT_EOS;
@@ -159,20 +161,27 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
 
   const int vb = virtual_block();
   const int u0 = vb * a.upb, u1 = min(a.units, u0 + a.upb);
-  const int G = a.g.num_graphs;
-  int g = u0 * wpb + wave;
-  if (u0 >= u1 || g >= G) return;
+  // K epochs in one launch: the wave's index runs over (epoch, graph) pairs, epoch-major - pair gv is graph gv mod G in
+  // epoch gv / G and row gv of the [K, G, ld] slab.  A wave's pairs are wpb apart: the graph index advances by wpb and
+  // wraps (one division per wave, at its first pair).
+  const int G = a.g.num_graphs, GV = G * a.epochs;
+  auto wrap = [&](int v) -> int { while (v >= G) v -= G; return v; };   // (one subtraction unless the batch has fewer graphs than the workgroup waves)
+  int gv = u0 * wpb + wave;
+  if (u0 >= u1 || gv >= GV) return;
+  int g = gv;
+  uint32_t epoch = epoch0;
+  if (a.epochs > 1) { const int e0 = gv / G; g = gv - e0 * G; epoch += (uint32_t)e0; }
   Ptrs pc = load_ptrs(g);
   Data dc = load_data(g, pc);
-  bool has_next = (u0 + 1 < u1) && (g + wpb < G);
+  bool has_next = (u0 + 1 < u1) && (gv + wpb < GV);
   Ptrs pn = pc;
-  if (has_next) pn = load_ptrs(g + wpb);
+  if (has_next) pn = load_ptrs(wrap(g + wpb));
   for (int unit = u0;; ++unit) {
     Data dn = dc;
-    if (has_next) dn = load_data(g + wpb, pn);
-    const bool has_next2 = (unit + 2 < u1) && (g + 2 * wpb < G);
+    if (has_next) dn = load_data(wrap(g + wpb), pn);
+    const bool has_next2 = (unit + 2 < u1) && (gv + 2 * wpb < GV);
     Ptrs pnn = pn;
-    if (has_next2) pnn = load_ptrs(g + 2 * wpb);
+    if (has_next2) pnn = load_ptrs(wrap(wrap(g + wpb) + wpb));
 
     const int nfull = pc.n1 - pc.n0;
     const int n = min(nfull, 64);
@@ -419,9 +428,11 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
     }
     wave_sync();
     {
-      int32_t *__restrict__ orow = a.out + (int64_t)g * a.ld;
+      int32_t *__restrict__ orow = a.out + (int64_t)gv * a.ld;
+      uint16_t *__restrict__ orow16 = reinterpret_cast<uint16_t *>(a.out) + (int64_t)gv * a.ld;
       const int ld = a.ld, pad = a.p.pad_id, lw = min(len, ld);
-      if (((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(orow) & 15u) == 0)) {
+      const uintptr_t addr = u16 ? reinterpret_cast<uintptr_t>(orow16) : reinterpret_cast<uintptr_t>(orow);
+      if (((ld & 3) == 0) && ((addr & (u16 ? 7u : 15u)) == 0)) {
         for (int i = lane * 4; i < ld; i += kWave * 4) {
           int4 o = make_int4(pad, pad, pad, pad);
           if (i < lw) {
@@ -444,7 +455,13 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
             o.z = i + 2 < lw ? t[2] : pad;
             o.w = i + 3 < lw ? t[3] : pad;
           }
-          *reinterpret_cast<int4 *>(orow + i) = o;
+          if (u16) {
+            uint2 p2;
+            p2.x = ((uint32_t)o.x & 0xFFFFu) | ((uint32_t)o.y << 16); p2.y = ((uint32_t)o.z & 0xFFFFu) | ((uint32_t)o.w << 16);
+            *reinterpret_cast<uint2 *>(orow16 + i) = p2;
+          } else {
+            *reinterpret_cast<int4 *>(orow + i) = o;
+          }
         }
       } else {
         for (int i = lane; i < ld; i += kWave) {
@@ -456,14 +473,15 @@ __global__ void __launch_bounds__(256) sent_reg_kernel(const SentArgs a) {
               t = remap ? remap_edge_type(at, edge_off) : edge_off + at;
             }
           }
-          orow[i] = t;
+          if (u16) orow16[i] = (uint16_t)t; else orow[i] = t;
         }
       }
     }
-    if (is0) a.out_len[g] = len;
+    if (is0) a.out_len[gv] = len;
     wave_sync();
     if (!has_next) break;
-    g += wpb;
+    gv += wpb;
+    for (g += wpb; g >= G; g -= G) ++epoch;      // into the next epoch's slice
     pc = pn; dc = dn; pn = pnn;
     has_next = has_next2;
   }

@@ -136,7 +136,7 @@ def pack8(batch: GraphBatch) -> bool:
     return True
 
 
-LANE_UNIT_LDS = 10240      # LDS bytes a unit of the reordered batch may need: 16 waves per CU stay resident (160 KB / 16)
+LANE_UNIT_LDS = 10224      # LDS bytes a unit of the reordered batch may need: 16 waves per CU stay resident (160 KB / 16, less the 16 bytes of the workgroup's ticket counter)
 
 
 def lane_sorted(batch: GraphBatch) -> Optional[GraphBatch]:
@@ -267,36 +267,53 @@ def adjbits(batch: GraphBatch) -> bool:
 def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: int = 0, labeled: bool = False,
          num_node_types: int = 0, num_edge_types: int = 0, remap_zinc: bool = False, pad_id: int = SENT_PAD,
          graph_base: int = 0, query: Optional[torch.Tensor] = None,
-         ld: Optional[int] = None, out=None, pad: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+         ld: Optional[int] = None, out=None, pad: bool = True, epochs: int = 1, u16: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """SENT trail walk.  Returns (ids int32 [G, ld], len int32 [G]); len > ld flags a too-narrow slab.
     pad=False (GTOK_SENT_NO_PAD): rows are only written up to their length - for consumers that go through `len`
-    (ops.collate does); the rest of the slab keeps whatever it held."""
+    (ops.collate does); the rest of the slab keeps whatever it held.
+    epochs=K > 1 (gtok_sent_params.epoch_count): the trails of epochs epoch .. epoch + K - 1 in ONE launch - returns
+    (ids [K, G, ld], len [K, G]); slice e is what a call with epoch + e returns.  The trainer re-tokenizes its splits every
+    epoch (trainer/train_agtt.py:246-250): K epochs of a small split fill the chip where one cannot.
+    u16=True (GTOK_SENT_U16): the slab holds 16-bit ids (torch.int16 storage, to be read as unsigned: every SENT id fits) -
+    half the bytes; readers: ops.collate_packed / ops.unpack_rows with row_ptr=None, ops.pack_rows_u16."""
     _need_gpu(batch.col, "sent")
     dev = batch.device
+    K = max(1, int(epochs))
     if query is not None:
         query = query.to(dev, dtype=torch.int32).contiguous()
         if tuple(query.shape) != (batch.num_graphs, 2):
             raise ValueError("query must be [G, 2] (query_u, query_v)")
     if ld is None:
         ld = sent_safe_ld(batch, labeled, max_len, query is not None)
-    ids, ln = _alloc_out(batch.num_graphs, ld, dev, out)
+    G = batch.num_graphs
+    if out is not None:
+        ids, ln = out
+        want = torch.int16 if u16 else torch.int32
+        if ids.dtype != want or ln.dtype != torch.int32 or ids.numel() != K * G * ld or ln.numel() != K * G \
+                or not ids.is_contiguous() or not ln.is_contiguous() or ids.device != torch.device(dev) or (G and ids.shape[-1] != ld):
+            raise ValueError(f"out must be ({want} [K * G, ld] contiguous, int32 [K * G]) on the batch's device")
+    else:
+        ids = torch.empty((K * G, ld), dtype=torch.int16 if u16 else torch.int32, device=dev)
+        ln = torch.empty((K * G,), dtype=torch.int32, device=dev)
     pack8(batch)
     pin = os.environ.get("GTOK_SENT_KERNEL", "")
     # the bit-matrix mirror is only built where gtok_sent would pick the kernel that reads it: unlabelled batches of
-    # >= ADJBITS_MIN_GRAPHS graphs that the molecule kernel (<= 64 nodes, simple symmetric, >= LANE_MIN_GRAPHS) does not
+    # >= ADJBITS_MIN_GRAPHS walks that the molecule kernel (<= 64 nodes, simple symmetric, >= LANE_MIN_GRAPHS) does not
     # take - and never again for a batch that turned out unusable (a closure degree above 255)
+    walks = G * K
     lane_takes = batch.max_nodes <= 64 and batch.max_edges <= 255 and bool(batch.flags & _lib.CSR_SIMPLE_SYMMETRIC) \
-        and batch.num_graphs >= LANE_MIN_GRAPHS
-    wants_blane = pin == "blane" or (not pin and not labeled and not remap_zinc and batch.num_graphs >= ADJBITS_MIN_GRAPHS and not lane_takes)
+        and walks >= LANE_MIN_GRAPHS
+    wants_blane = pin == "blane" or (not pin and not labeled and not remap_zinc and walks >= ADJBITS_MIN_GRAPHS and not lane_takes)
     if wants_blane and not batch.adj_unusable:
         if adjbits(batch):
             if os.environ.get("GTOK_BLANE_ORDER", "1") != "0" and batch.lane_order_len != max(1, max_len):
                 batch.lane_order, batch.lane_order_len = _lane_order(batch, max(1, max_len)), max(1, max_len)   # once per (batch, max_len)
         elif batch.col.device.type == "cuda" and batch.max_nodes <= 256 and os.environ.get("GTOK_NO_ADJBITS") != "1":
             batch.adj_unusable = True
+    flags = (0 if pad else _lib.SENT_NO_PAD) | (_lib.SENT_U16 if u16 else 0)
     p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc),
-                       pad_id, 0 if pad else _lib.SENT_NO_PAD, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
-                       None if query is None else query.data_ptr())
+                       pad_id, flags, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
+                       None if query is None else query.data_ptr(), K, 0)
     cs = batch.c_struct()
     if os.environ.get("GTOK_NO_LANE_SORT") != "1" and batch.graph_ids is None \
             and lib().gtok_sent_kernel_name(ctypes.byref(cs), ctypes.byref(p)) == b"sent_lane_kernel":
@@ -305,14 +322,16 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
             cs = sb.c_struct()
     check(lib().gtok_sent(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)),
           "gtok_sent")
-    return ids, ln
+    if K > 1:
+        return ids.view(K, G, ld), ln.view(K, G)
+    return ids.view(G, ld), ln.view(G)
 
 
 def sent_kernel_name(batch: GraphBatch, max_num_nodes: int, max_len: int, labeled: bool = False, num_node_types: int = 0,
-                     num_edge_types: int = 0, remap_zinc: bool = False) -> str:
+                     num_edge_types: int = 0, remap_zinc: bool = False, epochs: int = 1) -> str:
     """Name of the kernel gtok_sent() picks for this batch (for profiles and bench labels)."""
     p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc), SENT_PAD,
-                       0, 0, 0, 0, None)
+                       0, 0, 0, 0, None, max(1, int(epochs)), 0)
     cs = batch.c_struct()
     return lib().gtok_sent_kernel_name(ctypes.byref(cs), ctypes.byref(p)).decode()
 
@@ -412,33 +431,66 @@ def pack_rows(ids: torch.Tensor, ln: torch.Tensor, row_ptr: Optional[torch.Tenso
     return packed, row_ptr
 
 
-def unpack_rows(packed: torch.Tensor, row_ptr: torch.Tensor, ln: torch.Tensor, ld: int, pad_id: int,
-                segment_rows: int = 0, segment_stride: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """packed rows -> [rows, ld] int32 slab with pad_id behind every row (gtok_unpack_rows).  segment_rows /
-    segment_stride: the packed buffer is the concatenation of per-rank buffers (see include/gtok.h)."""
+def pack_rows_u16(ids16: torch.Tensor, ln: torch.Tensor, row_ptr: Optional[torch.Tensor] = None, elem_bytes: int = 2,
+                  capacity: Optional[int] = None, align: int = ROW_ALIGN, check_status: bool = True):
+    """pack_rows reading a 16-bit slab (ops.sent(..., u16=True)): -> (packed, row_ptr) with int16, int32 or int64 storage
+    (elem_bytes 2 / 4 / 8; 8 = the dtype the reference's token tensors have: the packed buffer can leave for the host as
+    it is).  check_status=False: (packed, row_ptr, status) and no host read."""
+    _need_gpu(ids16, "pack_rows_u16")
+    if ids16.dtype != torch.int16 or ids16.dim() != 2 or not ids16.is_contiguous() or ln.dtype != torch.int32:
+        raise ValueError("pack_rows_u16 expects a contiguous int16 [rows, ld] slab and int32 lengths")
+    if elem_bytes not in (2, 4, 8):
+        raise ValueError("elem_bytes must be 2, 4 or 8")
+    dev, (rows, ld) = ids16.device, ids16.shape
+    if int(ln.numel()) != rows:
+        raise ValueError("pack_rows_u16: one length per row")
+    if row_ptr is None:
+        row_ptr = row_offsets(ln, ld, align)
+    cap = int(row_ptr[-1]) if capacity is None else int(capacity)
+    packed = torch.empty(max(cap, 1), dtype={2: torch.int16, 4: torch.int32, 8: torch.int64}[elem_bytes], device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().gtok_pack_rows_u16(ids16.data_ptr(), ld, ln.data_ptr(), rows, row_ptr.data_ptr(), elem_bytes, packed.data_ptr(),
+                                   cap, status.data_ptr(), _stream(dev)), "gtok_pack_rows_u16")
+    if not check_status:
+        return packed, row_ptr, status
+    if int(status.item()) & 2:
+        raise _lib.GtokError(f"pack_rows_u16: capacity {cap} is too small for these rows")
+    return packed, row_ptr
+
+
+def unpack_rows(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: torch.Tensor, ld: int, pad_id: int,
+                segment_rows: int = 0, segment_stride: int = 0, out: Optional[torch.Tensor] = None,
+                status: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """packed rows -> [rows, ld] int32 slab with pad_id behind every row (gtok_unpack_rows_checked).  segment_rows /
+    segment_stride: the packed buffer is the concatenation of per-rank buffers (see include/gtok.h).  row_ptr=None: the
+    strided form - `packed` is itself a [rows, ld] slab of 16- or 32-bit ids (ops.sent(..., u16=True)), widened in place.
+    Rows that would end beyond their segment or the buffer come out as all pad; `status` (int32 [1], zeroed by the
+    caller) gets bit 1 then."""
     _need_gpu(packed, "unpack_rows")
     dev, rows = packed.device, int(ln.numel())
     eb = packed.element_size()
     if eb not in (2, 4):
         raise ValueError("unpack_rows expects int16 or int32 storage")
     ids = torch.empty((rows, ld), dtype=torch.int32, device=dev) if out is None else out
-    check(lib().gtok_unpack_rows(packed.data_ptr(), eb, row_ptr.data_ptr(), ln.data_ptr(), rows, int(segment_rows),
-                                 int(segment_stride), int(pad_id), ids.data_ptr(), int(ld), _stream(dev)), "gtok_unpack_rows")
+    check(lib().gtok_unpack_rows_checked(packed.data_ptr(), eb, None if row_ptr is None else row_ptr.data_ptr(), ln.data_ptr(), rows,
+                                         int(segment_rows), int(segment_stride), int(packed.numel()), int(pad_id), ids.data_ptr(), int(ld),
+                                         None if status is None else status.data_ptr(), _stream(dev)), "gtok_unpack_rows")
     return ids
 
 
-def collate_packed(packed: torch.Tensor, row_ptr: torch.Tensor, ln: torch.Tensor, ld: int, index: torch.Tensor,
+def collate_packed(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: torch.Tensor, ld: int, index: torch.Tensor,
                    pad_id: int, out_ld: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """ops.collate over the packed form: rows `index` -> (X int64 [B, out_ld], attn bool [B, out_ld])."""
+    """ops.collate over the packed form: rows `index` -> (X int64 [B, out_ld], attn bool [B, out_ld]).  row_ptr=None: the
+    strided form - `packed` is a [rows, ld] slab of 16- or 32-bit ids read in place (ops.sent(..., u16=True))."""
     _need_gpu(packed, "collate_packed")
     dev = packed.device
     index = index.to(dev, dtype=torch.int64).contiguous()
     B = int(index.numel())
     X = torch.empty((B, out_ld), dtype=torch.int64, device=dev)
     A = torch.empty((B, out_ld), dtype=torch.bool, device=dev)
-    check(lib().gtok_collate_packed(packed.data_ptr(), packed.element_size(), row_ptr.data_ptr(), ln.data_ptr(), int(ld),
-                                    index.data_ptr(), B, int(pad_id), X.data_ptr(), A.data_ptr(), int(out_ld), _stream(dev)),
-          "gtok_collate_packed")
+    check(lib().gtok_collate_packed(packed.data_ptr(), packed.element_size(), None if row_ptr is None else row_ptr.data_ptr(),
+                                    ln.data_ptr(), int(ld), index.data_ptr(), B, int(pad_id), X.data_ptr(), A.data_ptr(), int(out_ld),
+                                    _stream(dev)), "gtok_collate_packed")
     return X, A
 
 

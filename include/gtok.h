@@ -221,6 +221,13 @@ int gtok_text_to_ids(const uint8_t *bytes, const int64_t *text_ptr,
 #define GTOK_SENT_NO_PAD 1 /* rows are only guaranteed up to out_len[g] (rounded up to a multiple of 16 ids); the pad tails -
                               56 % of a ZINC slab - may be left unwritten.  For callers that read rows through out_len
                               anyway (gtok_collate pads per batch, as both reference collates do).                  */
+#define GTOK_SENT_U16 2    /* out_ids points at uint16_t storage: a [rows, ld] slab of 16-bit ids (ld still counts ids).  Every
+                              SENT id fits (gtok_sent checks the id space and pad_id against 65535): the walk kernels hold
+                              tokens 16 bits each anyway, so the rows leave as they are - half the bytes of the int32 slab,
+                              no unpacking.  The reference never materialises a padded corpus slab (it pads per batch,
+                              trainer/train_agtt.py:276-302); readers: gtok_collate_packed / gtok_unpack_rows with
+                              row_ptr == NULL (the slab read in place) and gtok_pack_rows_u16.  The int32 slab stays the
+                              documented default.                                                                   */
 
 typedef struct gtok_sent_params {
   int32_t max_num_nodes;  /* tokenizer.set_num_nodes()                      */
@@ -236,9 +243,16 @@ typedef struct gtok_sent_params {
   int64_t graph_base;     /* global index of graph 0 (shard-invariant RNG)  */
   const int32_t *query;   /* NULL, or [G,2] (query_u, query_v): appends
                              idx_off+N, idx_off+u, idx_off+v after the trail */
+  int32_t epoch_count;    /* K epochs in ONE launch (0 and 1 both mean one): epoch slice e = 0..K-1 holds the trails of
+                             epoch `epoch + e` - out_ids is [K, G, ld], out_len [K, G], `query` is shared.  The trainer
+                             re-tokenizes the same split every epoch (trainer/train_agtt.py:246-250, epoch loop :676-680)
+                             and a trail is a pure function of (seed, epoch, graph_base + g): K epochs of a small split
+                             fill the chip where one epoch cannot (ABI v4).                                        */
+  int32_t reserved;       /* must be 0                                      */
 } gtok_sent_params;
 
-/* SENT trail walk -> ids.  out_len[g] = min(trail, max_len) (+3 if query). */
+/* SENT trail walk -> ids.  out_len[g] = min(trail, max_len) (+3 if query).  With epoch_count = K > 1 the result is
+ * that of K calls with epoch, epoch + 1, ... written to consecutive [G, ld] slices.                               */
 int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids,
               int32_t ld, int32_t *out_len, void *stream);
 
@@ -293,7 +307,15 @@ int gtok_parse_graph_text(const uint8_t *bytes, const int64_t *text_ptr, int32_t
  * gives - rows [s * segment_rows, (s + 1) * segment_rows) live in segment s: row r starts at
  * s * segment_stride + row_ptr[r] - row_ptr[s * segment_rows], with row_ptr = gtok_row_offsets over the gathered
  * lengths (same align).
- * gtok_collate_packed: gtok_collate reading the packed form (unsegmented) instead of the slab.                    */
+ * gtok_collate_packed: gtok_collate reading the packed form (unsegmented) instead of the slab.
+ * row_ptr == NULL (gtok_unpack_rows with segment_rows == 0, gtok_collate_packed): the STRIDED form - row r starts at
+ * element r * ld of `packed` - i.e. a GTOK_SENT_U16 slab (or any [rows, ld] slab of 16- / 32-bit ids) read in place.
+ * gtok_unpack_rows never reads beyond a segment: with segment_rows > 0 a row whose ids would end past segment_stride
+ * (a rank whose rows did not fit the caller-given capacity skipped them in gtok_pack_rows, status bit 1) is written as
+ * all pad and, when `status` is not NULL, flagged there (bit 1) - gtok_unpack_rows_checked is gtok_unpack_rows with that
+ * status word and the total number of elements `packed` holds (0 = unknown) as further bounds.
+ * gtok_pack_rows_u16: gtok_pack_rows reading a GTOK_SENT_U16 slab; elem_bytes 2, 4 or 8 (8: int64 ids, the dtype the
+ * reference's tensors have - the D2H copy behind TokenizedGraphDataset.__getitem__ needs no widening pass).           */
 int gtok_row_offsets(const int32_t *len, int64_t num_rows, int32_t ld, int32_t align, int64_t *row_ptr, void *stream);
 int gtok_pack_rows(const int32_t *ids, int32_t ld, const int32_t *len, int64_t num_rows, const int64_t *row_ptr,
                    int32_t elem_bytes, void *packed, int64_t capacity, int32_t *status, void *stream);
@@ -303,6 +325,11 @@ int gtok_unpack_rows(const void *packed, int32_t elem_bytes, const int64_t *row_
 int gtok_collate_packed(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
                         int32_t ld, const int64_t *index, int32_t batch, int32_t pad_id, int64_t *out_x,
                         uint8_t *out_attn, int32_t out_ld, void *stream);
+int gtok_unpack_rows_checked(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
+                             int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int64_t packed_elems,
+                             int32_t pad_id, int32_t *out_ids, int32_t ld, int32_t *status, void *stream);
+int gtok_pack_rows_u16(const uint16_t *ids16, int32_t ld, const int32_t *len, int64_t num_rows, const int64_t *row_ptr,
+                       int32_t elem_bytes, void *packed, int64_t capacity, int32_t *status, void *stream);
 
 /* Rows of ids -> TEXT: the strings ZINCTokenizationDataset.__getitem__ returns (zinc_dataset_indexbase.py:143-227: the
  * trainer builds its vocab from them, trainer/train_ibtt.py:229-235, :361-372) rendered for a whole split at once.  Row
@@ -361,8 +388,9 @@ int gtok_vocab_stats_text(const uint8_t *bytes, const int64_t *text_ptr, int32_t
  * k is the k-th node the trail visited.  Per row: num_nodes, num_edges, the edges in stream order - edge_a =
  * the node the edge was written from, edge_b = the other end, edge_type = its type token minus the edge offset
  * (-1 unlabelled) - in [rows, edge_cap] arrays, node types in [rows, node_cap], and status: 0 complete (EOS
- * reached), 1 malformed, 2 a capacity exceeded (counts are still right), 3 well-formed but cut before EOS (a row
- * truncated at max_len).  The reverse of the spec in DESIGN.md section 5; with the trail's visit order it gives back
+ * reached), 1 malformed, 2 a capacity exceeded (the row is still read to its end: num_nodes / num_edges are those of
+ * the whole row, entries beyond a capacity are dropped - edge_cap = node_cap = 0 is a count-only pass), 3 well-formed but
+ * cut before EOS (a row truncated at max_len).  The reverse of the spec in DESIGN.md section 5; with the trail's visit order it gives back
  * the input graph exactly (oracle_sent_roundtrip checks that for every row).                                      */
 int gtok_sent_decode(const int32_t *ids, int32_t ld, const int32_t *len, int32_t num_rows,
                      int32_t max_num_nodes, int32_t labeled, int32_t num_node_types,
@@ -381,8 +409,9 @@ const char *gtok_sent_kernel_name(const gtok_csr *g, const gtok_sent_params *p);
 const char *gtok_ibtt_zinc_kernel_name(const gtok_csr *g);
 
 /* ABI version (GTOK_ABI_VERSION of the header the library was built from: 2 since gtok_csr carries the optional
- * mirrors - a binding checks it before passing structs; 3 adds the packed-row entry points) and build target string ("gfx950").                     */
-#define GTOK_ABI_VERSION 3
+ * mirrors - a binding checks it before passing structs; 3 adds the packed-row entry points; 4: gtok_sent_params carries
+ * epoch_count, GTOK_SENT_U16, the strided / checked packed-row readers) and build target string ("gfx950").                     */
+#define GTOK_ABI_VERSION 4
 int gtok_version(void);
 const char *gtok_target(void);
 
