@@ -145,9 +145,10 @@ def boundary_section(d, G, dev, max_nodes, max_len):
         t1, _ = clock(per_item_loop)                           # epoch 0: includes ingestion + the first launch
         t2, ntok = clock(per_item_loop)                        # epoch 1: steady state
         out["agtt_zero_edit_tokenizer_call"] = dict(items_per_sec=round(G / t2, 1), first_epoch_items_per_sec=round(G / t1, 1),
-                                                    launches_per_epoch=tok.launches / 2, tokens_per_sec=round(ntok / t2, 1), items=G,
+                                                    launches_per_epoch=tok.launches / 2, epochs_per_launch=tok.epochs_for(G),
+                                                    tokens_per_sec=round(ntok / t2, 1), items=G,
                                                     note="for i: tokens = tokenizer(pyg_dataset[i]) with this package's ZINCDatasetForAutoGraph: "
-                                                         "one gtok_sent launch + one packed D2H copy per epoch, rows are slices of it")
+                                                         "one gtok_sent launch per K epochs (16-bit rows) + one packed int64 D2H copy per epoch, rows are slices of it")
         S = min(G, 2000)
         loose = [pyg[i] for i in range(S)]                     # objects the datasets did not hand out: one launch per call
         t, _ = clock(lambda: [tok(x) for x in loose])
@@ -165,6 +166,24 @@ def boundary_section(d, G, dev, max_nodes, max_len):
         t, _ = clock(getitem_loop)
         out["agtt_dataset_getitem"] = dict(items_per_sec=round(G / t, 1), items=G,
                                            note="agtt.TokenizedGraphDataset.__getitem__ over a whole epoch (fused remap; incl. the packed D2H copy)")
+
+        # the reference's loader construction (train_agtt.py:599-607) unchanged over the one-line-swap class: the stock DataLoader
+        # fetches whole batches through __getitems__ (collated on the device, collate_fn passes them through)
+        from torch.utils.data import DataLoader
+
+        def loader_epoch(dl):
+            n = 0
+            for X, A, Y, data_list in dl:
+                n += X.shape[0]
+            return n
+        for shuffle in (True, False):
+            dl = DataLoader(ds, batch_size=128, shuffle=shuffle, num_workers=0, collate_fn=gtok.agtt.collate_fn)
+            clock(lambda: loader_epoch(dl))
+            t, n = clock(lambda: loader_epoch(dl))
+            out["agtt_dataloader_shuffle" if shuffle else "agtt_dataloader"] = dict(
+                items_per_sec=round(n / t, 1), batch_size=128, items=n, shuffle=shuffle,
+                note="for X, A, Y, data_list in DataLoader(agtt.TokenizedGraphDataset, batch_size=128, shuffle, num_workers=0, collate_fn=agtt.collate_fn): "
+                     "batch-level fetch (__getitems__ -> gtok_collate_packed on the 16-bit slab), data_list is a lazy sequence")
 
         def batches(with_data, bs=128):
             n = 0
@@ -191,6 +210,13 @@ def boundary_section(d, G, dev, max_nodes, max_len):
         out["ibtt_token_dataset_init"] = dict(items_per_sec=round(G / t_td, 1), seconds=round(t_td, 3), items=G,
                                               note="TokenDataset(examples, vocab, max_len): pack texts + gtok_text_to_ids + one packed host copy of the rows")
         out["ibtt_examples_to_token_dataset_seconds"] = round(t_str + t_td, 3)
+        pad_id = vocab["<pad>"]
+        dl = DataLoader(td, batch_size=128, shuffle=True, num_workers=0, collate_fn=lambda b: gdl.collate(b, pad_id))
+        clock(lambda: sum(X.shape[0] for X, A, Y in dl))
+        t, n = clock(lambda: sum(X.shape[0] for X, A, Y in dl))
+        out["ibtt_dataloader"] = dict(items_per_sec=round(n / t, 1), batch_size=128, items=n,
+                                      note="for X, attn, Y in DataLoader(TokenDataset, batch_size=128, shuffle=True, collate_fn=lambda b: collate(b, pad_id)) "
+                                           "(train_ibtt.py:399-402; num_workers=0 here): batches gathered from the packed host buffer (__getitems__)")
         S = min(G, 5000)
         zds._bulk = False; zds._texts = None
         t_py, _ = clock(lambda: [zds[i] for i in range(S)])
@@ -201,6 +227,28 @@ def boundary_section(d, G, dev, max_nodes, max_len):
         out["ibtt_tokenize_csr"] = dict(first_call_graphs_per_sec=round(G / t1, 1), resident_graphs_per_sec=round(G / t2, 1), graphs=G,
                                         note="ZINCTokenizationDataset.tokenize(vocab): CSR -> ids, no strings (first call includes ingestion)")
     return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves - fresh child processes, started BEFORE
+    this process has touched the GPU (nothing above this line initialises HIP), one per GPU, rendezvous on 127.0.0.1 -
+    relay rank 0's JSON line and exit non-zero if any rank failed."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
 
 
 def main():
@@ -229,7 +277,14 @@ def main():
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 1 s back-to-back leg")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary section (call-site throughput through the Dataset classes)")
     ap.add_argument("--no-unpadded", action="store_true", help="skip the GTOK_SENT_NO_PAD leg (profiling runs: one launch flavour per kernel name)")
+    ap.add_argument("--epochs-per-launch", type=int, default=None,
+                    help="epochs (steps) one gtok_sent launch carries (gtok_sent_params.epoch_count). Default: 1 for corpora that fill "
+                         "the chip on their own (zinc_full, synth_*), 24 for zinc_subset - the trainer re-tokenizes its split "
+                         "every epoch and trails depend on (seed, epoch, graph) only")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.dup2(real_stdout, 1)
+        return spawn_ranks(args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -273,57 +328,103 @@ def main():
         ld = gtok.dist.all_reduce_max_int(ld, dev)
     else:
         ld = gtok.dist.all_reduce_max_int(safe_ld, dev)
-    ids = torch.empty((G, ld), dtype=torch.int32, device=dev)
-    lens = [torch.empty((G,), dtype=torch.int32, device=dev) for _ in range(args.steps)]
-    scratch_len = torch.empty((G,), dtype=torch.int32, device=dev)
+    # epochs per launch: a step is one epoch pass; one gtok_sent launch may carry E of them (gtok_sent_params.epoch_count: the
+    # trainer re-tokenizes the same split every epoch, trainer/train_agtt.py:246-250, :676-680, and a trail is a pure function
+    # of (seed, epoch, graph)) - a split that cannot fill the chip on its own (zinc_subset: 12 k molecules) is launched 24 epochs
+    # at a time.  K steps = ceil(K / E) launches, the last one with the remaining epochs.
+    E = args.epochs_per_launch or (24 if args.workload == "zinc_subset" else 1)
+    E = max(1, min(E, args.steps))
+    n_launch = -(-args.steps // E)
+    ids = torch.empty((E * G, ld), dtype=torch.int32, device=dev)
+    lens_all = torch.empty((n_launch * E, G), dtype=torch.int32, device=dev)
+    lens = [lens_all[k] for k in range(args.steps)]
+    scratch_len = torch.empty((E * G,), dtype=torch.int32, device=dev)
 
-    def step(k, ln):
-        gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(ids, ln), pad=args.rows == "padded", **kw)
+    def step(k, ln):          # ONE epoch in one launch (secondary legs and the end-of-run parity check)
+        gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(ids[:G], ln.view(-1)[:G]), pad=args.rows == "padded", **kw)
 
-    # steady state first: >= 1 s of back-to-back launches (clocks, L2 / MALL state of a slab rewritten in place), one event pair
-    # around all of them - reported as `sustained`.  It runs BEFORE the K timed steps, not after them: a device that has been
-    # idle through the CSR build takes longer than W + K launches (~2 ms) to reach its working clocks, and the K-step figure
-    # is meant to be the rate an epoch loop sees (--no-sustained gives the cold figure: ~7 % slower on zinc_full)
+    def launch(j, ln, count=E, first=None, pad=None, u16=False, out_ids=None):
+        """epochs first .. first + count - 1 (default: launch j of the timed region) in one gtok_sent call"""
+        o = ids if out_ids is None else out_ids
+        gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=j * E if first is None else first, ld=ld,
+                      out=(o[:count * G], ln.view(-1)[:count * G]), pad=(args.rows == "padded") if pad is None else pad, epochs=count, u16=u16, **kw)
+
+    def timed_launches(first_epoch):
+        """the K steps: n_launch calls, epochs first_epoch .. first_epoch + K - 1, lengths of step k in lens_all[k]"""
+        def f(j):
+            cnt = min(E, args.steps - j * E)
+            launch(j, lens_all[j * E:j * E + cnt], count=cnt, first=first_epoch + j * E)
+        return f
+
+    # the requested protocol first, from a cold start (the device idled through the CSR build): W warm-up steps, then the K
+    # steps - reported as `cold_start`; the headline below is measured the same way AFTER the >= 1 s leg (working clocks)
+    for w in range(-(-args.warmup // E)):
+        launch(w, scratch_len)
+    cold_wall, cold_ms = timed_loop(timed_launches(args.warmup), n_launch, multi, per_launch_events=False)
+    cold = dict(ms_per_step=round(cold_wall / args.steps * 1e3, 4), kernel_ms_per_step=round(float(np.sum(cold_ms)) / args.steps, 4),
+                graphs_per_sec=round(world * G * args.steps / cold_wall, 1),
+                note="the same W warm-up + K timed steps right after the CSR build, before the sustained leg (the r01 / r02 protocol)")
+    # steady state: >= 1 s of back-to-back launches (clocks, L2 / MALL state of a slab rewritten in place), one event pair
+    # around all of them - reported as `sustained`.  It runs BEFORE the K timed steps of the headline, not after them: a device
+    # that has been idle through the CSR build takes longer than W + K launches (~2 ms) to reach its working clocks, and the
+    # K-step figure is meant to be the rate an epoch loop sees
     sustained = None
     if not args.no_sustained:
         for w in range(3):
-            step(w, scratch_len)
-        _, est = timed_loop(lambda k: step(k, scratch_len), 5, multi, per_launch_events=False)
-        n_s = max(args.steps, min(200000, int(1.2 / max(float(est[0]) * 1e-3, 2e-5))))
+            launch(w, scratch_len)
+        _, est = timed_loop(lambda k: launch(k, scratch_len), 5, multi, per_launch_events=False)
+        n_s = max(n_launch, min(200000, int(1.2 / max(float(est[0]) * 1e-3, 2e-5))))
         n_s = int(gtok.dist.all_reduce_max_int(n_s, dev)) if multi else n_s
-        _, sm = timed_loop(lambda k: step(k, scratch_len), n_s, multi, per_launch_events=False)
-        sustained = dict(launches=n_s, seconds=round(float(sm[0]) * n_s * 1e-3, 3), ms_per_step=round(float(sm[0]), 4),
-                         graphs_per_sec=round(G / float(sm[0]) * 1e3, 1), order="before the K timed steps")
-        log(f"[bench] sustained leg done: {float(sm[0]):.4f} ms per step over {n_s} launches")
-    for w in range(args.warmup):
-        step(w, scratch_len)
-    # the timed region: exactly K steps, barrier + synchronize on both sides, one HIP event pair around the K launches
-    # (roofline.kernel_ms = elapsed / K: launch-to-launch, the ~1.5 us kernel boundary included)
-    wall, kern_ms = timed_loop(lambda k: step(args.warmup + k, lens[k]), args.steps, multi, per_launch_events=False)
-    # cross-check outside the timed region: the same K steps with an event pair around every launch (the kernel alone;
+        _, sm = timed_loop(lambda k: launch(k, scratch_len), n_s, multi, per_launch_events=False)
+        sustained = dict(launches=n_s, epochs_per_launch=E, seconds=round(float(sm[0]) * n_s * 1e-3, 3), ms_per_step=round(float(sm[0]) / E, 5),
+                         graphs_per_sec=round(G * E / float(sm[0]) * 1e3, 1), order="before the K timed steps")
+        log(f"[bench] sustained leg done: {float(sm[0]) / E:.5f} ms per step over {n_s} launches of {E} epochs")
+    for w in range(-(-args.warmup // E)):
+        launch(w, scratch_len)
+    # the timed region: exactly K steps (ceil(K / E) launches), barrier + synchronize on both sides, one HIP event pair around
+    # the launches (roofline.kernel_ms = elapsed / launches: launch-to-launch, the ~1.5 us kernel boundary included)
+    wall, kern_ms = timed_loop(timed_launches(args.warmup), n_launch, multi, per_launch_events=False)
+    # cross-check outside the timed region: the same launches with an event pair around every one (the kernel alone;
     # what rocprofv3 --kernel-trace --stats reports for it)
-    _, kern_each_ms = timed_loop(lambda k: step(args.warmup + k, lens[k]), args.steps, multi)
+    _, kern_each_ms = timed_loop(timed_launches(args.warmup), n_launch, multi)
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     # beside the headline: the same steps with GTOK_SENT_NO_PAD (rows written up to their length only - what
     # TokenizedGraphDataset uses, its readers go through `len`); not the headline because the C ABI's documented output is the padded slab
-    nopad_ms = ragged = None
+    nopad_ms = ragged = u16_ms = u16p_ms = ragged16 = None
     if zinc and not args.no_unpadded:
-        _, npm = timed_loop(lambda k: gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=args.warmup + k, ld=ld, out=(ids, scratch_len), pad=False, **kw),
-                            args.steps, multi, per_launch_events=False)
-        nopad_ms = float(np.mean(npm))
-        # ragged rows: tokens only (no pad tails) + one pass that packs them back to back (row_ptr + ids, 4 bytes each) -
-        # the form gtok_collate_packed / the compact all-gather / the D2H copy of an epoch read
+        per_step = lambda ms: float(np.sum(ms)) / (n_launch * E)
+        _, npm = timed_loop(lambda j: launch(j, scratch_len, pad=False), n_launch, multi, per_launch_events=False)
+        nopad_ms = per_step(npm)
+        # 16-bit rows (GTOK_SENT_U16): the walk kernels hold tokens 16 bits each, the rows leave as they are - what
+        # TokenizedGraphDataset, EpochRows, gtok_collate_packed (row_ptr NULL) and the compact all-gather read
+        ids16 = torch.empty((E * G, ld), dtype=torch.int16, device=dev)
+        launch(0, scratch_len, pad=False, u16=True, out_ids=ids16)
+        _, um = timed_loop(lambda j: launch(j, scratch_len, pad=False, u16=True, out_ids=ids16), n_launch, multi, per_launch_events=False)
+        u16_ms = per_step(um)
+        _, upm = timed_loop(lambda j: launch(j, scratch_len, pad=True, u16=True, out_ids=ids16), n_launch, multi, per_launch_events=False)
+        u16p_ms = per_step(upm)
+        # ragged rows: tokens only (no pad tails) + one pass that packs them back to back (row_ptr + ids) - the form the compact
+        # all-gather and the D2H copy of an epoch move; from the int32 slab (round 3) and from the 16-bit slab
         def ragged_step(k):
-            gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=args.warmup + k, ld=ld, out=(ids, scratch_len), pad=False, **kw)
+            launch(k, scratch_len, pad=False)
             ptr = gtok.ops.row_offsets(scratch_len, ld)
-            return gtok.ops.pack_rows(ids, scratch_len, ptr, elem_bytes=4, capacity=G * ld, check_status=False)
+            return gtok.ops.pack_rows(ids, scratch_len, ptr, elem_bytes=4, capacity=E * G * ld, check_status=False)
         ragged_step(0)
-        _, rgm = timed_loop(ragged_step, args.steps, multi, per_launch_events=False)
-        ragged = float(np.mean(rgm))
-    log(f"[bench] timed region done: {wall / args.steps * 1e3:.4f} ms per step")
+        _, rgm = timed_loop(ragged_step, n_launch, multi, per_launch_events=False)
+        ragged = per_step(rgm)
+
+        def ragged16_step(k):
+            launch(k, scratch_len, pad=False, u16=True, out_ids=ids16)
+            ptr = gtok.ops.row_offsets(scratch_len, ld)
+            return gtok.ops.pack_rows_u16(ids16, scratch_len, ptr, elem_bytes=2, capacity=E * G * ld, check_status=False)
+        ragged16_step(0)
+        _, rgm = timed_loop(ragged16_step, n_launch, multi, per_launch_events=False)
+        ragged16 = per_step(rgm)
+        del ids16
+    log(f"[bench] timed region done: {wall / args.steps * 1e3:.5f} ms per step ({n_launch} launches of {E} epochs)")
     # one-off layout steps ops.sent did inside the warm-up (like the CSR build: once per resident batch, never per epoch):
     # their time and bytes, re-measured on a fresh copy of the batch, and the kernel WITHOUT any of them (what a C-ABI
     # caller that passes only the int32 CSR gets)
@@ -358,9 +459,10 @@ def main():
         os.environ.update(GTOK_NO_LANE_SORT="1", GTOK_NO_PACK8="1", GTOK_NO_ADJBITS="1")
         try:
             fb = fresh()
+            one = (ids[:G], scratch_len[:G])
             for w in range(args.warmup):
-                gtok.ops.sent(fb, max_nodes, max_len, seed=0, epoch=w, ld=ld, out=(ids, scratch_len), **kw)
-            _, nm = timed_loop(lambda k: gtok.ops.sent(fb, max_nodes, max_len, seed=0, epoch=args.warmup + k, ld=ld, out=(ids, scratch_len), **kw),
+                gtok.ops.sent(fb, max_nodes, max_len, seed=0, epoch=w, ld=ld, out=one, **kw)
+            _, nm = timed_loop(lambda k: gtok.ops.sent(fb, max_nodes, max_len, seed=0, epoch=args.warmup + k, ld=ld, out=one, **kw),
                                args.steps, multi, per_launch_events=False)
             layout["without_any_mirror"] = dict(kernel=gtok.ops.sent_kernel_name(fb, max_nodes, max_len, labeled=zinc, num_node_types=ntypes,
                                                                                  num_edge_types=etypes, remap_zinc=zinc),
@@ -374,7 +476,7 @@ def main():
                     os.environ[k] = v
         step(args.warmup, scratch_len)      # back on the resident layouts for the legs below
 
-    all_len = torch.stack(lens)
+    all_len = lens_all[:args.steps]
     if int(all_len.max().item()) > ld:
         raise SystemExit(f"slab width {ld} too narrow for a timed step (max len {int(all_len.max())}): rerun with --ld safe")
     tok_total = torch.tensor([float(all_len.sum().item())], dtype=torch.float64, device=dev)
@@ -387,17 +489,21 @@ def main():
     # roofline of the dominant kernel (sent_kernel<1,true>): algorithmic bytes / launch duration
     read_b = host.algorithmic_read_bytes(ibtt=False, labeled=zinc)
     write_b = 4.0 * tokens_per_step_rank + 4.0 * G
+    # per LAUNCH: the figure of SURVEY section 8d per graph x the graphs one launch processes (E epochs of the corpus: every
+    # (unit, epoch) pair stages its CSR chunk and writes its rows) over the average launch duration
+    epl = args.steps / n_launch                       # epochs per launch, averaged over the timed region (= E when E divides K)
+    read_b, write_b = read_b * epl, write_b * epl
     kern_s = float(np.mean(kern_ms)) * 1e-3
     achieved = (read_b + write_b) / kern_s / 1e9
     kname = gtok.ops.sent_kernel_name(batch, max_nodes, max_len, labeled=zinc, num_node_types=ntypes, num_edge_types=etypes,
-                                      remap_zinc=zinc) + ("<labelled>" if zinc else "<unlabelled>")
+                                      remap_zinc=zinc, epochs=E) + ("<labelled>" if zinc else "<unlabelled>")
     # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass, and counter
     # collection perturbs the timing), i.e. from an EARLIER run of this same command: profiles/pmc_traffic.json records
     # the kernel and the commit it was measured at, and the figure is dropped when the kernel chosen now differs.
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
-        rec = json.load(open(tpath)).get(f"sent:{args.workload}:{G}:{args.ld}")
+        rec = json.load(open(tpath)).get(f"sent:{args.workload}:{G}:{args.ld}" + (f":x{E}" if E > 1 else ""))
         if rec and rec.get("kernel_label", kname) == kname:
             traffic = rec["hbm_bytes_per_launch"]
             traffic_source = f"{rec.get('source', 'profiles/pmc_traffic.json')} (rocprofv3 --pmc, measured at commit {rec.get('commit', 'unknown')}, not in this run)"
@@ -407,31 +513,38 @@ def main():
     trunc = None
     if not zinc:
         step(args.warmup, scratch_len)
-        dec = gtok.ops.sent_decode(ids, scratch_len, max_nodes, False, 0, edge_cap=4, node_cap=4)
+        # (count-only decode: capacities of 0 - the row is read to its end; round 3 passed capacities of 4 to a decoder that
+        # stopped at the first entry that did not fit and reported ~5 nodes per walk where the walks reach ~68)
+        dec = gtok.ops.sent_decode(ids[:G], scratch_len[:G], max_nodes, False, 0, edge_cap=0, node_cap=0)
         vis_n = dec["num_nodes"].to(torch.float64)
         nc_t = (batch.node_ptr[1:] - batch.node_ptr[:-1]).to(torch.float64).clamp(min=1)
         ec_t = (batch.edge_ptr[1:] - batch.edge_ptr[:-1]).to(torch.float64)
-        need_read = float((4 * (vis_n + 1) + 4 * ec_t * (vis_n / nc_t).clamp(max=1.0)).sum().item())
+        need_read = float((4 * (vis_n + 1) + 4 * ec_t * (vis_n / nc_t).clamp(max=1.0)).sum().item()) * epl
         tb = need_read + write_b
         trunc = dict(bytes_per_launch=int(tb), achieved=round(tb / kern_s / 1e9, 2), frac=round(tb / kern_s / 1e9 / HBM_PEAK_GBS, 5),
-                     rows_cut=int((scratch_len >= max_len).sum().item()), avg_nodes_visited=round(float(vis_n.mean().item()), 2),
+                     rows_cut=int((scratch_len[:G] >= max_len).sum().item()), avg_nodes_visited=round(float(vis_n.mean().item()), 2),
                      note="4(k+1) + 4 E k/N + 4L + 4 with k = nodes the walk reached before max_len (estimate: entries in proportion)")
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(read_b + write_b), kernel_ms=round(kern_s * 1e3, 4),
                     kernel_ms_event_pair_per_launch=round(float(np.mean(kern_each_ms)), 4),
-                    padded_slab_bytes_per_launch=int(4 * G * ld))
+                    epochs_per_launch=E, launches=n_launch, kernel_ms_per_epoch=round(kern_s * 1e3 / epl, 5),
+                    padded_slab_bytes_per_launch=int(4 * G * ld * epl))
     if trunc is not None:
         roofline["truncation_aware"] = trunc
 
     out = dict(metric="graphs_tokenized_per_sec", value=round(value, 1), unit="graphs/s", n_gpus=world,
-               steps=args.steps, warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 4),
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 5),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
                tokens_per_sec=round(tokens_per_sec, 1),
                config=dict(workload=f"{args.workload}: {wl['desc']}" + ("" if args.rows == "padded" else " [GTOK_SENT_NO_PAD rows]"), graphs_per_gpu=G, max_len=max_len,
                            slab_width=ld, slab_width_mode=args.ld, avg_tokens_per_graph=round(tokens_per_step_rank / G, 2),
-                           parallelism=f"graph-sharded x{world}, no data-path collective"),
-               roofline=roofline)
+                           parallelism=f"graph-sharded x{world}, no data-path collective",
+                           epochs_per_launch=E, launches_in_timed_region=n_launch,
+                           methodology="a step = one epoch pass; K steps = ceil(K / E) gtok_sent launches of E epochs; since round 3 the >= 1 s "
+                                       "sustained leg runs BEFORE the K timed steps (working clocks) - `cold_start` is the same W + K protocol "
+                                       "right after the CSR build, comparable with the r01 / r02 records"),
+               roofline=roofline, cold_start=cold)
     # layout steps done once per resident batch by ops.sent (outside the timed region, like the CSR build): say which were used
     layouts = [n for n, on in (("byte mirror of rowptr/col", batch.rowptr8 is not None or (batch.lane_sorted is not None and batch.lane_sorted.rowptr8 is not None)),
                                ("copy reordered by expected walk length (graph_ids + unit table)", batch.lane_sorted is not None),
@@ -445,8 +558,14 @@ def main():
         out["unpadded_rows"] = dict(ms_per_step=round(nopad_ms, 4), graphs_per_sec=round(G / nopad_ms * 1e3, 1),
                                     note="GTOK_SENT_NO_PAD: tokens only, pad tails of the slab not written")
         out["ragged_rows"] = dict(ms_per_step=round(ragged, 4), graphs_per_sec=round(G / ragged * 1e3, 1),
-                                  note="GTOK_SENT_NO_PAD + gtok_row_offsets + gtok_pack_rows (int32): rows back to back behind row_ptr, "
-                                       "what gtok_collate_packed reads")
+                                  note="GTOK_SENT_NO_PAD + gtok_row_offsets + gtok_pack_rows (int32): rows back to back behind row_ptr "
+                                       "(the round-3 route to gtok_collate_packed / the compact exchange)")
+        out["u16_rows"] = dict(unpadded_ms_per_step=round(u16_ms, 4), unpadded_graphs_per_sec=round(G / u16_ms * 1e3, 1),
+                               padded_ms_per_step=round(u16p_ms, 4), padded_graphs_per_sec=round(G / u16p_ms * 1e3, 1),
+                               packed_ms_per_step=round(ragged16, 4),
+                               note="GTOK_SENT_U16: rows of 16-bit ids straight from the walk's token windows (no unpacking, half the bytes); "
+                                    "unpadded = + GTOK_SENT_NO_PAD: what TokenizedGraphDataset / gtok_collate_packed(row_ptr NULL) / EpochRows read in place, "
+                                    "no second pass; packed = + gtok_row_offsets + gtok_pack_rows_u16 (16-bit rows back to back: the compact all-gather's payload)")
 
     log("[bench] headline assembled; secondary legs follow")
     # IBTT serialiser on the same corpus (second half of the metric; outside the timed region)
@@ -555,12 +674,12 @@ def main():
     # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
     if multi:
         log("[bench] all-gather legs")
-        gtok.dist.gather_tokens(ids, lens[-1], world * G, 5, force=True)
+        gtok.dist.gather_tokens(ids[:G], lens[-1], world * G, 5, force=True)
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            gtok.dist.gather_tokens(ids, lens[-1], world * G, 5, force=True)
+            gtok.dist.gather_tokens(ids[:G], lens[-1], world * G, 5, force=True)
         torch.cuda.synchronize(); dist.barrier()
         ag = (time.perf_counter() - t0) / reps
         agt = torch.tensor([ag], dtype=torch.float64, device=dev)
@@ -581,50 +700,71 @@ def main():
         del whole
         gtok.ops.pack8(mine)
         kws = dict(kw, graph_base=lo)
-        sids = torch.empty((hi - lo, ld), dtype=torch.int32, device=dev)
-        sln = torch.empty((hi - lo,), dtype=torch.int32, device=dev)
-
+        # K epochs per launch (round 4): a rank's 31 k-molecule share cannot fill the chip for one epoch (0.065 ms against
+        # 0.076 ms for the whole corpus on one GPU), Es epochs of it can - and ONE exchange then carries Es epochs of rows.
+        # Rows leave the walk as 16-bit ids without padding; the compact exchange packs them as they are.  Each rank's
+        # buffer is [Es, per, ld] (epoch-major); the gathered slab is rank-major: epoch e of graph g sits at row
+        # ((g // per) * Es + e) * per + g % per - consumers index it (gtok_collate takes any row list).
+        Gs, per = hi - lo, -(-Gt // world)
+        Es = max(1, min(32, gtok.Graph2TrailTokenizer.EPOCH_WALKS // max(1, Gs))) if Gt % world == 0 else 1
+        if os.environ.get("GTOK_BENCH_STRONG_EPOCHS"):
+            Es = max(1, int(os.environ["GTOK_BENCH_STRONG_EPOCHS"]))
+        sids = torch.empty((Es * Gs, ld), dtype=torch.int16, device=dev)
+        sln = torch.empty((Es * Gs,), dtype=torch.int32, device=dev)
         gstats = {}
 
         def sstep(k, gather):
-            gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(sids, sln), **kws)
-            if gather == "padded":
-                return gtok.dist.gather_tokens(sids, sln, Gt, 5, force=True, stats=gstats.setdefault("padded", {}))
-            if gather == "compact":    # capacity = the first epoch's largest rank + 2 %: no size exchange, no host round trip
-                return gtok.dist.gather_tokens(sids, sln, Gt, 5, force=True, compact=True, capacity=gstats.get("cap"),
+            gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k * Es, ld=ld, out=(sids, sln), pad=False, epochs=Es, u16=True, **kws)
+            if gather == "padded":      # the 16-bit slab as it is (pad tails and all: they are not written, the bytes still travel)
+                return gtok.dist.gather_tokens(sids, sln, Gt * Es, 5, force=True, stats=gstats.setdefault("padded", {}))
+            if gather == "compact":    # capacity = the first launch's largest rank + 2 %: no size exchange, no host round trip
+                return gtok.dist.gather_tokens(sids, sln, Gt * Es, 5, force=True, compact=True, capacity=gstats.get("cap"),
                                                stats=gstats.setdefault("compact", {}))
         res = {}
+        n_sl = max(2, -(-args.steps // Es))
         for gather in (None, "padded", "compact"):
             if gather == "compact":
                 sstep(0, gather)                              # sized by an all-reduce once ...
                 gstats["cap"] = int(gstats["compact"]["capacity"] * 1.02) + 64      # ... then a fixed bound
-            for w in range(args.warmup):
+            for w in range(max(1, args.warmup // Es)):
                 sstep(w, gather)
-            swall, _ = timed_loop(lambda k: sstep(args.warmup + k, gather), args.steps, True)
+            swall, _ = timed_loop(lambda k: sstep(args.warmup + k, gather), n_sl, True)
             tm = torch.tensor([swall], dtype=torch.float64, device=dev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             res[gather] = float(tm.item())
         if int(sln.max().item()) > ld:
             raise SystemExit("strong-scaling leg: slab too narrow")
-        # the compact exchange must give the padded one's slab (checked on the last epoch's buffers)
+        # the compact exchange must give the padded one's rows (checked on the last launch's buffers, inside the row lengths:
+        # the 16-bit slab travels without its pad tails written)
         p_ids, p_ln = sstep(args.warmup, "padded")
         c_ids, c_ln = sstep(args.warmup, "compact")
-        same = bool(torch.equal(p_ids, c_ids) and torch.equal(p_ln, c_ln)) and int(gstats["compact"]["status"].item()) == 0
-        per_step = lambda t: round(t / args.steps * 1e3, 4)
+        inside = torch.arange(ld, device=dev)[None, :] < c_ln[:, None]
+        p_wide = p_ids.to(torch.int32) & 0xFFFF
+        same = bool(torch.equal(p_ln, c_ln) and torch.equal(torch.where(inside, p_wide, 0), torch.where(inside, c_ids, 0))
+                    and bool((c_ids[~inside] == 5).all())) and int(gstats["compact"]["status"].item()) == 0
+        epochs_timed = n_sl * Es
+        per_epoch = lambda t: round(t / epochs_timed * 1e3, 5)
         out["strong_scaling"] = dict(
-            workload=f"one {Gt}-graph corpus block-sharded x{world} (graphs_per_gpu {hi - lo}), kernel {gtok.ops.sent_kernel_name(mine, max_nodes, max_len, labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True)}",
-            tokenize_graphs_per_sec=round(Gt * args.steps / res[None], 1), tokenize_ms_per_step=per_step(res[None]),
-            tokenize_and_allgather_graphs_per_sec=round(Gt * args.steps / res["compact"], 1),
-            tokenize_and_allgather_ms_per_step=per_step(res["compact"]),
-            exchange="compact: packed 16-bit rows + lengths over RCCL, re-padded locally (dist.gather_tokens(compact=True))",
-            compact=dict(ms_per_step=per_step(res["compact"]), exchange_ms=per_step(res["compact"] - res[None]),
-                         bytes_sent_per_rank=gstats["compact"]["bytes_sent_per_rank"], bytes_gathered_per_rank=world * gstats["compact"]["bytes_sent_per_rank"]),
-            padded=dict(ms_per_step=per_step(res["padded"]), exchange_ms=per_step(res["padded"] - res[None]),
-                        bytes_sent_per_rank=gstats["padded"]["bytes_sent_per_rank"], bytes_gathered_per_rank=world * gstats["padded"]["bytes_sent_per_rank"]),
-            compact_equals_padded=same, gathered_slab_bytes=int(Gt) * (ld + 1) * 4)
+            workload=f"one {Gt}-graph corpus block-sharded x{world} (graphs_per_gpu {Gs}), {Es} epochs per launch and per exchange, kernel "
+                     f"{gtok.ops.sent_kernel_name(mine, max_nodes, max_len, labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True, epochs=Es)}",
+            epochs_per_launch=Es, launches_timed=n_sl,
+            tokenize_graphs_per_sec=round(Gt * epochs_timed / res[None], 1), tokenize_ms_per_epoch=per_epoch(res[None]),
+            tokenize_and_allgather_graphs_per_sec=round(Gt * epochs_timed / res["compact"], 1),
+            tokenize_and_allgather_ms_per_epoch=per_epoch(res["compact"]),
+            exchange="compact: 16-bit rows straight from the walk, packed (gtok_pack_rows_u16) + lengths over RCCL, re-padded locally "
+                     "(dist.gather_tokens(compact=True)); one exchange per launch = per Es epochs",
+            compact=dict(ms_per_epoch=per_epoch(res["compact"]), exchange_ms_per_epoch=per_epoch(res["compact"] - res[None]),
+                         bytes_sent_per_rank_per_epoch=gstats["compact"]["bytes_sent_per_rank"] // Es,
+                         bytes_gathered_per_rank_per_epoch=world * gstats["compact"]["bytes_sent_per_rank"] // Es),
+            padded=dict(ms_per_epoch=per_epoch(res["padded"]), exchange_ms_per_epoch=per_epoch(res["padded"] - res[None]),
+                        bytes_sent_per_rank_per_epoch=gstats["padded"]["bytes_sent_per_rank"] // Es,
+                        bytes_gathered_per_rank_per_epoch=world * gstats["padded"]["bytes_sent_per_rank"] // Es,
+                        note="the 16-bit slab [Es, per, ld] as it is (half the bytes of round 3's int32 slab)"),
+            compact_equals_padded=same, gathered_slab_bytes_per_epoch=int(Gt) * (ld * 2 + 4),
+            note="no N > 1 run exists until a SCALE record does: with one rank (GTOK_BENCH_FORCE_DIST=1) the collective is a device-local copy")
         if args.scaling == "strong":      # make the configured workload the headline of this run
             out.update(value=out["strong_scaling"]["tokenize_and_allgather_graphs_per_sec"], scaling="strong",
-                       ms_per_step=out["strong_scaling"]["tokenize_and_allgather_ms_per_step"])
+                       ms_per_step=out["strong_scaling"]["tokenize_and_allgather_ms_per_epoch"])
             out["config"]["parallelism"] = f"one corpus block-sharded x{world} + RCCL all-gather of the padded slab"
             out["config"]["graphs_per_gpu"] = hi - lo
 

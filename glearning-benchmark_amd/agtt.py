@@ -6,6 +6,7 @@ fixed vocabulary (remap_zinc_tokens :171-244), `[idx_offset+num_nodes, idx_offse
 appended for shortest_path (:257-267), padding with Graph2TrailTokenizer.pad = 5 even after the remap
 (:285-286), float32 labels iff the first label is a Python float (:296-299).
 """
+from collections.abc import Sequence
 from typing import Optional
 
 import numpy as np
@@ -36,6 +37,10 @@ class TokenizedGraphDataset(Dataset):
         self._epoch = -1
         self._rows = None                      # rows.EpochRows: the host view __getitem__ serves from
         self._ids = self._lens = None
+        self._slab = None                      # (ids16 [K, G, ld], len [K, G], first epoch, padded): the last K-epoch launch
+        self._served = None                    # __getitems__: which rows of the current epoch went out already
+        self._y_dev = None                     # labels on the device (batch-level fetch)
+        self._lens_h = None                    # the current epoch's row lengths on the host (batch-level fetch)
 
     def __len__(self):
         return len(self.pyg_dataset)
@@ -77,7 +82,25 @@ class TokenizedGraphDataset(Dataset):
         batch = self._graphs()
         self._ids, self._lens = self.tokenizer.tokenize_batch(batch, epoch=epoch, remap_zinc=self.remap_to_fixed_vocab,
                                                               query=self._query, pad=pad)
-        self._epoch, self._rows = epoch, None
+        self._epoch, self._rows, self._served = epoch, None, None
+        return self._ids, self._lens
+
+    def tokenize_epoch_u16(self, epoch: int):
+        """(ids16 int16 [G, ld], len int32 [G]) on the device for `epoch`: rows of 16-bit ids, written up to their length
+        only (GTOK_SENT_U16 | GTOK_SENT_NO_PAD) - what __getitem__ / __getitems__ / device_batches read.  One launch
+        carries K epochs (tokenizer.epochs_for: trails depend on (seed, epoch, graph) only, and the trainer asks for the
+        same split again every epoch, trainer/train_agtt.py:676-680); the following K - 1 calls are slices of it."""
+        batch = self._graphs()
+        sl = self._slab
+        if sl is None or not sl[2] <= epoch < sl[2] + sl[0].shape[0]:
+            K = self.tokenizer.epochs_for(batch.num_graphs) if hasattr(self.tokenizer, "epochs_for") else 1
+            ids, ln = self.tokenizer.tokenize_batch(batch, epoch=epoch, remap_zinc=self.remap_to_fixed_vocab, query=self._query,
+                                                    pad=False, epochs=K, u16=True)
+            G = batch.num_graphs
+            sl = self._slab = (ids.view(K, G, -1), ln.view(K, G), epoch)
+        e = epoch - sl[2]
+        self._epoch, self._rows, self._served = epoch, None, None
+        self._ids, self._lens = sl[0][e], sl[1][e]
         return self._ids, self._lens
 
     def remap_zinc_tokens(self, tokens: torch.Tensor, data=None) -> torch.Tensor:
@@ -106,7 +129,7 @@ class TokenizedGraphDataset(Dataset):
         if self._batched and not self._mixed_query:
             tokens = self._rows.take(idx) if self._rows is not None else None
             if tokens is None:                                  # first fetch, or fetched again -> a new random trail
-                ids, lens = self.tokenize_epoch(self._epoch + 1, pad=False)
+                ids, lens = self.tokenize_epoch_u16(self._epoch + 1)
                 self._rows = _rows.EpochRows(ids, lens, self._epoch)     # ONE packed D2H copy per epoch
                 tokens = self._rows.take(idx)
         else:                                                   # any tokenizer object: per-item call
@@ -118,36 +141,117 @@ class TokenizedGraphDataset(Dataset):
                 tokens = torch.cat([tokens, tail])
         return tokens, torch.ones(tokens.size(0), dtype=torch.bool), data.y.item(), data
 
+    def _labels_on_device(self):
+        """Labels of the split as one device tensor (float32 iff the reference's collate would make floats, :296-299)."""
+        if self._y_dev is None:
+            ds, n = self.pyg_dataset, len(self)
+            got = _csr.collated_storage(ds) or _csr.collated_storage(getattr(ds, "zinc_dataset", None))
+            if got is not None and got["y"] is not None:            # labels from the collated storage: no item is touched
+                yv = torch.as_tensor(got["y"]).reshape(-1)
+                if got["indices"] is not None:
+                    yv = yv[torch.as_tensor(got["indices"], dtype=torch.int64)]
+                self._y_dev = yv.to(torch.float if yv.is_floating_point() else torch.long).to(self._dev())
+            else:
+                labels = [ds[i].y.item() for i in range(n)]
+                is_float = n > 0 and isinstance(labels[0], float)
+                self._y_dev = torch.tensor(labels, dtype=torch.float if is_float else torch.long, device=self._dev())
+        return self._y_dev
+
+    # ---- batch-level fetch: what torch.utils.data.DataLoader calls instead of __getitem__ when a dataset has it
+    def __getitems__(self, indices):
+        """One pre-collated batch per call: the stock DataLoader of the reference (trainer/train_agtt.py:599-607,
+        `DataLoader(ds, batch_size, shuffle, num_workers=0, collate_fn=collate_fn)`) hands its index list here and the
+        result to collate_fn.  The batch is collated ON THE DEVICE (gtok_collate_packed over the epoch's 16-bit slab: X
+        int64 pad 5, attn bool, labels - the tensors the trainer moves `.to(device)` anyway) and wrapped in a list-like
+        object: this module's collate_fn passes it through; any other collate function (the reference's own, in the
+        zero-edit layout) iterates it and gets the per-item tuples of __getitem__, made on demand.  A batch that asks for
+        a row already served starts the next epoch (a second fetch of an item is a new random trail in the reference)."""
+        if not (self._batched and torch.utils.data.get_worker_info() is None):
+            return [self[i] for i in indices]
+        self._graphs()
+        if self._mixed_query:
+            return [self[i] for i in indices]
+        idx = np.asarray(indices, dtype=np.int64)
+        if self._served is None or self._ids is None or self._ids.dtype != torch.int16 or self._served[idx].any():
+            self.tokenize_epoch_u16(self._epoch + 1)
+            self._served = np.zeros(len(self), dtype=bool)
+            self._lens_h = self._lens.cpu().numpy()
+        self._served[idx] = True
+        idx_d = torch.from_numpy(idx).to(self._dev(), non_blocking=True)
+        lmax = int(np.minimum(self._lens_h[idx], self._ids.shape[1]).max()) if idx.size else 0
+        X, A = _ops.collate_packed(self._ids, None, self._lens, self._ids.shape[1], idx_d, PAD, lmax)
+        return CollatedBatch(self, idx, X, A, self._labels_on_device()[idx_d], self._epoch)
+
     def device_batches(self, batch_size: int, epoch: int, shuffle: bool = False,
                        generator: Optional[torch.Generator] = None, with_data: bool = True):
-        """Yield collate_fn's tuple with X/attn/labels on the device (gtok_collate over the epoch's slab).
-        with_data=False: the 4th element (the batch's Data objects, which collate_fn hands on and the model only reads
-        for shortest_path's query nodes, train_agtt.py:127-133) is an empty list and no item object is touched."""
-        ids, lens = self.tokenize_epoch(epoch, pad=False)
+        """Yield collate_fn's tuple with X/attn/labels on the device (gtok_collate_packed over the epoch's 16-bit slab).
+        with_data=True: the 4th element is a lazy sequence of the batch's Data objects (collate_fn hands them on and the
+        model only reads data_list[0].num_nodes, train_agtt.py:127-133: an item is made when it is asked for);
+        with_data=False: an empty list."""
+        ids, lens = self.tokenize_epoch_u16(epoch)
         n = len(self)
         ds = self.pyg_dataset
-        got = _csr.collated_storage(ds) or _csr.collated_storage(getattr(ds, "zinc_dataset", None))
-        if got is not None and got["y"] is not None:            # labels from the collated storage: no item is touched
-            yv = torch.as_tensor(got["y"]).reshape(-1)
-            if got["indices"] is not None:
-                yv = yv[torch.as_tensor(got["indices"], dtype=torch.int64)]
-            y = yv.to(torch.float if yv.is_floating_point() else torch.long).to(ids.device)
-        else:
-            labels = [ds[i].y.item() for i in range(n)]
-            is_float = n > 0 and isinstance(labels[0], float)
-            y = torch.tensor(labels, dtype=torch.float if is_float else torch.long, device=ids.device)
+        y = self._labels_on_device()
         lens_h = lens.cpu()
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
         order_d = order.to(ids.device)
+        ld = ids.shape[1]
         for s in range(0, n, batch_size):
             idx = order[s:s + batch_size]
             idx_d = order_d[s:s + batch_size]
-            X, A = _ops.collate(ids, lens, idx_d, PAD, int(lens_h[idx].max()))
-            yield X, A, y[idx_d], ([ds[i] for i in idx.tolist()] if with_data else [])
+            X, A = _ops.collate_packed(ids, None, lens, ld, idx_d, PAD, min(ld, int(lens_h[idx].max())))
+            yield X, A, y[idx_d], (LazyDataList(ds, idx.tolist()) if with_data else [])
+
+
+class LazyDataList(Sequence):
+    """The batch's Data objects as a sequence that fetches `dataset[i]` when element i is asked for: collate_fn returns
+    `list(data_list)` (trainer/train_agtt.py:301) and the model reads data_list[0].num_nodes only (:127-133)."""
+
+    def __init__(self, dataset, indices):
+        self._ds, self._idx = dataset, indices
+
+    def __len__(self):
+        return len(self._idx)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return LazyDataList(self._ds, self._idx[i])
+        return self._ds[self._idx[i]]
+
+
+class CollatedBatch(Sequence):
+    """What TokenizedGraphDataset.__getitems__ returns: the batch already collated on the device (`collated`), and -
+    for a collate function that does not know about it - a sequence of the per-item tuples (tokens, mask, label, data)
+    that __getitem__ would have produced for the same epoch, cut from the device batch on demand."""
+
+    def __init__(self, owner, idx, X, A, Y, epoch):
+        self._owner, self._idx, self.epoch = owner, idx, epoch
+        self.collated = (X, A, Y, LazyDataList(owner.pyg_dataset, idx.tolist()))
+        self._items = None
+
+    def __len__(self):
+        return len(self._idx)
+
+    def _materialise(self):
+        if self._items is None:
+            X, A, Y, datas = self.collated
+            Xh, n = X.cpu(), A.sum(1).cpu().tolist()
+            ys = Y.cpu().tolist()
+            self._items = [(Xh[b, :n[b]].clone(), torch.ones(n[b], dtype=torch.bool), ys[b], datas[b]) for b in range(len(n))]
+        return self._items
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+    def __iter__(self):
+        return iter(self._materialise())
 
 
 def collate_fn(batch):
-    """[(tokens, mask, label, data)] -> (X int64 [B,L] pad 5, attn bool [B,L], labels, list(data)) (:276-302)."""
+    """[(tokens, mask, label, data)] -> (X int64 [B,L] pad 5, attn bool [B,L], labels, list(data)) (:276-302).
+    A batch that TokenizedGraphDataset.__getitems__ collated on the device already is passed through."""
+    if isinstance(batch, CollatedBatch):
+        return batch.collated
     toks, masks, labels, datas = zip(*batch)
     L = max(t.size(0) for t in toks)
     X = torch.full((len(toks), L), PAD, dtype=torch.long)

@@ -30,7 +30,7 @@ class Graph2TrailTokenizer:
 
     def __init__(self, dataset_names: Optional[Sequence[str]] = None, max_length: int = -1,
                  truncation_length: Optional[int] = None, labeled_graph: bool = False, undirected: bool = True,
-                 seed: int = 0, device=None, **unused):
+                 seed: int = 0, device=None, epochs_per_launch: Optional[int] = None, **unused):
         if dataset_names:
             raise ValueError("dataset-name tokens are not supported (the reference always passes dataset_names=[])")
         if not undirected:
@@ -47,6 +47,9 @@ class Graph2TrailTokenizer:
         self.num_edge_types = 0
         self.seed = seed
         self.device = device
+        # K epochs of a split per gtok_sent launch (gtok_sent_params.epoch_count): None = as many as fill the chip once
+        # (EPOCH_WALKS walks), 1 = an epoch per launch
+        self.epochs_per_launch = epochs_per_launch
         self._calls = 0
         self.launches = 0                        # gtok_sent launches issued so far (tests / bench read it)
         self._splits = weakref.WeakKeyDictionary()    # dataset -> _Split: the split's resident CSR and its current epoch
@@ -80,24 +83,38 @@ class Graph2TrailTokenizer:
 
     # ---- batched fast path: one launch for a whole split / epoch
     def tokenize_batch(self, batch: "GraphBatch", epoch: int = 0, graph_base: int = 0, remap_zinc: bool = False,
-                       query: Optional[torch.Tensor] = None, ld: Optional[int] = None, out=None, pad: bool = True):
+                       query: Optional[torch.Tensor] = None, ld: Optional[int] = None, out=None, pad: bool = True,
+                       epochs: int = 1, u16: bool = False):
         """(ids int32 [G, ld], len int32 [G]) on the device; trail g is a function of (seed, epoch, graph_base+g).
-        pad=False: rows are only written up to their length (consumers that read through `len`: ops.collate)."""
+        pad=False: rows are only written up to their length (consumers that read through `len`: ops.collate).
+        epochs=K > 1: epochs epoch .. epoch + K - 1 in ONE launch -> ([K, G, ld], [K, G]); u16: rows of 16-bit ids."""
         if self.max_num_nodes is None:
             raise RuntimeError("call set_num_nodes() first")
         self.launches += 1
         return _ops.sent(batch, self.max_num_nodes, self._max_len(), self.seed, epoch, labeled=self.labeled_graph,
                          num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
-                         remap_zinc=remap_zinc, pad_id=self.pad, graph_base=graph_base, query=query, ld=ld, out=out, pad=pad)
+                         remap_zinc=remap_zinc, pad_id=self.pad, graph_base=graph_base, query=query, ld=ld, out=out, pad=pad,
+                         epochs=epochs, u16=u16)
+
+    EPOCH_WALKS = 1 << 18         # walks that fill the chip once: 4,096 resident waves x 64 lanes (sent_lane_kernel)
+
+    def epochs_for(self, num_graphs: int) -> int:
+        """How many epochs of a split of `num_graphs` graphs one launch should carry.  The reference re-tokenizes a split
+        every epoch (trainer/train_agtt.py:246-250, epoch loop :676-680) and a trail depends on (seed, epoch, graph) only:
+        a 12 k-molecule split (configs/agtt_zinc.yaml:4 `subset: true`) tokenizes 21 epochs in the time of two."""
+        if self.epochs_per_launch is not None:
+            return max(1, int(self.epochs_per_launch))
+        return max(1, min(32, self.EPOCH_WALKS // max(1, int(num_graphs))))
 
     # ---- reference call site: one Data in, one 1-D LongTensor out, a fresh random trail per call
     def _signature(self):
         return (self.max_num_nodes, self.labeled_graph, self.num_node_types, self.num_edge_types, self._max_len(), self.seed)
 
     def _serve(self, owner, idx: int):
-        """Row `idx` of the item's split.  The split is tokenized as a whole - ONE launch per epoch - the first time an
-        item of it is asked for and again whenever an item is asked for a second time (in the reference every fetch
-        is a new random trail: a second fetch of an item is the next epoch)."""
+        """Row `idx` of the item's split.  The split is tokenized as a whole - ONE launch per K epochs (epochs_for) - the
+        first time an item of it is asked for; an item asked for a second time starts the next epoch (in the reference
+        every fetch is a new random trail: a second fetch of an item is the next epoch), which is served from the same
+        launch's next slice until its K epochs are used up."""
         sp = self._splits.get(owner)
         if sp is None or sp.signature != self._signature() or sp.batch.num_graphs != len(owner):
             gb = getattr(owner, "graph_batch", None)
@@ -110,8 +127,13 @@ class Graph2TrailTokenizer:
         row = sp.rows.take(idx) if sp.rows is not None else None
         if row is None:
             sp.epoch += 1
-            ids, ln = self.tokenize_batch(sp.batch, epoch=sp.epoch, pad=False)
-            sp.rows = _rows.EpochRows(ids, ln, sp.epoch)
+            if sp.slab is None or not sp.first <= sp.epoch < sp.first + sp.slab[0].shape[0]:
+                K = self.epochs_for(sp.batch.num_graphs)
+                ids, ln = self.tokenize_batch(sp.batch, epoch=sp.epoch, pad=False, epochs=K, u16=True)
+                G = sp.batch.num_graphs
+                sp.slab, sp.first = (ids.view(K, G, -1), ln.view(K, G)), sp.epoch
+            e = sp.epoch - sp.first
+            sp.rows = _rows.EpochRows(sp.slab[0][e], sp.slab[1][e], sp.epoch)     # one packed D2H copy per epoch
             row = sp.rows.take(idx)
         return row
 
@@ -134,7 +156,8 @@ class Graph2TrailTokenizer:
 
 
 class _Split:
-    __slots__ = ("batch", "signature", "epoch", "rows")
+    __slots__ = ("batch", "signature", "epoch", "rows", "slab", "first")
 
     def __init__(self, batch, signature):
         self.batch, self.signature, self.epoch, self.rows = batch, signature, -1, None
+        self.slab, self.first = None, 0          # the K-epoch device slab of the last launch and the epoch of its slice 0

@@ -44,16 +44,22 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     Ranks hold blocks from block_bounds(); the last blocks may be short, so every rank pads its
     block to ceil(G/P) rows first (one fixed-size all_gather_into_tensor, no size exchange).
     force: issue the collective even in a one-rank group (rehearsal of the N>1 path on a one-GPU box).
+    ids: the int32 slab, or the 16-bit slab of ops.sent(..., u16=True) (int16 storage; the padded exchange then moves half
+    the bytes and returns the 16-bit slab, the compact one packs it directly and returns the int32 slab as always).
 
     compact=True moves the PACKED form over the links instead of the padded slab (include/gtok.h, "packed rows"): every
     rank packs its rows back to back at `elem_bytes` (2: every SENT / IBTT id fits 16 bits; 4 otherwise) per id
     (gtok_pack_rows), the packed buffers - sized to the largest rank's total, one all_reduce(MAX) of an int, or to
-    `capacity` elements when the caller knows a bound (then nothing waits for the host; stats["status"] is a device tensor
-    that is nonzero when a rank's rows did not fit or an id needed more than 16 bits) - and the lengths are gathered, and every rank re-pads locally at
-    HBM speed (gtok_unpack_rows).  More than half of a ZINC slab is padding and ids are 32 bits wide there: 208 MB per
-    corpus become ~46 MB.  Same result as the padded path, bit for bit.  rows_impl: the module providing row_offsets /
-    pack_rows / unpack_rows (default: ops, i.e. the HIP kernels; the CPU tests of the collective pass the oracle's).
-    stats: a dict that receives the bytes each rank contributed to the collective."""
+    `capacity` elements when the caller knows a bound (then nothing waits for the host) - and the lengths are gathered, and
+    every rank re-pads locally at HBM speed (gtok_unpack_rows).  More than half of a ZINC slab is padding and ids are 32
+    bits wide there: 208 MB per corpus become ~46 MB.  Same result as the padded path, bit for bit.
+    Every rank's pack status travels WITH its lengths (one more int per rank in the same collective), so all ranks see the
+    same verdict: bit 0 = an id did not fit 16 bits, bit 1 = a rank's rows did not fit `capacity` (those rows come out as
+    all pad: gtok_unpack_rows never reads beyond a rank's segment).  Without a caller-given capacity a nonzero status
+    raises - on every rank, after the collectives, so nobody is left waiting in one; with it, stats["status"] holds the
+    verdict as a device tensor for the caller to read when it likes.
+    rows_impl: the module providing row_offsets / pack_rows / unpack_rows (default: ops, i.e. the HIP kernels; the CPU
+    tests of the collective pass the oracle's).  stats: a dict that receives the bytes each rank contributed."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return ids, ln
     world = dist.get_world_size()
@@ -64,35 +70,43 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
         ids = torch.cat([ids, torch.full((fill, ld), pad_id, dtype=ids.dtype, device=ids.device)])
         ln = torch.cat([ln, torch.zeros(fill, dtype=ln.dtype, device=ln.device)])
     ids, ln = ids.contiguous(), ln.contiguous()
-    all_ln = torch.empty((world * per,), dtype=ln.dtype, device=ln.device)
     if not compact:
+        all_ln = torch.empty((world * per,), dtype=ln.dtype, device=ln.device)
         all_ids = torch.empty((world * per, ld), dtype=ids.dtype, device=ids.device)
-        dist.all_gather_into_tensor(all_ids, ids)
+        dist.all_gather_into_tensor(all_ids.view(torch.uint8), ids.view(torch.uint8))     # bytes: every backend moves uint8
         dist.all_gather_into_tensor(all_ln, ln)
         if stats is not None:
             stats.update(bytes_sent_per_rank=ids.numel() * ids.element_size() + ln.numel() * 4, compact=False)
         return all_ids[:num_graphs], all_ln[:num_graphs]
     if rows_impl is None:
         from . import ops as rows_impl
+    pack = rows_impl.pack_rows_u16 if ids.dtype == torch.int16 else rows_impl.pack_rows
     row_ptr = rows_impl.row_offsets(ln, ld)
-    status = None
-    if capacity is None:
+    caller_bound = capacity is not None
+    if not caller_bound:
         capacity = all_reduce_max_int(int(row_ptr[-1]), ids.device)
-        capacity = max(8, -(-int(capacity) // 8) * 8)       # keeps every rank's segment 16-byte aligned
-        packed, _ = rows_impl.pack_rows(ids, ln, row_ptr, elem_bytes, capacity=capacity)
-    else:
-        # a caller-given bound (e.g. last epoch's size plus a margin): no size exchange and no host round trip at all -
-        # a rank whose rows do not fit raises status bit 1 on the device; the caller reads stats["status"] when it likes
-        capacity = max(8, -(-int(capacity) // 8) * 8)
-        packed, _, status = rows_impl.pack_rows(ids, ln, row_ptr, elem_bytes, capacity=capacity, check_status=False)
+    capacity = max(8, -(-int(capacity) // 8) * 8)           # keeps every rank's segment 16-byte aligned
+    # (a caller-given bound - e.g. last epoch's size plus a margin - means no size exchange and no host round trip at all)
+    packed, _, status = pack(ids, ln, row_ptr, elem_bytes, capacity=capacity, check_status=False)
     all_packed = torch.empty(world * capacity, dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(all_packed.view(torch.uint8), packed.view(torch.uint8))   # bytes: every backend moves uint8
-    dist.all_gather_into_tensor(all_ln, ln)
+    dist.all_gather_into_tensor(all_packed.view(torch.uint8), packed[:capacity].contiguous().view(torch.uint8))
+    ext = torch.cat([ln, status.to(ln.dtype).reshape(1)])   # lengths + this rank's pack status, one collective
+    all_ext = torch.empty((world * (per + 1),), dtype=ln.dtype, device=ln.device)
+    dist.all_gather_into_tensor(all_ext, ext)
+    all_ext = all_ext.view(world, per + 1)
+    all_ln = all_ext[:, :per].reshape(-1).contiguous()
     all_ptr = rows_impl.row_offsets(all_ln, ld)
-    all_ids = rows_impl.unpack_rows(all_packed, all_ptr, all_ln, ld, pad_id, segment_rows=per, segment_stride=capacity)
+    ustatus = torch.zeros(1, dtype=torch.int32, device=ln.device)
+    all_ids = rows_impl.unpack_rows(all_packed, all_ptr, all_ln, ld, pad_id, segment_rows=per, segment_stride=capacity, status=ustatus)
+    verdict = torch.maximum(all_ext[:, per].max().to(torch.int32).reshape(1), ustatus)
+    if not caller_bound:
+        st = int(verdict.item())
+        if st:
+            from ._lib import GtokError
+            raise GtokError("gather_tokens: " + ("an id does not fit 16 bits (pass elem_bytes=4)" if st & 1 else f"a rank's rows did not fit the agreed size (status {st})"))
     if stats is not None:
-        stats.update(bytes_sent_per_rank=packed.numel() * packed.element_size() + ln.numel() * 4, compact=True,
-                     elem_bytes=elem_bytes, capacity=capacity, status=status)
+        stats.update(bytes_sent_per_rank=capacity * packed.element_size() + (ln.numel() + 1) * 4, compact=True,
+                     elem_bytes=elem_bytes, capacity=capacity, status=verdict)
     return all_ids[:num_graphs], all_ln[:num_graphs]
 
 

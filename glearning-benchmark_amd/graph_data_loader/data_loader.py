@@ -317,6 +317,11 @@ class _Rows(Sequence):
     def __init__(self, buf: torch.Tensor, start, count):
         self._buf, self._start, self._count = buf, start, count
 
+    @property
+    def buffer(self) -> torch.Tensor:
+        """The one host buffer the rows are views of (int64, rows back to back)."""
+        return self._buf
+
     def __len__(self):
         return len(self._count)
 
@@ -380,12 +385,14 @@ class TokenDataset(Dataset):
             # to the host, row i is a view of it cut at its length - what the reference stores as one tensor per example
             rows = _root().rows.EpochRows(self.ids, self.lens, pin=False)   # pageable: forked DataLoader workers read it
             self._lens_h = torch.tensor(rows.count, dtype=torch.int32)
+            self._starts_h = torch.tensor(rows.start, dtype=torch.int64)
             self.seqs = _Rows(rows.tokens, rows.start, rows.count)
         else:
             self._table = None
             self.ids = torch.empty((0, 4), dtype=torch.int32, device=self.device)
             self.lens = torch.empty((0,), dtype=torch.int32, device=self.device)
             self._lens_h = torch.empty((0,), dtype=torch.int32)
+            self._starts_h = torch.empty((0,), dtype=torch.int64)
             self.seqs = _Rows(torch.empty(0, dtype=torch.int64), [], [])
 
     def __getstate__(self):
@@ -399,6 +406,13 @@ class TokenDataset(Dataset):
 
     def __getitem__(self, idx):       # CPU tensors only: safe in DataLoader workers
         return self.seqs[idx], self.labels[idx]
+
+    def __getitems__(self, indices):
+        """Batch-level fetch (torch.utils.data.DataLoader calls it instead of __getitem__ when a dataset has one): the
+        batch's rows as ONE object that `collate` turns into (X, attn, Y) with a handful of vectorised gathers over the
+        packed host buffer - no per-item tensor, works in DataLoader workers (host memory only).  Any other collate
+        function iterates it and gets __getitem__'s (ids, label) pairs."""
+        return RowBatch(self, indices)
 
     def device_batches(self, batch_size: int, shuffle: bool = False, generator: Optional[torch.Generator] = None,
                        pad_id: Optional[int] = None):
@@ -416,8 +430,37 @@ class TokenDataset(Dataset):
             yield X, A, y[idx.to(self.device)]
 
 
+class RowBatch(Sequence):
+    """What TokenDataset.__getitems__ returns: the indices of a batch, collated in one go by `collate` (below); a
+    sequence of __getitem__'s (ids, label) pairs for any other collate function."""
+
+    def __init__(self, ds, indices):
+        self._ds, self._idx = ds, list(indices)
+
+    def __len__(self):
+        return len(self._idx)
+
+    def __getitem__(self, i):
+        return self._ds[self._idx[i]]
+
+    def collate(self, pad_id: int):
+        ds = self._ds
+        idx = torch.as_tensor(self._idx, dtype=torch.int64)
+        lens = ds._lens_h[idx].to(torch.int64)
+        L = int(lens.max()) if idx.numel() else 0
+        pos = torch.arange(L)
+        attn = pos[None, :] < lens[:, None]
+        buf = ds.seqs.buffer
+        src = (ds._starts_h[idx][:, None] + pos[None, :]).clamp_(max=max(buf.numel() - 1, 0))
+        X = torch.where(attn, buf[src], torch.tensor(pad_id, dtype=torch.long)) if buf.numel() else torch.full((idx.numel(), L), pad_id, dtype=torch.long)
+        return X, attn, ds._y[idx]
+
+
 def collate(batch, pad_id: int):
-    """[(ids, label)] -> (X int64 [B,L] padded with pad_id, attn bool [B,L], Y int64 [B]) (reference :488-497)."""
+    """[(ids, label)] -> (X int64 [B,L] padded with pad_id, attn bool [B,L], Y int64 [B]) (reference :488-497).
+    A batch fetched through TokenDataset.__getitems__ is collated without touching an item."""
+    if isinstance(batch, RowBatch):
+        return batch.collate(pad_id)
     xs, ys = zip(*batch)
     lens = torch.tensor([x.size(0) for x in xs])
     L = int(lens.max())

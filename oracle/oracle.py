@@ -351,29 +351,56 @@ def row_offsets(ln, ld, align=8):
     return ptr
 
 
-def pack_rows(ids, ln, ld=None, elem_bytes=2, align=8, capacity=None, fill=0):
+def pack_rows(ids, ln, ld=None, elem_bytes=2, align=8, capacity=None, fill=0, with_status=False):
     """(packed, row_ptr): row r's min(len, ld) ids from packed[row_ptr[r]]; slots between rows hold `fill`
-    (the product leaves them unwritten: compare through unpack_rows or row by row)."""
-    ids = np.asarray(ids, np.int32)
+    (the product leaves them unwritten: compare through unpack_rows or row by row).  with_status: (packed, row_ptr,
+    status) with gtok_pack_rows' bits - 1: an id does not fit 16 bits (stored truncated), 2: a row did not fit `capacity`
+    (skipped) - instead of raising."""
+    ids = np.asarray(ids)
+    if ids.dtype == np.int16:                       # a 16-bit slab (GTOK_SENT_U16)
+        ids = ids.view(np.uint16)
+    ids = ids.astype(np.int64)
     ld = ids.shape[1] if ld is None else ld
     ptr = row_offsets(ln, ld, align)
-    dt = np.uint16 if elem_bytes == 2 else np.int32
-    if elem_bytes == 2 and ids.size and any(((ids[r, :min(max(int(l), 0), ld)] >> 16) != 0).any() for r, l in enumerate(ln)):
-        raise ValueError("an id does not fit 16 bits")
+    dt = {2: np.uint16, 4: np.int32, 8: np.int64}[elem_bytes]
+    status = 0
     packed = np.full(int(ptr[-1]) if capacity is None else capacity, fill, dt)
     for r, l in enumerate(np.clip(np.asarray(ln, np.int64), 0, ld)):
-        packed[ptr[r]:ptr[r] + l] = ids[r, :l].astype(dt)
+        if ptr[r] + l > packed.size:
+            status |= 2
+            continue
+        if elem_bytes == 2 and (ids[r, :l] >> 16).any():
+            status |= 1
+        packed[ptr[r]:ptr[r] + l] = (ids[r, :l] & 0xFFFF if elem_bytes == 2 else ids[r, :l]).astype(dt)
+    if with_status:
+        return packed, ptr, status
+    if status & 1:
+        raise ValueError("an id does not fit 16 bits")
+    if status & 2:
+        raise ValueError("capacity too small")
     return packed, ptr
 
 
-def unpack_rows(packed, row_ptr, ln, ld, pad_id, segment_rows=0, segment_stride=0):
+def unpack_rows(packed, row_ptr, ln, ld, pad_id, segment_rows=0, segment_stride=0, with_status=False):
+    """row_ptr None: the strided form (row r at r * ld).  A row that would end beyond its segment or the buffer comes out
+    as all pad (status bit 2), as gtok_unpack_rows_checked does."""
     ln = np.asarray(ln, np.int64)
     out = np.full((ln.size, ld), pad_id, np.int32)
+    status = 0
     for r, l in enumerate(np.clip(ln, 0, ld)):
-        if segment_rows > 0:
+        if row_ptr is None:
+            start = r * ld
+        elif segment_rows > 0:
             s = r // segment_rows
-            start = s * segment_stride + row_ptr[r] - row_ptr[s * segment_rows]
+            rel = row_ptr[r] - row_ptr[s * segment_rows]
+            if rel + l > segment_stride:
+                status |= 2 if l > 0 else 0
+                continue
+            start = s * segment_stride + rel
         else:
             start = row_ptr[r]
+        if start + l > packed.size:
+            status |= 2 if l > 0 else 0
+            continue
         out[r, :l] = packed[start:start + l].astype(np.int64)
-    return out
+    return (out, status) if with_status else out

@@ -42,6 +42,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         nc = np.maximum(np.asarray(d["node_counts"]), 1)
         query = np.stack([rng.integers(0, nc), rng.integers(0, nc)], 1).astype(np.int32)
     pad = bool(rng.integers(0, 4))
+    K = int(rng.choice([1, 1, 2, 3, 7]))                    # epochs per launch (gtok_sent_params.epoch_count)
+    if K * coo.G > 400000: K = 1
+    u16 = bool(rng.integers(0, 2))                          # rows of 16-bit ids (GTOK_SENT_U16)
     ref = None
     for pin in pins:
         os.environ["GTOK_SENT_KERNEL"] = pin.split("-")[0]
@@ -49,15 +52,17 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         os.environ["GTOK_NO_PACK8"] = "1" if pin == "lane-int32" else "0"
         os.environ["GTOK_BLANE_ORDER"] = "0" if pin == "blane-unordered" else "1"
         fresh = batch.to(DEV)                               # the resident layouts are made per pin
-        ids, ln = gtok.ops.sent(fresh, nn, max_len, sd, ep, graph_base=base, query=None if query is None else torch.from_numpy(query), pad=pad, **kw)
+        ids, ln = gtok.ops.sent(fresh, nn, max_len, sd, ep, graph_base=base, query=None if query is None else torch.from_numpy(query), pad=pad,
+                                epochs=K, u16=u16, **kw)
+        ids, ln = ids.view(K, coo.G, -1), ln.view(K, coo.G)
         if ref is None:
-            ref = orc.sent(coo, nn, max_len, sd, ep, graph_base=base, ld=ids.shape[1], nthreads=T, query=query, **kw)
-        if pad:
-            cmp(f"sent it={it} kind={kind} pin={pin or 'auto'} G={coo.G} max_len={max_len} query={query is not None}", ids, ln, *ref)
-        else:                                               # GTOK_SENT_NO_PAD: rows equal inside their lengths
-            inside = np.arange(ref[0].shape[1])[None, :] < ref[1][:, None]
-            if not (np.array_equal(ln.cpu().numpy(), ref[1]) and np.array_equal(np.where(inside, ids.cpu().numpy(), 0), np.where(inside, ref[0], 0))):
-                fails += 1; print("MISMATCH (no pad)", pin, it, flush=True)
+            ref = [orc.sent(coo, nn, max_len, sd, ep + e, graph_base=base, ld=ids.shape[2], nthreads=T, query=query, **kw) for e in range(K)]
+        for e in range(K):
+            got = ids[e].cpu().numpy()
+            got = got.view(np.uint16).astype(np.int32) if u16 else got
+            inside = np.arange(ref[e][0].shape[1])[None, :] < ref[e][1][:, None] if not pad else np.ones_like(ref[e][0], bool)   # GTOK_SENT_NO_PAD: rows equal inside their lengths
+            if not (np.array_equal(ln[e].cpu().numpy(), ref[e][1]) and np.array_equal(np.where(inside, got, 0), np.where(inside, ref[e][0], 0))):
+                fails += 1; print(f"MISMATCH sent it={it} kind={kind} pin={pin or 'auto'} G={coo.G} max_len={max_len} query={query is not None} pad={pad} K={K} e={e} u16={u16}", flush=True)
     for k in ("GTOK_SENT_KERNEL", "GTOK_NO_LANE_SORT", "GTOK_NO_PACK8", "GTOK_BLANE_ORDER"):
         os.environ[k] = "" if k == "GTOK_SENT_KERNEL" else ("1" if k == "GTOK_BLANE_ORDER" else "0")
     if labeled:

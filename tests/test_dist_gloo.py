@@ -26,16 +26,23 @@ class _OracleRows:
 
     @staticmethod
     def pack_rows(ids, ln, row_ptr, elem_bytes=2, capacity=None, check_status=True):
-        packed, ptr = orc.pack_rows(ids.numpy(), ln.numpy(), ids.shape[1], elem_bytes, capacity=capacity, fill=0x7ABC)
+        packed, ptr, st = orc.pack_rows(ids.numpy(), ln.numpy(), ids.shape[1], elem_bytes, capacity=capacity, fill=0x7ABC, with_status=True)
         assert np.array_equal(ptr, row_ptr.numpy())
+        if check_status and st:
+            raise ValueError(f"pack status {st}")
         out = (torch.from_numpy(packed.view(np.int16) if elem_bytes == 2 else packed), row_ptr)
-        return out if check_status else out + (torch.zeros(1, dtype=torch.int32),)
+        return out if check_status else out + (torch.tensor([st], dtype=torch.int32),)
+
+    pack_rows_u16 = pack_rows           # (the oracle's statement takes either slab)
 
     @staticmethod
-    def unpack_rows(packed, row_ptr, ln, ld, pad_id, segment_rows=0, segment_stride=0):
+    def unpack_rows(packed, row_ptr, ln, ld, pad_id, segment_rows=0, segment_stride=0, status=None):
         p = packed.numpy()
         p = p.view(np.uint16) if p.dtype == np.int16 else p
-        return torch.from_numpy(orc.unpack_rows(p, row_ptr.numpy(), ln.numpy(), ld, pad_id, segment_rows, segment_stride))
+        out, st = orc.unpack_rows(p, None if row_ptr is None else row_ptr.numpy(), ln.numpy(), ld, pad_id, segment_rows, segment_stride, with_status=True)
+        if status is not None:
+            status |= st
+        return torch.from_numpy(out)
 
 
 def _worker(rank, world, port, G, q):
@@ -63,6 +70,30 @@ def _worker(rank, world, port, G, q):
             k_ids, k_ln = gtok.dist.gather_tokens(torch.from_numpy(ids), torch.from_numpy(ln), G, 5, compact=True, elem_bytes=eb,
                                                   capacity=st["capacity"] + 40, rows_impl=_OracleRows, stats=st)
             ok = ok and torch.equal(k_ids, full_ids) and int(st["status"]) == 0
+            # a 16-bit slab (ops.sent(..., u16=True)) goes through both exchanges as it is
+            i16 = torch.from_numpy(ids.astype(np.uint16).view(np.int16))
+            u_ids, u_ln = gtok.dist.gather_tokens(i16, torch.from_numpy(ln), G, 5, compact=True, elem_bytes=eb, rows_impl=_OracleRows)
+            p_ids, p_ln = gtok.dist.gather_tokens(i16, torch.from_numpy(ln), G, 5)
+            ok = ok and torch.equal(u_ids, full_ids) and p_ids.dtype == torch.int16 \
+                and np.array_equal(p_ids.numpy().view(np.uint16).astype(np.int32), full_ids.numpy()) and torch.equal(p_ln, full_ln)
+        # a caller-given capacity that turns out too small: no rank reads beyond a segment, every rank sees the same verdict,
+        # the rows that did not fit come out as pad, the others are right
+        st = {}
+        small = int(orc.row_offsets(ref_ln[:-(-G // world)], 160)[-1]) // 2 // 8 * 8      # the same bound on every rank
+        s_ids, s_ln = gtok.dist.gather_tokens(torch.from_numpy(ids), torch.from_numpy(ln), G, 5, compact=True, capacity=small,
+                                              rows_impl=_OracleRows, stats=st)
+        ok = ok and int(st["status"]) & 2 and torch.equal(s_ln, full_ln)
+        same = (s_ids == full_ids).all(1) | (s_ids == 5).all(1)
+        ok = ok and bool(same.all()) and bool((s_ids == full_ids).all(1).any()) and bool((s_ids != full_ids).any())
+        # an id beyond 16 bits with the default elem_bytes=2 and no caller capacity: EVERY rank raises, after the collectives
+        wide = torch.from_numpy(ids).clone()
+        if rank == 1:
+            wide[0, 0] = 70000
+        try:
+            gtok.dist.gather_tokens(wide, torch.from_numpy(ln), G, 5, compact=True, rows_impl=_OracleRows)
+            ok = False
+        except gtok.GtokError:
+            pass
         # corpus-wide vocab statistics from per-rank tables (SUM / MIN all-reduce)
         s = gtok.synth.graph_token_like(G, seed=78, with_text=False)
         sc = orc.Coo(s["node_counts"], s["edge_counts"], s["src"], s["dst"])

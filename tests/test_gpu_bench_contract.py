@@ -31,3 +31,18 @@ def test_bench_prints_one_contract_line():
     cb = b["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] in ("port", "reference")
     assert cb["cores"] >= 1 and cb["value"] > 0 and cb.get("parity_with_gpu") is True
+    # round 4: a step is an epoch, a launch carries E of them for the split that cannot fill the chip on its own
+    assert b["config"]["epochs_per_launch"] == 3 and rf["epochs_per_launch"] == 3 and rf["launches"] == 1
+    assert "cold_start" in b and b["cold_start"]["ms_per_step"] > 0 and "u16_rows" in b
+
+
+def test_truncation_aware_yardstick_counts_the_nodes_the_walks_reach():
+    """the decode pass behind roofline.truncation_aware stopped at its capacities (~5 nodes per walk reported
+    where the walks reach ~68).  The count-only decode reads every row to its end."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "synth_er", "--graphs", "24000", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-ibtt", "--no-sustained"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    ta = b["roofline"]["truncation_aware"]
+    assert ta["avg_nodes_visited"] > 30, ta
+    assert 0 < ta["bytes_per_launch"] <= b["roofline"]["algorithmic_bytes_per_launch"]

@@ -38,7 +38,10 @@ def _zinc_tokenizer(max_nodes):
     return tok
 
 
-def test_reference_per_item_loop_is_one_launch_per_epoch():
+def test_reference_per_item_loop_is_one_launch_per_k_epochs():
+    """The reference's per-item loop over this package's dataset: ONE gtok_sent launch serves K epochs of the split
+    (K = tokenizer.epochs_for(G) = 21 for the 12 k split: trails depend on (seed, epoch, graph) only), every epoch's rows
+    equal to the single-epoch batched call and to the oracle."""
     G = 12000                                                            # BASELINE config 2
     d = gtok.synth.zinc_like(G, seed=40)
     batch, coo = both(d)
@@ -51,7 +54,7 @@ def test_reference_per_item_loop_is_one_launch_per_epoch():
             tokens, mask, label, data = _reference_getitem(pyg, tok, i, remap=True)
             got[i] = tokens
             assert mask.all() and mask.numel() == tokens.numel() and label == pytest.approx(float(d["y"][i]))
-        assert tok.launches == epoch + 1, "one gtok_sent launch per epoch, however the items are fetched"
+        assert tok.epochs_for(G) == 21 and tok.launches == 1, "one gtok_sent launch per K epochs, however the items are fetched"
         ids, ln = tok.tokenize_batch(batch.to(DEV), epoch=epoch, remap_zinc=True)       # the batched call, fused remap
         ref, rln = orc.sent(coo, 37, 1024, 5, epoch, ld=ids.shape[1], labeled=True, num_node_types=9, num_edge_types=4,
                             remap_zinc=True, nthreads=8)
@@ -64,10 +67,19 @@ def test_reference_per_item_loop_is_one_launch_per_epoch():
     before = tok.launches
     one = tok(loose)
     assert tok.launches == before + 1 and one[0] == 0 and one[-1] == 4
-    # fetching one item of a finished epoch again starts the next epoch (a new random trail), once
+    # fetching one item of a finished epoch again starts the next epoch (a new random trail) - a slice of the same launch
     before = tok.launches
     t1 = tok(pyg[0]); t2 = tok(pyg[1])
-    assert tok.launches == before + 1
+    assert tok.launches == before
+    ids, ln = tok.tokenize_batch(batch.to(DEV), epoch=2)
+    assert torch.equal(t1, ids[0, :int(ln[0])].cpu().long()) and torch.equal(t2, ids[1, :int(ln[1])].cpu().long())
+    # with an epoch per launch (epochs_per_launch=1) every epoch is a launch of its own, same rows
+    tok1 = _zinc_tokenizer(37); tok1.epochs_per_launch = 1
+    for epoch in range(2):
+        rows = [tok1(pyg[i]) for i in range(0, G, 97)]
+        assert tok1.launches == epoch + 1
+        ids, ln = tok.tokenize_batch(batch.to(DEV), epoch=epoch)
+        assert all(torch.equal(r, ids[i, :int(ln[i])].cpu().long()) for r, i in zip(rows, range(0, G, 97)))
 
 
 def test_three_splits_share_a_tokenizer_and_the_swapped_in_dataset_serves_packed_rows():
@@ -80,7 +92,7 @@ def test_three_splits_share_a_tokenizer_and_the_swapped_in_dataset_serves_packed
         for _ in range(rounds):
             for i in range(len(pyg)):
                 tok(pyg[i])
-    assert tok.launches == 4
+    assert tok.launches == 3          # one launch per split: the second epoch of the train split is a slice of the first launch
     for pyg, d in zip(pygs, ds):
         _, coo = both(d)
         fast = gtok.agtt.TokenizedGraphDataset(pyg, tok, task="zinc", remap_to_fixed_vocab=True, device=DEV)
@@ -90,8 +102,10 @@ def test_three_splits_share_a_tokenizer_and_the_swapped_in_dataset_serves_packed
         ref, rln = orc.sent(coo, 37, 1024, 5, 0, ld=256, labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True, nthreads=8)
         for i, (t, m, y, data) in enumerate(items):
             assert np.array_equal(t.numpy(), ref[i, :rln[i]]) and m.all() and isinstance(y, float)
-        again = fast[0][0]                                               # second fetch: next epoch's trail
-        assert tok.launches == before + 2 and fast._epoch == 1
+        again = fast[0][0]                                               # second fetch: next epoch's trail, from the same launch
+        assert tok.launches == before + 1 and fast._epoch == 1
+        ref1, rln1 = orc.sent(coo, 37, 1024, 5, 1, ld=256, labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True, nthreads=8)
+        assert np.array_equal(again.numpy(), ref1[0, :rln1[0]])
 
 
 def test_graph_token_split_with_queries_through_the_reference_loop(tmp_path):
@@ -253,3 +267,77 @@ def test_text_to_ids_adopts_left_out_short_keys_while_splitting():
         ids, ln = gtok.ops.text_to_ids(blob.to(DEV), ptr, table, max_len, strip, ld=256)
         ref, rln = orc.text_to_ids(texts, vocab, max_len, 256, strip_label=strip, nthreads=8)
         assert np.array_equal(ln.cpu().numpy(), rln) and np.array_equal(ids.cpu().numpy(), ref), (max_len, strip)
+
+
+def test_stock_dataloader_fetches_whole_batches_through_getitems():
+    """trainer/train_agtt.py:599-607 unchanged - `DataLoader(ds, batch_size, shuffle, num_workers=0, collate_fn=collate_fn)` -
+    over the one-line-swap class: the loader hands its index list to __getitems__, the batch is collated on the device and
+    collate_fn passes it through.  Batches equal what per-item __getitem__ + collate_fn give for the same epoch (shuffle=True
+    and False); a second pass over the loader is the next epoch; a collate function that knows nothing about it (the
+    reference's own) still gets per-item tuples."""
+    from torch.utils.data import DataLoader
+    G = 3000
+    d = gtok.synth.zinc_like(G, seed=77)
+    _, coo = both(d)
+    pyg = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=gtok.synth.InMemoryLike(d))
+    agtt = gtok.agtt
+    ds = agtt.TokenizedGraphDataset(pyg, _zinc_tokenizer(37), task="zinc", remap_to_fixed_vocab=True, device=DEV)
+    refs = [orc.sent(coo, 37, 1024, 5, e, ld=256, labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True, nthreads=8) for e in range(3)]
+
+    def check(X, A, Y, datas, idx, epoch):
+        ref, rln = refs[epoch]
+        L = int(rln[idx].max())
+        assert X.dtype == torch.long and A.dtype == torch.bool and tuple(X.shape) == (len(idx), L) and X.device.type == "cuda"
+        Xh, Ah = X.cpu().numpy(), A.cpu().numpy()
+        for b, i in enumerate(idx):
+            n = int(rln[i])
+            assert np.array_equal(Xh[b, :n], ref[i, :n]) and (Xh[b, n:] == 5).all() and Ah[b, :n].all() and not Ah[b, n:].any()
+        assert Y.dtype == torch.float32 and np.allclose(Y.cpu().numpy(), d["y"][idx]) and len(datas) == len(idx)
+        assert datas[0].num_nodes == int(d["node_counts"][idx[0]])
+    dl = DataLoader(ds, batch_size=128, shuffle=True, num_workers=0, collate_fn=agtt.collate_fn, generator=torch.Generator().manual_seed(11))
+    launches = ds.tokenizer.launches
+    y32 = d["y"].astype(np.float32)
+    assert np.unique(y32).size == G                          # rows of a shuffled batch are identified by their label
+    by_label = {float(v): i for i, v in enumerate(y32)}
+    for epoch in range(2):                                   # two passes: two epochs, one launch (K epochs per launch)
+        seen = set()
+        for X, A, Y, datas in dl:
+            idx = np.asarray([by_label[float(v)] for v in Y.cpu().numpy()])
+            check(X, A, Y, datas, idx, epoch)
+            seen.update(idx.tolist())
+        assert len(seen) == G
+    assert ds.tokenizer.launches == launches + 1
+    # shuffle=False (val / test loaders): dataset order, next epoch
+    dl2 = DataLoader(ds, batch_size=100, shuffle=False, num_workers=0, collate_fn=agtt.collate_fn)
+    for k, (X, A, Y, datas) in enumerate(dl2):
+        check(X, A, Y, datas, np.arange(k * 100, min(G, (k + 1) * 100)), 2)
+    # a collate function that does not know CollatedBatch (the reference's own, restated) gets per-item tuples of the same epoch
+    def reference_collate(batch):
+        toks, masks, labels, datas = zip(*batch)
+        L = max(t.size(0) for t in toks)
+        X = torch.full((len(toks), L), 5, dtype=torch.long); Am = torch.zeros((len(toks), L), dtype=torch.bool)
+        for i, (t, m) in enumerate(zip(toks, masks)):
+            X[i, :t.size(0)] = t; Am[i, :t.size(0)] = m
+        return X, Am, torch.tensor(labels, dtype=torch.float if isinstance(labels[0], float) else torch.long), list(datas)
+    ds3 = agtt.TokenizedGraphDataset(pyg, _zinc_tokenizer(37), task="zinc", remap_to_fixed_vocab=True, device=DEV)
+    for k, (X, A, Y, datas) in enumerate(DataLoader(ds3, batch_size=64, shuffle=False, num_workers=0, collate_fn=reference_collate)):
+        assert X.device.type == "cpu"
+        check(X.cuda(), A.cuda(), Y.cuda(), datas, np.arange(k * 64, min(G, (k + 1) * 64)), 0)
+        if k == 3:
+            break
+
+
+def test_token_dataset_batches_through_getitems_equal_per_item_collate():
+    """IBTT: `DataLoader(TokenDataset, batch_size, shuffle, num_workers=2, collate_fn=lambda b: collate(b, pad_id))`
+    (trainer/train_ibtt.py:399-402) - batches built from the packed host buffer in one go equal the per-item collate."""
+    from torch.utils.data import DataLoader
+    g = gtok.synth.graph_token_like(700, seed=14, task="cycle_check")
+    ex = [{"text": t, "label": int(l)} for t, l in zip(g["texts"], g["labels"])]
+    vocab = gdl.build_vocab_from_texts([e["text"] for e in ex], max_tokens=600)
+    td = gdl.TokenDataset(ex, vocab, max_len=600, device=DEV)
+    pad = vocab["<pad>"]
+    per_item = [gdl.collate([td[i] for i in range(s, min(len(td), s + 50))], pad) for s in range(0, len(td), 50)]
+    for workers in (0, 2):
+        dl = DataLoader(td, batch_size=50, shuffle=False, num_workers=workers, collate_fn=lambda b: gdl.collate(b, pad))
+        for (X, A, Y), (rX, rA, rY) in zip(dl, per_item):
+            assert torch.equal(X, rX) and torch.equal(A, rA) and torch.equal(Y, rY)

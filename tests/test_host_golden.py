@@ -296,3 +296,18 @@ def test_custom_ops_are_registered_cuda_only_and_have_meta_kernels():
     assert torch.ops.gtok.unpack_rows(packed, ptr, ln.to("meta"), 8, 5, 0, 0).shape == (4, 8)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.gtok.row_offsets(ln, 8, 8)
+
+
+def test_bench_spawns_its_own_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its N ranks itself - children, started before
+    the parent initialises HIP - relays rank 0's line and fails loudly when a rank fails.  Without a GPU every rank exits
+    with bench.py's own "needs a GPU" message: the parent must report exactly that, non-zero."""
+    import subprocess
+    import sys
+    if __import__("torch").cuda.is_available():
+        pytest.skip("covers the GPU-less failure path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "ranks failed" in r.stderr and "needs a GPU" in r.stderr, r.stderr[-1500:]
+    assert "(0," in r.stderr and "(1," in r.stderr          # both ranks were started and both reported
