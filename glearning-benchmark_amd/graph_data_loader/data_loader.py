@@ -444,16 +444,21 @@ class RowBatch(Sequence):
         return self._ds[self._idx[i]]
 
     def collate(self, pad_id: int):
+        # numpy on purpose: a [128, ~200] batch is below torch's intra-op threading threshold for some of these ops and above
+        # it for others, and on a box whose cgroup grants 16 CPUs of a 256-thread host a threaded gather costs milliseconds
         ds = self._ds
-        idx = torch.as_tensor(self._idx, dtype=torch.int64)
-        lens = ds._lens_h[idx].to(torch.int64)
-        L = int(lens.max()) if idx.numel() else 0
-        pos = torch.arange(L)
+        idx = np.asarray(self._idx, dtype=np.int64)
+        buf = ds.seqs.buffer.numpy()
+        lens = ds._lens_h.numpy()[idx].astype(np.int64)
+        L = int(lens.max()) if idx.size else 0
+        pos = np.arange(L, dtype=np.int64)
         attn = pos[None, :] < lens[:, None]
-        buf = ds.seqs.buffer
-        src = (ds._starts_h[idx][:, None] + pos[None, :]).clamp_(max=max(buf.numel() - 1, 0))
-        X = torch.where(attn, buf[src], torch.tensor(pad_id, dtype=torch.long)) if buf.numel() else torch.full((idx.numel(), L), pad_id, dtype=torch.long)
-        return X, attn, ds._y[idx]
+        if buf.size:
+            src = np.minimum(ds._starts_h.numpy()[idx][:, None] + pos[None, :], buf.size - 1)
+            X = np.where(attn, buf[src], np.int64(pad_id))
+        else:
+            X = np.full((idx.size, L), pad_id, np.int64)
+        return torch.from_numpy(X), torch.from_numpy(attn), ds._y[torch.from_numpy(idx)]
 
 
 def collate(batch, pad_id: int):

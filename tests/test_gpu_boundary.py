@@ -333,7 +333,7 @@ def test_token_dataset_batches_through_getitems_equal_per_item_collate():
     from torch.utils.data import DataLoader
     g = gtok.synth.graph_token_like(700, seed=14, task="cycle_check")
     ex = [{"text": t, "label": int(l)} for t, l in zip(g["texts"], g["labels"])]
-    vocab = gdl.build_vocab_from_texts([e["text"] for e in ex], max_tokens=600)
+    vocab, _ = gdl.build_vocab_from_texts([e["text"] for e in ex], max_tokens=600)
     td = gdl.TokenDataset(ex, vocab, max_len=600, device=DEV)
     pad = vocab["<pad>"]
     per_item = [gdl.collate([td[i] for i in range(s, min(len(td), s + 50))], pad) for s in range(0, len(td), 50)]

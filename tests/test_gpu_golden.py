@@ -207,7 +207,9 @@ def test_agtt_items_through_dataloader_no_workers():
     seen = 0
     for X, A, Y, dl in DataLoader(a, batch_size=16, shuffle=False, num_workers=0, collate_fn=gtok.agtt.collate_fn):
         Xw, Aw, Yw, _ = gtok.agtt.collate_fn(direct[seen:seen + X.shape[0]])
-        assert torch.equal(X, Xw) and torch.equal(A, Aw) and torch.equal(Y, Yw) and len(dl) == X.shape[0]
+        # (round 4: the loader fetches whole batches through __getitems__, collated on the device - the tensors the trainer
+        # moves `.to(device)` anyway, train_agtt.py:309)
+        assert X.device.type == "cuda" and torch.equal(X.cpu(), Xw) and torch.equal(A.cpu(), Aw) and torch.equal(Y.cpu(), Yw) and len(dl) == X.shape[0]
         seen += X.shape[0]
     assert seen == len(a)
     # worker processes would have to launch kernels: refused with a clear message instead of a HIP re-init failure
