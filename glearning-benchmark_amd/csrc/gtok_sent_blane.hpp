@@ -448,20 +448,26 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
     }
     // ---- pad tails: four rows per pass, 16 lanes x 16-byte stores on each (rows of a unit need not be neighbours)
     if (!no_pad) {
-      const int q = lane & 15;
-      for (int it = 0; it < 16; ++it) {
-        const int r = it * 4 + (lane >> 4);
-        const int lr = __builtin_amdgcn_ds_bpermute(r << 2, padfrom);
-        const int gr = __builtin_amdgcn_ds_bpermute(r << 2, valid ? (int)(row0 + g) : -1);
-        if (unit * 64 + it * 4 >= G) break;
-        if (gr >= 0) {
-          out_t *__restrict__ rowp = out_base + (int64_t)gr * ld + lr;
-          const int nrem = ld - lr, nvec = nrem / EV;
-          _Pragma("clang loop vectorize(disable) unroll(disable)")
-          for (int t = q; t < nvec; t += 16) store_pad16(rowp + EV * t, pad, pad_nt);
-          if (q < (nrem & (EV - 1))) rowp[nvec * EV + q] = (out_t)pad;
+      auto pad_tails = [&](auto nt_tag) __attribute__((always_inline)) {
+        constexpr bool NT = decltype(nt_tag)::value;
+        const int q = lane & 15;
+        const gtok_v4i pv = pad_vec(out_base, pad);
+        for (int it = 0; it < 16; ++it) {
+          const int r = it * 4 + (lane >> 4);
+          const int lr = __builtin_amdgcn_ds_bpermute(r << 2, padfrom);
+          const int gr = __builtin_amdgcn_ds_bpermute(r << 2, valid ? (int)(row0 + g) : -1);
+          if (unit * 64 + it * 4 >= G) break;
+          if (gr >= 0) {
+            out_t *__restrict__ rowp = out_base + (int64_t)gr * ld + lr;
+            const int nrem = ld - lr, nvec = nrem / EV;
+            _Pragma("clang loop vectorize(disable) unroll(disable)")
+            for (int t = q; t < nvec; t += 16) store_pad16<NT>(rowp + EV * t, pv);
+            if (q < (nrem & (EV - 1))) rowp[nvec * EV + q] = (out_t)pad;
+          }
         }
-      }
+      };
+      if (pad_nt) pad_tails(std::true_type{});
+      else pad_tails(std::false_type{});
     }
     __builtin_amdgcn_wave_barrier();
 #ifdef GTOK_PHASE_TIMING

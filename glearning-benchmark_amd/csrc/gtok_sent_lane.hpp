@@ -102,19 +102,27 @@ __device__ __forceinline__ void lane_commit16(const uint8_t *__restrict__ src, i
 // nt: non-temporal stores - for slabs beyond the 256 MB of the memory-side cache the padding (more than half of a molecule
 // slab) otherwise pushes the half-written token lines out ahead of their time: 31 k molecules x 21 epochs 0.289 -> 0.190 ms,
 // 1 M molecules 0.378 -> 0.345 ms; a slab that fits (ZINC-full: 208 MB) is 1.5 % slower with them, so the launcher decides
-__device__ __forceinline__ void store_pad16_raw(void *p, int pp, bool nt) {
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  const v4i v = {pp, pp, pp, pp};
+// The loops that use it are the tail of every wave's life (the padding of a unit's 64 rows): the padding vector is made
+// once per call (pad_vec) and the non-temporal switch is taken outside the store loops - with the vector rebuilt and the
+// switch tested at every store the ZINC-full launch was 3 us longer.
+typedef int gtok_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gtok_v4i pad_vec(const int32_t *, int pad) { gtok_v4i v = {pad, pad, pad, pad}; asm volatile("" : "+v"(v)); return v; }
+// (GTOK_SENT_U16 slab: eight 16-bit ids per 16-byte store)
+__device__ __forceinline__ gtok_v4i pad_vec(const uint16_t *, int pad) {
+  const int pp = (int)(((uint32_t)pad & 0xFFFFu) * 0x00010001u);
+  gtok_v4i v = {pp, pp, pp, pp};
+  asm volatile("" : "+v"(v));
+  return v;
+}
+template <bool NT>
+__device__ __forceinline__ void store_pad16(void *p, const gtok_v4i &v) {
 #if defined(GTOK_SC1_PAD_STORES)
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 #else
-  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
-  else *reinterpret_cast<I32x4 *>(p) = I32x4{pp, pp, pp, pp};
+  if (NT) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 #endif
 }
-__device__ __forceinline__ void store_pad16(int32_t *p, int pad, bool nt) { store_pad16_raw(p, pad, nt); }
-// (GTOK_SENT_U16 slab: eight 16-bit ids per 16-byte store)
-__device__ __forceinline__ void store_pad16(uint16_t *p, int pad, bool nt) { store_pad16_raw(p, (int)(((uint32_t)pad & 0xFFFFu) * 0x00010001u), nt); }
 // four tokens of a row at once: a 16-byte store into the int32 slab, an 8-byte store into the 16-bit slab
 __device__ __forceinline__ void store_tok4(int32_t *p, int t0, int t1, int t2, int t3) { *reinterpret_cast<I32x4 *>(p) = I32x4{t0, t1, t2, t3}; }
 __device__ __forceinline__ void store_tok4(uint16_t *p, int t0, int t1, int t2, int t3) {
@@ -271,22 +279,33 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   int lw = 0, done_row = -1, done_cnt = 0;  // pad start of this lane's finished row, that row (-1: none), rows of the finished unit
   // pad the tails of a finished unit's 64 rows: four rows per pass, 16 lanes x 16-byte stores on each
   const bool no_pad = (a.p.flags & GTOK_SENT_NO_PAD) != 0, pad_nt = a.pad_nt != 0;
-  auto pad_rows = [&]() __attribute__((always_inline)) {
-    if (no_pad) return;
+  auto pad_rows_impl = [&](auto nt_tag) __attribute__((always_inline)) {
+    constexpr bool NT = decltype(nt_tag)::value;
     const int q = lane & 15;
+    const gtok_v4i pv = pad_vec(out_base, pad);
+    // (the padding is the tail of a wave's life - of the launch, for the last wave: the two cross-lane reads of the NEXT pass
+    // are requested before this pass's stores, so that their LDS round trip does not stand in the chain 16 times over)
+    int lr_n = __builtin_amdgcn_ds_bpermute((lane >> 4) << 2, lw);
+    int gr_n = __builtin_amdgcn_ds_bpermute((lane >> 4) << 2, done_row);   // (rows of a reordered batch are not neighbours)
     for (int it = 0; it < 16; ++it) {
-      const int r = it * 4 + (lane >> 4);
-      const int lr = __builtin_amdgcn_ds_bpermute(r << 2, lw);
-      const int gr = __builtin_amdgcn_ds_bpermute(r << 2, done_row);   // (rows of a reordered batch are not neighbours)
+      const int lr = lr_n, gr = gr_n;
       if (it * 4 >= done_cnt) break;
+      const int rn = min(it * 4 + 4, 60) + (lane >> 4);
+      lr_n = __builtin_amdgcn_ds_bpermute(rn << 2, lw);
+      gr_n = __builtin_amdgcn_ds_bpermute(rn << 2, done_row);
       if (gr >= 0) {
         out_t *__restrict__ rowp = out_base + (int64_t)gr * ld + lr;
         const int nrem = ld - lr, nvec = nrem / EV;
         _Pragma("clang loop vectorize(disable) unroll(disable)")
-        for (int t = q; t < nvec; t += 16) store_pad16(rowp + EV * t, pad, pad_nt);
+        for (int t = q; t < nvec; t += 16) store_pad16<NT>(rowp + EV * t, pv);
         if (q < (nrem & (EV - 1))) rowp[nvec * EV + q] = (out_t)pad;
       }
     }
+  };
+  auto pad_rows = [&]() __attribute__((always_inline)) {
+    if (no_pad) return;
+    if (pad_nt) pad_rows_impl(std::true_type{});
+    else pad_rows_impl(std::false_type{});
   };
 #ifdef GTOK_PHASE_TIMING   // profiling build only: cycle stamps per phase, left in the last 8 columns of the unit's first row
   uint64_t ts[5] = {0, 0, 0, 0, 0};

@@ -12,6 +12,7 @@ from collections.abc import Sequence
 from glob import glob
 from typing import Any, Dict, Iterator, List, Optional, Tuple
 
+import numpy as np
 import torch
 from torch.utils.data import Dataset
 
