@@ -35,6 +35,7 @@ class GtokCsr(ctypes.Structure):
         ("adj_rows", ctypes.c_void_p), ("adj_planes", ctypes.c_void_p), ("lane_order", ctypes.c_void_p),
         ("adj_words", ctypes.c_int32), ("adj_max_degree", ctypes.c_int32),
         ("graph_ids", ctypes.c_void_p), ("unit_ptr", ctypes.c_void_p), ("num_units", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("unit_info", ctypes.c_void_p),
     ]
 
 

@@ -70,6 +70,7 @@ class GraphBatch:
     graph_ids: Optional[torch.Tensor] = None     # a batch reordered for the lane-per-graph SENT kernel (ops.lane_sorted):
     unit_ptr: Optional[torch.Tensor] = None      # int32 [G] dataset index of every slot, int32 [units + 1] slots per wave
     num_units: int = 0
+    unit_info: Optional[torch.Tensor] = None     # int32 [units, 8]: per-unit descriptor (include/gtok.h: gtok_csr.unit_info)
     lane_sorted: Optional["GraphBatch"] = None   # the reordered copy of THIS batch (device batches, made on first use)
     adj_unusable: bool = False                   # gtok_csr_adjbits found a closure degree above 255: do not try again
 
@@ -91,7 +92,7 @@ class GraphBatch:
                           mv(self.rowptr), mv(self.col), mv(self.eorder), mv(self.nattr), mv(self.eattr),
                           self.flags, self.chunk_nodes, self.chunk_edges, self.max_degree, mv(self.rowptr8), mv(self.col8),
                           mv(self.adj_rows), mv(self.adj_planes), mv(self.lane_order), self.adj_words, self.adj_max_degree,
-                          0, mv(self.graph_ids), mv(self.unit_ptr), self.num_units)
+                          0, mv(self.graph_ids), mv(self.unit_ptr), self.num_units, mv(self.unit_info))
 
     def c_struct(self) -> GtokCsr:
         p = lambda t: None if t is None else t.data_ptr()
@@ -99,7 +100,7 @@ class GraphBatch:
                        p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr),
                        self.chunk_nodes, self.chunk_edges, self.max_degree, 0, p(self.rowptr8), p(self.col8),
                        p(self.adj_rows), p(self.adj_planes), p(self.lane_order), self.adj_words, self.adj_max_degree,
-                       p(self.graph_ids), p(self.unit_ptr), self.num_units, 0)
+                       p(self.graph_ids), p(self.unit_ptr), self.num_units, 0, p(self.unit_info))
 
     def node_counts(self) -> torch.Tensor:
         return self.node_ptr[1:] - self.node_ptr[:-1]

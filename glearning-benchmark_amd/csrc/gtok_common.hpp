@@ -132,11 +132,10 @@ struct Tickets {
 // used it last has FINISHED: every slot carries a HIP event recorded behind its launch, and take_queue_slot waits for
 // that event when the ring has wrapped onto a launch still in flight (256+ launches queued without a
 // synchronisation) - two live launches never share counters.  Launches issued while the stream is being CAPTURED
-// into a hipGraph get a slot of their own from a reserved pool that is never recycled (a replay must find the
-// counters it was captured with, and event queries are not capturable): at most kGraphSlots captured launches of the
-// ticket-scheduled kernels per device and process - the 65th capture fails with GTOK_E_GRAPH_SLOTS (capture once and
-// replay; a graph that is re-captured per epoch or per shape should pin one of the kernels without tickets).  The first
-// call on a device allocates (not capturable: warm up once before capturing).
+// into a hipGraph get a block of their own from a reserved pool (a replay must find the counters it was captured with,
+// and event queries are not capturable), which the graph hands back when it is destroyed (release_graph_slot): at most
+// kGraphSlots captured launches of the ticket-scheduled kernels in LIVE graphs per device - one more fails with
+// GTOK_E_GRAPH_SLOTS.  The first call on a device allocates (not capturable: warm up once before capturing).
 struct QueueSlot {
   int *counters = nullptr;
   int index = -1;       // ring index, -1: reserved (captured) slot - nothing to record
@@ -150,9 +149,22 @@ struct QueueRing {
   hipEvent_t ev[kMaxDev][kSlots] = {};
   bool used[kMaxDev][kSlots] = {};
   unsigned seq[kMaxDev] = {};
-  int graph_taken[kMaxDev] = {};
+  bool graph_used[kMaxDev][kGraphSlots] = {};   // reserved blocks held by live hipGraphs
 };
 inline QueueRing &queue_ring() { static QueueRing r; return r; }
+
+// A reserved block goes back to the pool when the hipGraph that captured its launch is destroyed (and every executable
+// graph instantiated from it: they hold their own reference): a HIP user object owned by the graph carries the block's
+// (device, index) and hands it back from its destructor - which runs on a runtime thread and calls no HIP function.  The
+// block is clean then: the last wave of every launch re-arms its counters.
+inline void release_graph_slot(void *tag) {
+  const uintptr_t t = reinterpret_cast<uintptr_t>(tag) - 1;
+  const int dev = (int)(t / kGraphSlots), idx = (int)(t % kGraphSlots);
+  if (dev < 0 || dev >= kMaxDev) return;
+  QueueRing &r = queue_ring();
+  std::lock_guard<std::mutex> lock(r.mu);
+  r.graph_used[dev][idx] = false;
+}
 
 inline QueueSlot take_queue_slot(int dev, hipStream_t stream) {
   QueueSlot out;
@@ -173,8 +185,30 @@ inline QueueSlot take_queue_slot(int dev, hipStream_t stream) {
     }
     out.dev = dev;
     if (cap != hipStreamCaptureStatusNone) {
-      if (r.graph_taken[dev] >= kGraphSlots) { out.graph_pool_empty = true; return out; }
-      out.counters = r.mem[dev] + (size_t)kSlotInts * (kSlots + r.graph_taken[dev]++);
+      int idx = -1;
+      for (int i = 0; i < kGraphSlots; ++i)
+        if (!r.graph_used[dev][i]) { idx = i; break; }
+      if (idx < 0) { out.graph_pool_empty = true; return out; }
+      r.graph_used[dev][idx] = true;                    // (stays taken for the life of the process if the hand-over below fails)
+      out.counters = r.mem[dev] + (size_t)kSlotInts * (kSlots + idx);
+      // tie the block to the capturing graph's lifetime
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      hipGraph_t graph = nullptr;
+      unsigned long long id = 0;
+      if (hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, nullptr, nullptr) == hipSuccess && graph) {
+        hipUserObject_t obj = nullptr;
+        void *tag = reinterpret_cast<void *>((uintptr_t)dev * kGraphSlots + idx + 1);
+        if (hipUserObjectCreate(&obj, tag, release_graph_slot, 1, hipUserObjectNoDestructorSync) == hipSuccess) {
+          if (hipGraphRetainUserObject(graph, obj, 1, hipGraphUserObjectMove) != hipSuccess) {
+            (void)hipGetLastError();
+            r.graph_used[dev][idx] = true;              // keep it reserved: the destructor must not free a block still in a graph
+          }
+        } else {
+          (void)hipGetLastError();
+        }
+      } else {
+        (void)hipGetLastError();
+      }
       return out;
     }
     // the ring index is this call's alone until the ring wraps again (kSlots launches later): the wait for the launch

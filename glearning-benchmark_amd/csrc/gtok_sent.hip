@@ -86,6 +86,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   const int K = sent_epochs(p);
   if ((int64_t)g->num_graphs * K > 0x7FFFFFFF / 2) return GTOK_E_TOO_LARGE;   // rows of the [K, G, ld] slab are counted in 32 bits
   if (p->labeled && (!g->nattr || !g->eattr)) return GTOK_E_INVAL;
+  if (g->unit_info && !g->unit_ptr) return GTOK_E_INVAL;     // the per-unit records describe the units of unit_ptr
   if (g->max_nodes > GTOK_MAX_NODES) return GTOK_E_TOO_LARGE;
   if (g->max_edges > 60000) return GTOK_E_TOO_LARGE;   // neighbour lists are staged as uint16 in LDS
   // tokens are staged as uint16
@@ -149,6 +150,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
       a.off_nat = off; off += align_up(a.cap_n + 8, 16);  // unlabelled: the node -> visit index table alone
     }
     a.lds = align_up(off, 16);
+    if (a.lds < 512) a.lds = 512;       // (a wave's slice also carries its last unit's 64 (row, pad start) pairs: the shared padding)
     if (a.lds > 64 * 1024) return GTOK_E_TOO_LARGE;
     // counter planes: degree < 2^P; an unknown max_degree is covered by P = 6 (a node of a simple graph with <= 64 nodes has < 64 neighbours)
     const bool p3 = g->max_degree > 0 && g->max_degree <= 15;
@@ -182,14 +184,15 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     // a reordered batch: one 16-wave workgroup per CU (the kernel pairs long units with short ones on every SIMD) when a
     // wave's share of the CU's 160 KB is enough and the batch fills the chip; else one-wave workgroups with the units spread
     const char *wg = std::getenv("GTOK_LANE_PER_CU");   // tuning knob: 0 = never
-    // (+ 16 bytes: the workgroup's ticket counter, from which its waves draw their units after the first round)
-    if (g->unit_ptr && a.lds * 16 + 16 <= 160 * 1024 && vunits >= 4 * ncu && !(wg && wg[0] == '0')) {
+    // (+ kLaneWgShared bytes: the workgroup's ticket counter, from which its waves draw their units after the first round,
+    // and the words through which they share the padding of their last units)
+    if (g->unit_ptr && a.lds * 16 + kLaneWgShared <= 160 * 1024 && vunits >= 4 * ncu && !(wg && wg[0] == '0')) {
       // (the opt-in to more than 64 KB of dynamic LDS is per kernel and per device: a host-side call of a microsecond)
       const bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       int occ16 = 0;
       const char *ww = std::getenv("GTOK_LANE_WG_WAVES");   // tuning knob: 8 = two 8-wave workgroups per CU
       const int wgw = (ww && ww[0] == '8') ? 8 : 16;
-      const size_t wg_lds = (size_t)a.lds * wgw + (wgw == 16 ? 16 : 8);
+      const size_t wg_lds = (size_t)a.lds * wgw + kLaneWgShared;
       if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 64 * wgw, wg_lds) == hipSuccess && occ16 >= 16 / wgw) {
         hipLaunchKernelGGL(kern, dim3(ncu * (16 / wgw)), dim3(64 * wgw), wg_lds, (hipStream_t)stream, a);
         return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;

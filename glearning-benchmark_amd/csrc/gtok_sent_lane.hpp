@@ -137,6 +137,8 @@ __device__ __forceinline__ void store_win2(uint16_t *p, uint64_t w0, uint64_t w1
   *reinterpret_cast<I32x4 *>(p) = I32x4{(int)(uint32_t)w0, (int)(uint32_t)(w0 >> 32), (int)(uint32_t)w1, (int)(uint32_t)(w1 >> 32)};
 }
 
+constexpr int kLaneWgShared = 256;   // bytes of workgroup-shared LDS behind the waves' slices (per-CU launch)
+
 struct SentLaneArgs {
   gtok_csr g;
   gtok_sent_params p;
@@ -190,20 +192,31 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   // pointers / 16 type bytes per lane and load), packed to bytes and written to LDS in two phases so that at most
   // ~64 staging registers are live: A = row pointers + types, B = neighbour ids.
   constexpr int UR = 8, UC = 16, UE = 4, UN = 2;   // vectors per lane held in registers (chunks beyond: tail loops)
-  struct Hdr { int g0, gl, N0, N1; int64_t E0, E1; int nb0, nfull, n, e; int64_t e0; bool valid; };
+  struct Hdr { int g0, gl, N0, N1; int64_t E0, E1; int nb0, nfull, n, e; int64_t e0; bool valid; int g; };
   auto header = [&](int unit) __attribute__((always_inline)) -> Hdr {
     Hdr h;
-    if (a.g.unit_ptr) { h.g0 = sload(a.g.unit_ptr, unit); h.gl = sload(a.g.unit_ptr, unit + 1); }   // reordered batch: <= 64 slots
-    else { h.g0 = unit * 64; h.gl = min(h.g0 + 64, G); }
-    h.N0 = sload(a.g.node_ptr, h.g0); h.N1 = sload(a.g.node_ptr, h.gl);
-    h.E0 = sload(a.g.edge_ptr, h.g0); h.E1 = sload(a.g.edge_ptr, h.gl);
+    if (a.g.unit_info) {                 // one 32-byte record: the chunk's loads can go out right behind this one round trip
+      const int32_t *ui = a.g.unit_info + 8 * (int64_t)unit;
+      h.g0 = sload(ui, 0); h.gl = sload(ui, 1); h.N0 = sload(ui, 2); h.N1 = sload(ui, 3);
+      h.E0 = (int64_t)(((uint64_t)(uint32_t)sload(ui, 5) << 32) | (uint32_t)sload(ui, 4));
+      h.E1 = (int64_t)(((uint64_t)(uint32_t)sload(ui, 7) << 32) | (uint32_t)sload(ui, 6));
+    } else {
+      if (a.g.unit_ptr) { h.g0 = sload(a.g.unit_ptr, unit); h.gl = sload(a.g.unit_ptr, unit + 1); }   // reordered batch: <= 64 slots
+      else { h.g0 = unit * 64; h.gl = min(h.g0 + 64, G); }
+      h.N0 = sload(a.g.node_ptr, h.g0); h.N1 = sload(a.g.node_ptr, h.gl);
+      h.E0 = sload(a.g.edge_ptr, h.g0); h.E1 = sload(a.g.edge_ptr, h.gl);
+    }
     h.valid = h.g0 + lane < h.gl;
     h.nb0 = h.N0; h.nfull = 0; h.e0 = h.E0; h.e = 0;
+    h.g = h.g0 + lane;
     if (h.valid) {
       h.nb0 = a.g.node_ptr[h.g0 + lane];
       h.nfull = a.g.node_ptr[h.g0 + lane + 1] - h.nb0;
       h.e0 = a.g.edge_ptr[h.g0 + lane];
       h.e = min((int)(a.g.edge_ptr[h.g0 + lane + 1] - h.e0), a.g.max_edges);
+      // the graph's dataset index: output row, out_len / query entry and RNG identity (slot = where its CSR is stored) -
+      // asked for here, with the other per-lane loads, not behind the staging fence where its round trip stood alone
+      if (a.g.graph_ids) h.g = a.g.graph_ids[h.g0 + lane];
     }
     h.n = min(h.nfull, a.maxn);
     return h;
@@ -342,9 +355,11 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   // counter in the workgroup's LDS.  (With the static split of round 3 - every wave one unit of every round, priorities
   // by quarter - the low-priority waves of a SIMD ran their later units alone at half the issue rate: 1 M molecules took
   // 6.5 x the time of 249 k.)
+  // the workgroup's shared words behind the waves' slices (kLaneWgShared bytes, zeroed here): [0] the ticket counter,
+  // [16 + w] wave w's "last unit published" flag, [32 + w] the next chunk of its padding to hand out (final phase below)
   int *wg_ticket = reinterpret_cast<int *>(smem_all + (size_t)wg_waves * a.lds);
   if (percu) {
-    if (threadIdx.x == 0) *wg_ticket = 0;
+    if (threadIdx.x < kLaneWgShared / 4) wg_ticket[threadIdx.x] = 0;
     __syncthreads();
   }
   // first unit: the static deal of the first round (per-CU workgroups), or the one-wave workgroup's own index
@@ -395,10 +410,8 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
 #ifdef GTOK_PHASE_TIMING
     ts[1] = __builtin_amdgcn_s_memtime();
 #endif
-    const int slot = h.g0 + lane;
     const bool valid = h.valid;
-    // the graph's dataset index: output row, out_len / query entry and RNG identity (slot = where its CSR is stored)
-    const int g = valid && a.g.graph_ids ? a.g.graph_ids[slot] : slot;
+    const int g = h.g;     // the graph's dataset index (header)
     const int n = h.n, e = h.e;
     const int rbase = (h.nb0 - h.N0) + lane, cbase = (int)(h.e0 - h.E0), nbase = h.nb0 - h.N0;
 
@@ -753,7 +766,60 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       vu = spread(cursor);
     }
   }
-  if (done_cnt > 0) pad_rows();
+  // ---- the last unit's padding.  It is the tail of the wave's life - for the last wave of the launch, of the launch: 16
+  // passes of cross-lane reads and stores, ~3 us in which the rest of the CU idles.  In the per-CU launch the waves of a
+  // workgroup therefore pad TOGETHER: each publishes its last unit's (row, pad start) pairs in its own LDS slice (free now)
+  // and then takes 4-row chunks - of whichever wave has published - until all 16 have published and every chunk is taken.
+  // Waves that finish early wait (s_sleep) for the late ones, whose padding is then shared sixteen ways.
+  if (percu && !no_pad) {
+    int *pub = reinterpret_cast<int *>(smem);
+    int *flags = wg_ticket + 16, *next = wg_ticket + 32;
+    wave_sync();                                           // every lane is through with the staged chunk
+    pub[lane] = done_cnt > 0 ? done_row : -1;
+    pub[kWave + lane] = lw;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(flags + wave, 1 + done_cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const gtok_v4i pv = pad_vec(out_base, pad);
+    const int q = lane & 15;
+    for (;;) {
+      int fl = 0, nx = 0;
+      if (lane < wg_waves) {
+        fl = __hip_atomic_load(flags + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        nx = __hip_atomic_load(next + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      const int nch = (fl + 2) >> 2;                       // chunks of 4 rows in fl - 1 rows (none while fl == 0)
+      const uint64_t avail = __ballot(lane < wg_waves && nx < nch);
+      const uint64_t pending = __ballot(lane < wg_waves && fl == 0);
+      if (avail) {
+        const int w = __builtin_ctzll(avail);
+        int c = 0;
+        if (lane == 0) c = __hip_atomic_fetch_add(next + w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c = uni(c);
+        if (c < __builtin_amdgcn_readlane(nch, w)) {
+          const int *pw = reinterpret_cast<const int *>(smem_all + (size_t)w * a.lds);
+          const int r = c * 4 + (lane >> 4);
+          const int gr = pw[r], lr = pw[kWave + r];
+          if (gr >= 0) {
+            out_t *__restrict__ rowp = out_base + (int64_t)gr * ld + lr;
+            const int nrem = ld - lr, nvec = nrem / EV;
+            if (pad_nt) {
+              _Pragma("clang loop vectorize(disable) unroll(disable)")
+              for (int t = q; t < nvec; t += 16) store_pad16<true>(rowp + EV * t, pv);
+            } else {
+              _Pragma("clang loop vectorize(disable) unroll(disable)")
+              for (int t = q; t < nvec; t += 16) store_pad16<false>(rowp + EV * t, pv);
+            }
+            if (q < (nrem & (EV - 1))) rowp[nvec * EV + q] = (out_t)pad;
+          }
+        }
+        continue;
+      }
+      if (!pending) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+  } else if (done_cnt > 0) {
+    pad_rows();
+  }
 #ifdef GTOK_PHASE_TIMING
   stamps_out();
 #endif

@@ -192,6 +192,13 @@ def lane_sorted(batch: GraphBatch) -> Optional[GraphBatch]:
     out.graph_ids = perm.to(torch.int32)
     out.unit_ptr = torch.from_numpy(starts.astype(np.int32)).to(dev)
     out.num_units = int(starts.size) - 1
+    # per-unit descriptor (gtok_csr.unit_info): slots, node range and entry range of every unit in one 32-byte record
+    info = np.empty((out.num_units, 8), np.int32)
+    info[:, 0], info[:, 1] = starts[:-1], starts[1:]
+    info[:, 2], info[:, 3] = cn[starts[:-1]], cn[starts[1:]]
+    e01 = np.stack([ce[starts[:-1]], ce[starts[1:]]], 1).astype(np.int64)
+    info[:, 4:8] = e01.view(np.int32).reshape(-1, 4)          # (low, high) words of the two int64 entry offsets
+    out.unit_info = torch.from_numpy(info).to(dev)
     pack8(out)
     batch.lane_sorted = out
     return out

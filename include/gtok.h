@@ -79,8 +79,9 @@ extern "C" {
 #define GTOK_E_LAUNCH (-3)    /* hipLaunchKernel reported an error              */
 #define GTOK_E_NO_DEVICE (-4) /* no gfx950 device visible                       */
 #define GTOK_E_GRAPH_SLOTS (-5) /* a launch captured into a hipGraph needed a reserved block of work-queue counters and all 64
-                                   per device are taken: the ticket-scheduled kernels ("sent_lds_kernel", "ibtt_zinc_lane_kernel")
-                                   keep one for the life of the process per CAPTURED launch - capture once and replay        */
+                                   per device are held by LIVE graphs: the ticket-scheduled kernels ("sent_lds_kernel",
+                                   "ibtt_zinc_lane_kernel") keep one per captured launch for as long as the capturing graph
+                                   (and the executable graphs made from it) exist - destroying a graph returns its blocks   */
 
 #define GTOK_MAX_NODES 512 /* SENT adjacency bit-matrix rows per wave (LDS)  */
 
@@ -133,6 +134,12 @@ typedef struct gtok_csr {
   const int32_t *unit_ptr;
   int32_t num_units;
   int32_t reserved2;
+  /* Optional (NULL = derived from unit_ptr / node_ptr / edge_ptr by the kernel; ABI v4): one 32-byte record per unit of a
+   * reordered batch, unit_info[8 u ..] = { unit_ptr[u], unit_ptr[u + 1], node_ptr[g0], node_ptr[gl], edge_ptr[g0] (low,
+   * high word), edge_ptr[gl] (low, high) } - everything a wave needs to request its unit's chunk arrives in ONE scalar
+   * load instead of a chain of two (a unit's staging is a chain of dependent HBM round trips: ~2 us each at launch start,
+   * when every resident wave stages at once).                                                                      */
+  const int32_t *unit_info;
 } gtok_csr;
 
 /* LUT layout for gtok_ibtt_zinc (int32 vocab ids; an absent token holds pad_id

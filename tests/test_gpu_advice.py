@@ -68,12 +68,48 @@ print("CAPTURED", len(graphs), "ERR", err)
 
 
 def test_captured_launches_beyond_the_reserved_pool_fail_with_their_own_code():
-    """64 reserved counter blocks per device for captured launches of the ticket-scheduled kernels: the 65th capture
-    reports GTOK_E_GRAPH_SLOTS (its own process: the pool is never refilled)."""
+    """64 reserved counter blocks per device for captured launches of the ticket-scheduled kernels in LIVE graphs: the
+    65th graph kept alive reports GTOK_E_GRAPH_SLOTS."""
     r = subprocess.run([sys.executable, "-c", _CAPTURE, ROOT], capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("CAPTURED")]
     assert line, r.stdout[-2000:] + r.stderr[-2000:]
     assert line[0].startswith("CAPTURED 64 ERR (64,") and "GTOK_E_GRAPH_SLOTS" in line[0], line[0]
+
+
+_CAPTURE_CYCLES = r"""
+import gc, importlib, os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from _util import both, gtok, orc
+os.environ["GTOK_SENT_KERNEL"] = "lds"
+d = gtok.synth.zinc_like(600, seed=1)
+batch, coo = both(d, False)
+b = batch.to("cuda:0")
+out = (torch.empty((600, 256), dtype=torch.int32, device="cuda:0"), torch.empty(600, dtype=torch.int32, device="cuda:0"))
+gtok.ops.sent(b, 40, 1024, 0, 0, ld=256, out=out)
+torch.cuda.synchronize()
+ok = 0
+for i in range(200):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gtok.ops.sent(b, 40, 1024, 0, i, ld=256, out=out)
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    if i % 50 == 49:
+        ref, rln = orc.sent(coo, 40, 1024, 0, i, ld=256)
+        assert np.array_equal(out[0].cpu().numpy(), ref) and np.array_equal(out[1].cpu().numpy(), rln)
+    del g
+    gc.collect()
+    ok += 1
+print("CYCLES", ok)
+"""
+
+
+def test_reserved_counter_blocks_return_when_their_graph_is_destroyed():
+    """200 capture / replay / destroy cycles of a sent_lds_kernel launch - the block a captured launch
+    reserves goes back to the pool with its graph (a HIP user object owned by the graph), so re-capturing per epoch or per
+    shape never runs the pool dry; replays of recycled blocks still give the oracle's tokens."""
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_CYCLES, ROOT], capture_output=True, text=True, timeout=900)
+    assert "CYCLES 200" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_text_vocab_table_verifies_token_bytes():
