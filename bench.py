@@ -272,8 +272,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None, help="graphs in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ibtt", action="store_true")
-    ap.add_argument("--rows", default="padded", choices=["padded", "unpadded"],
-                    help="unpadded: the timed step itself runs with GTOK_SENT_NO_PAD (counter passes of that flavour; the headline stays 'padded')")
+    ap.add_argument("--rows", default="padded", choices=["padded", "unpadded", "u16", "u16padded"],
+                    help="the flavour the timed step itself runs in (counter passes of that flavour; the headline stays 'padded'): "
+                         "unpadded = GTOK_SENT_NO_PAD, u16 = GTOK_SENT_U16 | GTOK_SENT_NO_PAD (16-bit rows, tokens only), u16padded = GTOK_SENT_U16")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 1 s back-to-back leg")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary section (call-site throughput through the Dataset classes)")
     ap.add_argument("--no-unpadded", action="store_true", help="skip the GTOK_SENT_NO_PAD leg (profiling runs: one launch flavour per kernel name)")
@@ -335,19 +336,21 @@ def main():
     E = args.epochs_per_launch or (24 if args.workload == "zinc_subset" else 1)
     E = max(1, min(E, args.steps))
     n_launch = -(-args.steps // E)
-    ids = torch.empty((E * G, ld), dtype=torch.int32, device=dev)
+    rows_u16, rows_pad = args.rows.startswith("u16"), args.rows in ("padded", "u16padded")
+    ids = torch.empty((E * G, ld), dtype=torch.int16 if rows_u16 else torch.int32, device=dev)
     lens_all = torch.empty((n_launch * E, G), dtype=torch.int32, device=dev)
     lens = [lens_all[k] for k in range(args.steps)]
     scratch_len = torch.empty((E * G,), dtype=torch.int32, device=dev)
 
     def step(k, ln):          # ONE epoch in one launch (secondary legs and the end-of-run parity check)
-        gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(ids[:G], ln.view(-1)[:G]), pad=args.rows == "padded", **kw)
+        gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(ids[:G], ln.view(-1)[:G]), pad=rows_pad, u16=rows_u16, **kw)
 
-    def launch(j, ln, count=E, first=None, pad=None, u16=False, out_ids=None):
+    def launch(j, ln, count=E, first=None, pad=None, u16=None, out_ids=None):
         """epochs first .. first + count - 1 (default: launch j of the timed region) in one gtok_sent call"""
         o = ids if out_ids is None else out_ids
         gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=j * E if first is None else first, ld=ld,
-                      out=(o[:count * G], ln.view(-1)[:count * G]), pad=(args.rows == "padded") if pad is None else pad, epochs=count, u16=u16, **kw)
+                      out=(o[:count * G], ln.view(-1)[:count * G]), pad=rows_pad if pad is None else pad, epochs=count,
+                      u16=(rows_u16 if out_ids is None else True) if u16 is None else u16, **kw)
 
     def timed_launches(first_epoch):
         """the K steps: n_launch calls, epochs first_epoch .. first_epoch + K - 1, lengths of step k in lens_all[k]"""
@@ -394,7 +397,7 @@ def main():
     # beside the headline: the same steps with GTOK_SENT_NO_PAD (rows written up to their length only - what
     # TokenizedGraphDataset uses, its readers go through `len`); not the headline because the C ABI's documented output is the padded slab
     nopad_ms = ragged = u16_ms = u16p_ms = ragged16 = None
-    if zinc and not args.no_unpadded:
+    if zinc and not args.no_unpadded and not rows_u16:
         per_step = lambda ms: float(np.sum(ms)) / (n_launch * E)
         _, npm = timed_loop(lambda j: launch(j, scratch_len, pad=False), n_launch, multi, per_launch_events=False)
         nopad_ms = per_step(npm)
@@ -454,7 +457,7 @@ def main():
         layout["adjbits"] = dict(ms=round(ms, 3), bytes=nbytes(fb.adj_rows, fb.adj_planes))
         ms, lo = once(lambda: gtok.ops._lane_order(fb, max(1, max_len)))
         layout["lane_order"] = dict(ms=round(ms, 3), bytes=nbytes(lo))
-    if layout:
+    if layout and not rows_u16:
         saved = {k: os.environ.get(k) for k in ("GTOK_NO_LANE_SORT", "GTOK_NO_PACK8", "GTOK_NO_ADJBITS")}
         os.environ.update(GTOK_NO_LANE_SORT="1", GTOK_NO_PACK8="1", GTOK_NO_ADJBITS="1")
         try:
@@ -511,7 +514,7 @@ def main():
     # row come from the tokens (sent_decode); the entries behind them are taken in proportion (E_g * visited / N_g), so this
     # second yardstick is an estimate, reported beside the fixed one of SURVEY section 8d
     trunc = None
-    if not zinc:
+    if not zinc and not rows_u16:
         step(args.warmup, scratch_len)
         # (count-only decode: capacities of 0 - the row is read to its end; round 3 passed capacities of 4 to a decoder that
         # stopped at the first entry that did not fit and reported ~5 nodes per walk where the walks reach ~68)
@@ -537,7 +540,7 @@ def main():
                steps=args.steps, warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 5),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
                tokens_per_sec=round(tokens_per_sec, 1),
-               config=dict(workload=f"{args.workload}: {wl['desc']}" + ("" if args.rows == "padded" else " [GTOK_SENT_NO_PAD rows]"), graphs_per_gpu=G, max_len=max_len,
+               config=dict(workload=f"{args.workload}: {wl['desc']}" + ("" if args.rows == "padded" else f" [--rows {args.rows}]"), graphs_per_gpu=G, max_len=max_len,
                            slab_width=ld, slab_width_mode=args.ld, avg_tokens_per_graph=round(tokens_per_step_rank / G, 2),
                            parallelism=f"graph-sharded x{world}, no data-path collective",
                            epochs_per_launch=E, launches_in_timed_region=n_launch,
@@ -778,7 +781,7 @@ def main():
             out["boundary"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     # CPU baseline: the oracle (a port, not the reference's Python) on a bounded sample, rank 0, N=1 only
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not rows_u16:
         try:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as orc

@@ -4,7 +4,7 @@
 #   gpurun --timeout 1200 -- 'bash profiles/tools/collect.sh r02'
 # Everything lands in gpurun_out/collect_<tag>/; profiles/tools/collect_merge.py turns it into profiles/<tag>/.
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/collect_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -27,10 +27,19 @@ for wl in zinc_full synth_er synth_mix zinc_subset; do
     step prof $out/pmc_${wl}_$name.log timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex gtok --output-format csv -d $out/pmc_${wl}_$name -o p -- python3 bench.py --steps 5 --warmup 1 --workload $wl --no-cpu-baseline --no-unpadded --no-boundary --no-sustained
   done
 done
-# the tokens-only flavour of the headline kernel (GTOK_SENT_NO_PAD): what reaches the L2's memory side when no pad tail is written
-for grp in "FETCH_SIZE" "WRITE_SIZE"; do
-  step prof $out/pmc_nopad_$grp.log timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex sent_lane --output-format csv -d $out/pmc_nopad_$grp -o p -- python3 bench.py --steps 5 --warmup 1 --rows unpadded --no-cpu-baseline --no-unpadded --no-boundary --no-sustained --no-ibtt
+# the other row flavours of the headline kernel: what reaches the L2's memory side when no pad tail is written (GTOK_SENT_NO_PAD),
+# and with rows of 16-bit ids (GTOK_SENT_U16, with and without padding)
+for rows in unpadded u16 u16padded; do
+  for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+    step prof $out/pmc_${rows}_$grp.log timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex sent_lane --output-format csv -d $out/pmc_${rows}_$grp -o p -- python3 bench.py --steps 5 --warmup 1 --rows $rows --no-cpu-baseline --no-unpadded --no-boundary --no-sustained --no-ibtt
+  done
 done
+# beyond one round of resident waves: 1,000,000 molecules in one launch (bit-exact against the oracle, then timed), and the
+# timing matrix of round 4 (row flavours x K epochs per launch x corpus sizes)
+if [ "${SKIP_EXTRAS:-0}" != 1 ]; then      # (gpurun's limit is 20 minutes per call: SKIP_EXTRAS=1 leaves these two to a call of their own)
+  step run_to $out/check_1m.txt timeout -k 10 500 python3 profiles/tools/check_1m.py
+  step run_to $out/time_r04.txt timeout -k 10 400 python3 profiles/tools/time_r04.py
+fi
 # keep what collect_merge.py reads: our kernels' counter rows and the stats tables (gpurun returns <= 64 MiB)
 find $out -name '*_kernel_trace.csv' -delete; find $out -name '*_agent_info.csv' -delete
 python3 - $out <<'PY'
