@@ -815,7 +815,10 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
         continue;
       }
       if (!pending) break;
-      __builtin_amdgcn_s_sleep(4);
+#ifndef GTOK_COOP_SLEEP
+#define GTOK_COOP_SLEEP 16
+#endif
+      __builtin_amdgcn_s_sleep(GTOK_COOP_SLEEP);   // ~1 k cycles between looks: a waiting wave must not take issue slots from the walks still running
     }
   } else if (done_cnt > 0) {
     pad_rows();

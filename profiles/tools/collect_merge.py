@@ -10,6 +10,8 @@ src, dst = f"gpurun_out/collect_{tag}", f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
 traffic = {}
 for wl in ("zinc_full", "synth_er", "synth_mix", "zinc_subset"):
+    if not os.path.exists(f"{src}/bench_{wl}.json"):
+        continue
     shutil.copy(f"{src}/bench_{wl}.json", f"{dst}/bench_{wl}_final.json")
     for f in glob.glob(f"{src}/stats_{wl}/**/*_kernel_stats.csv", recursive=True):
         shutil.copy(f, f"{dst}/bench_{wl}_kernel_stats_final.csv")
@@ -68,5 +70,9 @@ for rows, fname in (("unpadded", "nopad"), ("u16", "u16"), ("u16padded", "u16pad
 for extra in ("check_1m.txt", "time_r04.txt"):
     if os.path.exists(f"{src}/{extra}"):
         shutil.copy(f"{src}/{extra}", f"{dst}/{extra}")
+old = json.load(open("profiles/pmc_traffic.json")) if os.path.exists("profiles/pmc_traffic.json") else {}
+old = {k: v for k, v in old.items() if v.get("source", "").startswith(dst + "/")}      # entries of this round that were not re-collected
+old.update(traffic)
+traffic = old
 json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
