@@ -396,7 +396,7 @@ def main():
     wall = float(tmax.item())
     # beside the headline: the same steps with GTOK_SENT_NO_PAD (rows written up to their length only - what
     # TokenizedGraphDataset uses, its readers go through `len`); not the headline because the C ABI's documented output is the padded slab
-    nopad_ms = ragged = u16_ms = u16p_ms = ragged16 = None
+    nopad_ms = ragged = u16_ms = u16p_ms = ragged16 = epoch_loop = None
     if zinc and not args.no_unpadded and not rows_u16:
         per_step = lambda ms: float(np.sum(ms)) / (n_launch * E)
         _, npm = timed_loop(lambda j: launch(j, scratch_len, pad=False), n_launch, multi, per_launch_events=False)
@@ -427,6 +427,21 @@ def main():
         _, rgm = timed_loop(ragged16_step, n_launch, multi, per_launch_events=False)
         ragged16 = per_step(rgm)
         del ids16
+        # what an epoch of the dataset classes costs on the device: Graph2TrailTokenizer.epochs_for(G) epochs per launch as 16-bit
+        # rows without padding (agtt.TokenizedGraphDataset.tokenize_epoch_u16 / the tokenizer's _serve)
+        Kd = max(1, min(32, gtok.Graph2TrailTokenizer.EPOCH_WALKS // max(1, G)))
+        idsk = torch.empty((Kd * G, ld), dtype=torch.int16, device=dev)
+        lnk = torch.empty((Kd * G,), dtype=torch.int32, device=dev)
+        fk = lambda j: gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=j * Kd, ld=ld, out=(idsk, lnk), pad=False, epochs=Kd, u16=True, **kw)
+        for _ in range(3):
+            fk(0)
+        nk = max(3, -(-args.steps // Kd))
+        _, km = timed_loop(fk, nk, multi, per_launch_events=False)
+        epoch_loop = dict(epochs_per_launch=Kd, launches=nk, ms_per_launch=round(float(np.mean(km)), 4), ms_per_epoch=round(float(np.mean(km)) / Kd, 5),
+                          graphs_per_sec=round(G * Kd / float(np.mean(km)) * 1e3, 1),
+                          note="the dataset classes' epoch: tokenizer.epochs_for(G) epochs per gtok_sent launch, GTOK_SENT_U16 | GTOK_SENT_NO_PAD rows "
+                               "read in place by gtok_collate_packed / EpochRows")
+        del idsk, lnk
     log(f"[bench] timed region done: {wall / args.steps * 1e3:.5f} ms per step ({n_launch} launches of {E} epochs)")
     # one-off layout steps ops.sent did inside the warm-up (like the CSR build: once per resident batch, never per epoch):
     # their time and bytes, re-measured on a fresh copy of the batch, and the kernel WITHOUT any of them (what a C-ABI
@@ -569,6 +584,7 @@ def main():
                                note="GTOK_SENT_U16: rows of 16-bit ids straight from the walk's token windows (no unpacking, half the bytes); "
                                     "unpadded = + GTOK_SENT_NO_PAD: what TokenizedGraphDataset / gtok_collate_packed(row_ptr NULL) / EpochRows read in place, "
                                     "no second pass; packed = + gtok_row_offsets + gtok_pack_rows_u16 (16-bit rows back to back: the compact all-gather's payload)")
+        out["epoch_loop"] = epoch_loop
 
     log("[bench] headline assembled; secondary legs follow")
     # IBTT serialiser on the same corpus (second half of the metric; outside the timed region)

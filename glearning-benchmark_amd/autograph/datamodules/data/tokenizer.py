@@ -96,12 +96,14 @@ class Graph2TrailTokenizer:
                          remap_zinc=remap_zinc, pad_id=self.pad, graph_base=graph_base, query=query, ld=ld, out=out, pad=pad,
                          epochs=epochs, u16=u16)
 
-    EPOCH_WALKS = 1 << 18         # walks that fill the chip once: 4,096 resident waves x 64 lanes (sent_lane_kernel)
+    EPOCH_WALKS = 1 << 20         # walks per launch: four rounds of the 4,096 resident waves x 64 lanes of sent_lane_kernel - units that
+                                  # are staged and padded while other waves walk cost less than those of a one-round launch (ZINC-full as
+                                  # 16-bit rows: 0.0573 ms per epoch at 4 epochs per launch against 0.0648 at one)
 
     def epochs_for(self, num_graphs: int) -> int:
         """How many epochs of a split of `num_graphs` graphs one launch should carry.  The reference re-tokenizes a split
         every epoch (trainer/train_agtt.py:246-250, epoch loop :676-680) and a trail depends on (seed, epoch, graph) only:
-        a 12 k-molecule split (configs/agtt_zinc.yaml:4 `subset: true`) tokenizes 21 epochs in the time of two."""
+        a 12 k-molecule split (configs/agtt_zinc.yaml:4 `subset: true`) tokenizes 32 epochs in the time of four."""
         if self.epochs_per_launch is not None:
             return max(1, int(self.epochs_per_launch))
         return max(1, min(32, self.EPOCH_WALKS // max(1, int(num_graphs))))

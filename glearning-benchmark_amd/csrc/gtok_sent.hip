@@ -38,6 +38,11 @@ constexpr int GTOK_BLANE_MIN_GRAPHS = 20000;
 // 0 = lane-per-graph, 1 = register-resident wave-per-graph, 2 = LDS bit matrix, 3 = lane-per-graph over the adjacency
 // bit-matrix mirror.  GTOK_SENT_KERNEL=lane|reg|lds|blane pins a kernel where it is applicable (tests run every path).
 static inline int sent_epochs(const gtok_sent_params *p) { return p->epoch_count > 1 ? p->epoch_count : 1; }
+static inline int ncu_hint() {     // compute units of the current device (256 on MI355X)
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  return ncu > 0 ? ncu : 256;
+}
 
 static int choose_sent_kernel(const gtok_csr *g, const gtok_sent_params *p) {
   const int maxn = g->max_nodes > 0 ? g->max_nodes : 1;
@@ -176,8 +181,15 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.units = g->unit_ptr ? g->num_units : (g->num_graphs + 63) / 64;
     a.epochs = K;
     a.pad_nt = pad_nt;
+    a.epoch_major = 0;     // set below, once the launch shape is known
     if ((int64_t)a.units * K > 0x7FFFFFFF / 64) return GTOK_E_TOO_LARGE;
     const int vunits = a.units * K;               // (unit, epoch) pairs the launch walks
+    // order of the pairs: unit-major (the K walks of a unit side by side: the deal stays sorted by walk length) for splits that
+    // need several epochs to fill the chip; epoch-major (epoch 0 of every unit, then epoch 1, ...) when one epoch fills half of
+    // the resident waves or more - the first round is then the tuned one-epoch deal (249,456 molecules x 2 epochs, int32 padded:
+    // 0.076 ms per epoch against 0.089; x 4 as 16-bit rows: 0.0573 against 0.0589; 12 k x 24: 0.0043 against 0.0039 the other way)
+    a.epoch_major = K > 1 && a.units >= 8 * ncu_hint();
+    if (const char *cs = std::getenv("GTOK_LANE_PAIR_ORDER")) a.epoch_major = cs[0] == 'e';   // tuning knob: unit | epoch
     a.unit_mul = 0;
     a.prio_cut[0] = 16; a.prio_cut[1] = 32; a.prio_cut[2] = 48;   // quartiles (profiles/tools/lane_prio_sweep.sh)
     if (const char *pc = std::getenv("GTOK_LANE_PRIO_CUTS")) std::sscanf(pc, "%d,%d,%d", &a.prio_cut[0], &a.prio_cut[1], &a.prio_cut[2]);   // tuning knob

@@ -154,6 +154,7 @@ struct SentLaneArgs {
   int unit_mul;   // 0: units in order
   int prio_cut[3];   // reordered batch: units below these ranks (in 64ths of the stored order) run at priority 3 / 2 / 1
   int pad_nt;        // padding leaves with non-temporal stores (slabs larger than the memory-side cache)
+  int epoch_major;   // order of the (unit, epoch) pairs: 0 = unit-major (pair v = unit v / K), 1 = epoch-major (pair v = unit v mod units)
 };
 
 // PK: the batch carries the byte-packed rowptr / col mirror (gtok_csr.rowptr8 / col8): a unit is staged with 12
@@ -377,7 +378,10 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   while (vu < vunits) {
     int unit = vu;
     uint32_t epoch = epoch0;
-    if (K > 1) { unit = vu / K; epoch += (uint32_t)(vu - unit * K); }
+    if (K > 1) {
+      if (a.epoch_major) { const int e_ = vu / a.units; unit = vu - e_ * a.units; epoch += (uint32_t)e_; }
+      else { unit = vu / K; epoch += (uint32_t)(vu - unit * K); }
+    }
     // ---- stage this unit; the loads of phase A go out ahead of the previous unit's padding stores
 #ifdef GTOK_PHASE_TIMING
     const uint64_t ts0_new = __builtin_amdgcn_s_memtime();

@@ -225,7 +225,9 @@ class GraphTokenDatasetForAutoGraph:
     def _item(self, i: int) -> Data:
         data, _ = self._coll
         a, b = self._es[i], self._es[i + 1]
-        d = Data(edge_index=data["edge_index"][:, a:b], y=data["y"][i:i + 1], num_nodes=int(data["num_nodes"][i]))
+        # copies, as torch_geometric's InMemoryDataset.get hands out: an in-place transform or a trainer that writes into an item
+        # must not reach the collated arrays graph_batch() / collated() / the data_gtok.pt cache are built from
+        d = Data(edge_index=data["edge_index"][:, a:b].clone(), y=data["y"][i:i + 1].clone(), num_nodes=int(data["num_nodes"][i]))
         if bool(data["has_query"][i]):
             d.query_u, d.query_v = int(data["query_u"][i]), int(data["query_v"][i])
         return d

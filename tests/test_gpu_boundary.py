@@ -40,7 +40,7 @@ def _zinc_tokenizer(max_nodes):
 
 def test_reference_per_item_loop_is_one_launch_per_k_epochs():
     """The reference's per-item loop over this package's dataset: ONE gtok_sent launch serves K epochs of the split
-    (K = tokenizer.epochs_for(G) = 21 for the 12 k split: trails depend on (seed, epoch, graph) only), every epoch's rows
+    (K = tokenizer.epochs_for(G) = 32 for the 12 k split: trails depend on (seed, epoch, graph) only), every epoch's rows
     equal to the single-epoch batched call and to the oracle."""
     G = 12000                                                            # BASELINE config 2
     d = gtok.synth.zinc_like(G, seed=40)
@@ -54,7 +54,7 @@ def test_reference_per_item_loop_is_one_launch_per_k_epochs():
             tokens, mask, label, data = _reference_getitem(pyg, tok, i, remap=True)
             got[i] = tokens
             assert mask.all() and mask.numel() == tokens.numel() and label == pytest.approx(float(d["y"][i]))
-        assert tok.epochs_for(G) == 21 and tok.launches == 1, "one gtok_sent launch per K epochs, however the items are fetched"
+        assert tok.epochs_for(G) == 32 and tok.launches == 1, "one gtok_sent launch per K epochs, however the items are fetched"
         ids, ln = tok.tokenize_batch(batch.to(DEV), epoch=epoch, remap_zinc=True)       # the batched call, fused remap
         ref, rln = orc.sent(coo, 37, 1024, 5, epoch, ld=ids.shape[1], labeled=True, num_node_types=9, num_edge_types=4,
                             remap_zinc=True, nthreads=8)
