@@ -427,8 +427,9 @@ def main():
         _, rgm = timed_loop(ragged16_step, n_launch, multi, per_launch_events=False)
         ragged16 = per_step(rgm)
         del ids16
-        # what an epoch of the dataset classes costs on the device: Graph2TrailTokenizer.epochs_for(G) epochs per launch as 16-bit
-        # rows without padding (agtt.TokenizedGraphDataset.tokenize_epoch_u16 / the tokenizer's _serve)
+    # what an epoch of the dataset classes costs on the device: Graph2TrailTokenizer.epochs_for(G) epochs per launch as 16-bit
+    # rows without padding (agtt.TokenizedGraphDataset.tokenize_epoch_u16 / the tokenizer's _serve) - every workload
+    if not args.no_unpadded and not rows_u16:
         Kd = max(1, min(32, gtok.Graph2TrailTokenizer.EPOCH_WALKS // max(1, G)))
         idsk = torch.empty((Kd * G, ld), dtype=torch.int16, device=dev)
         lnk = torch.empty((Kd * G,), dtype=torch.int32, device=dev)
@@ -439,6 +440,7 @@ def main():
         _, km = timed_loop(fk, nk, multi, per_launch_events=False)
         epoch_loop = dict(epochs_per_launch=Kd, launches=nk, ms_per_launch=round(float(np.mean(km)), 4), ms_per_epoch=round(float(np.mean(km)) / Kd, 5),
                           graphs_per_sec=round(G * Kd / float(np.mean(km)) * 1e3, 1),
+                          kernel=gtok.ops.sent_kernel_name(batch, max_nodes, max_len, labeled=zinc, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=zinc, epochs=Kd),
                           note="the dataset classes' epoch: tokenizer.epochs_for(G) epochs per gtok_sent launch, GTOK_SENT_U16 | GTOK_SENT_NO_PAD rows "
                                "read in place by gtok_collate_packed / EpochRows")
         del idsk, lnk
@@ -584,6 +586,7 @@ def main():
                                note="GTOK_SENT_U16: rows of 16-bit ids straight from the walk's token windows (no unpacking, half the bytes); "
                                     "unpadded = + GTOK_SENT_NO_PAD: what TokenizedGraphDataset / gtok_collate_packed(row_ptr NULL) / EpochRows read in place, "
                                     "no second pass; packed = + gtok_row_offsets + gtok_pack_rows_u16 (16-bit rows back to back: the compact all-gather's payload)")
+    if epoch_loop is not None:
         out["epoch_loop"] = epoch_loop
 
     log("[bench] headline assembled; secondary legs follow")

@@ -134,7 +134,11 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int vun = a.units * K;
     const int nb = vun < ncu ? vun : ncu;   // every CU, also when some of its waves stay without a unit
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * nw), lds * nw, (hipStream_t)stream, a);
+    // unit-major always: the K walks of a unit fetch the same adjacency rows at about the same time (L2 hits on the one HBM read
+    // of a step) - 125 k ER graphs x 8 epochs: 0.356 ms per epoch against 0.404 epoch-major (0.49 for one epoch per launch)
+    a.epoch_major = 0;
+    if (const char *cs = std::getenv("GTOK_LANE_PAIR_ORDER")) a.epoch_major = cs[0] == 'e';   // tuning knob: unit | epoch
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * nw), lds * nw + 16, (hipStream_t)stream, a);   // (+ the workgroup's ticket counter)
     return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
   }
   if (lane_path) {

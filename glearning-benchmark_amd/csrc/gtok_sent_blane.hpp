@@ -32,6 +32,7 @@ struct SentBLaneArgs {
   int epochs;  // K >= 1 (gtok_sent_params.epoch_count): the launch walks units x K (unit, epoch) pairs, unit-major
   int prio;    // long units at a higher issue priority than the short ones they share a SIMD with
   int pad_nt;  // padding leaves with non-temporal stores (slabs larger than the memory-side cache: gtok_sent_lane.hpp)
+  int epoch_major;   // order of the (unit, epoch) pairs (gtok_sent_lane.hpp)
 };
 
 struct __attribute__((aligned(16))) U64x2 { uint64_t a, b; };
@@ -78,12 +79,21 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
   } else if (nwaves > 4 && grp == 0) {
     __builtin_amdgcn_s_setprio(1);
   }
-  const int K = a.epochs, vunits = a.units * K;
-  for (int idx = 0; idx < vunits; idx += (int)gridDim.x * nwaves) {
-    const int vu = idx + grp * qsize + ((grp & 1) ? qsize - 1 - jq : jq);
-    if (vu >= vunits) continue;
+  // K epochs per launch: the launch walks (unit, epoch) pairs - unit-major, or epoch-major when one epoch fills half of the
+  // resident waves or more (gtok_sent_lane.hpp).  The first round of resident waves is dealt statically as described above;
+  // pairs beyond it are drawn from a ticket counter in the workgroup's LDS (workgroup b owns pairs nslots + t * gridDim + b,
+  // longest first), at priority 0: a wave that has finished takes the longest pair left instead of leaving its SIMD one wave
+  // short (125 k ER graphs x 2 epochs: 0.44 ms per epoch with the static deal already, against 0.51 for one epoch per launch).
+  const int K = a.epochs, vunits = a.units * K, nslots = (int)gridDim.x * nwaves;
+  int *wg_ticket = reinterpret_cast<int *>(smem_all + (size_t)nwaves * (18 * W * 256));
+  if (threadIdx.x == 0) *wg_ticket = 0;
+  __syncthreads();
+  for (int vu = grp * qsize + ((grp & 1) ? qsize - 1 - jq : jq); vu < vunits;) {
     int unit = vu, ep = 0;
-    if (K > 1) { unit = vu / K; ep = vu - unit * K; }
+    if (K > 1) {
+      if (a.epoch_major) { ep = vu / a.units; unit = vu - ep * a.units; }
+      else { unit = vu / K; ep = vu - unit * K; }
+    }
     const uint32_t epoch = epoch0 + (uint32_t)ep;
     const int64_t row0 = (int64_t)ep * G;          // first row of the epoch's [G, ld] slice
     const int slot = unit * 64 + lane;
@@ -479,6 +489,11 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
       row[7] = (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - pt_rt0);
     }
 #endif
+    // ---- the next pair
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(wg_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    vu = nslots + uni(t) * (int)gridDim.x + (int)blockIdx.x;
+    __builtin_amdgcn_s_setprio(0);
   }
 }
 
