@@ -36,6 +36,28 @@ def _(node_ptr, edge_ptr, rowptr, col, nattr, eattr, query, max_nodes, max_edges
     return node_ptr.new_empty((G, ld), dtype=torch.int32), node_ptr.new_empty((G,), dtype=torch.int32)
 
 
+@torch.library.custom_op("gtok::sent_epochs", mutates_args=(), device_types="cuda")
+def sent_epochs(node_ptr: Tensor, edge_ptr: Tensor, rowptr: Tensor, col: Tensor, nattr: Optional[Tensor],
+                eattr: Optional[Tensor], query: Optional[Tensor], max_nodes: int, max_edges: int, max_num_nodes: int,
+                max_len: int, ld: int, seed: int, epoch: int, epochs: int, labeled: bool, num_node_types: int, num_edge_types: int,
+                remap_zinc: bool, pad_id: int, graph_base: int, pad: bool, u16: bool) -> Tuple[Tensor, Tensor]:
+    """gtok_sent with ABI v4's epoch_count and row flags: epochs epoch .. epoch + epochs - 1 in ONE launch ->
+    (ids [epochs * G, ld] int32 - or int16 storage holding 16-bit ids when u16 -, len int32 [epochs * G]), epoch-major;
+    pad=False leaves the pad tails unwritten (GTOK_SENT_NO_PAD)."""
+    b = _batch(node_ptr, edge_ptr, rowptr, col, None, nattr, eattr, max_nodes, max_edges)
+    ids, ln = _ops.sent(b, max_num_nodes, max_len, seed, epoch, labeled=labeled, num_node_types=num_node_types,
+                        num_edge_types=num_edge_types, remap_zinc=remap_zinc, pad_id=pad_id, graph_base=graph_base,
+                        query=query, ld=ld, pad=pad, epochs=epochs, u16=u16)
+    return ids.reshape(-1, ld), ln.reshape(-1)
+
+
+@sent_epochs.register_fake
+def _(node_ptr, edge_ptr, rowptr, col, nattr, eattr, query, max_nodes, max_edges, max_num_nodes, max_len, ld, seed,
+      epoch, epochs, labeled, num_node_types, num_edge_types, remap_zinc, pad_id, graph_base, pad, u16):
+    rows = (node_ptr.shape[0] - 1) * max(1, epochs)
+    return node_ptr.new_empty((rows, ld), dtype=torch.int16 if u16 else torch.int32), node_ptr.new_empty((rows,), dtype=torch.int32)
+
+
 @torch.library.custom_op("gtok::ibtt_zinc", mutates_args=(), device_types="cuda")
 def ibtt_zinc(node_ptr: Tensor, edge_ptr: Tensor, rowptr: Tensor, col: Tensor, eorder: Optional[Tensor],
               nattr: Optional[Tensor], eattr: Optional[Tensor], lut: Tensor, max_nodes: int, max_edges: int,
@@ -188,9 +210,23 @@ def _(ids, lens, row_ptr, elem_bytes, capacity):
             ids.new_empty((1,), dtype=torch.int32))
 
 
+@torch.library.custom_op("gtok::pack_rows_u16", mutates_args=(), device_types="cuda")
+def pack_rows_u16(ids16: Tensor, lens: Tensor, row_ptr: Tensor, elem_bytes: int, capacity: int) -> Tuple[Tensor, Tensor]:
+    """gtok_pack_rows_u16: a slab of 16-bit ids (sent_epochs(..., u16=True)) packed at 2 / 4 / 8 bytes per id."""
+    packed, _, status = _ops.pack_rows_u16(ids16, lens, row_ptr, elem_bytes, capacity=capacity, check_status=False)
+    return packed, status
+
+
+@pack_rows_u16.register_fake
+def _(ids16, lens, row_ptr, elem_bytes, capacity):
+    return (ids16.new_empty((max(capacity, 1),), dtype={2: torch.int16, 4: torch.int32, 8: torch.int64}[elem_bytes]),
+            ids16.new_empty((1,), dtype=torch.int32))
+
+
 @torch.library.custom_op("gtok::unpack_rows", mutates_args=(), device_types="cuda")
-def unpack_rows(packed: Tensor, row_ptr: Tensor, lens: Tensor, ld: int, pad_id: int, segment_rows: int,
+def unpack_rows(packed: Tensor, row_ptr: Optional[Tensor], lens: Tensor, ld: int, pad_id: int, segment_rows: int,
                 segment_stride: int) -> Tensor:
+    """row_ptr None: `packed` is a [rows, ld] slab of 16- / 32-bit ids read in place (the strided form)."""
     return _ops.unpack_rows(packed, row_ptr, lens, ld, pad_id, segment_rows, segment_stride)
 
 
@@ -200,7 +236,7 @@ def _(packed, row_ptr, lens, ld, pad_id, segment_rows, segment_stride):
 
 
 @torch.library.custom_op("gtok::collate_packed", mutates_args=(), device_types="cuda")
-def collate_packed(packed: Tensor, row_ptr: Tensor, lens: Tensor, ld: int, index: Tensor, pad_id: int,
+def collate_packed(packed: Tensor, row_ptr: Optional[Tensor], lens: Tensor, ld: int, index: Tensor, pad_id: int,
                    out_ld: int) -> Tuple[Tensor, Tensor]:
     return _ops.collate_packed(packed, row_ptr, lens, ld, index, pad_id, out_ld)
 

