@@ -438,8 +438,13 @@ def main():
             fk(0)
         nk = max(3, -(-args.steps // Kd))
         _, km = timed_loop(fk, nk, multi, per_launch_events=False)
+        tok_k = float(lnk.to(torch.float64).sum().item())           # tokens of the last launch (Kd epochs)
+        bytes_k = host.algorithmic_read_bytes(ibtt=False, labeled=zinc) * Kd + 2.0 * tok_k + 4.0 * G * Kd
         epoch_loop = dict(epochs_per_launch=Kd, launches=nk, ms_per_launch=round(float(np.mean(km)), 4), ms_per_epoch=round(float(np.mean(km)) / Kd, 5),
                           graphs_per_sec=round(G * Kd / float(np.mean(km)) * 1e3, 1),
+                          roofline=dict(bound="hbm", achieved=round(bytes_k / (float(np.mean(km)) * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                        frac=round(bytes_k / (float(np.mean(km)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), algorithmic_bytes_per_launch=int(bytes_k),
+                                        note="SURVEY section 8d with 16-bit ids: 4(N+1) + 4E (+ N + E labelled) read, 2L + 4 written, x epochs per launch"),
                           kernel=gtok.ops.sent_kernel_name(batch, max_nodes, max_len, labeled=zinc, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=zinc, epochs=Kd),
                           note="the dataset classes' epoch: tokenizer.epochs_for(G) epochs per gtok_sent launch, GTOK_SENT_U16 | GTOK_SENT_NO_PAD rows "
                                "read in place by gtok_collate_packed / EpochRows")
