@@ -346,8 +346,8 @@ class GraphTokenDatasetForAutoGraph:
         if not 0 <= i < self._len:
             raise IndexError(idx)
         d = self._items.get(i)
-        if d is None:
-            d = self._items[i] = self._item(i)
+        if d is None:                             # made on demand from the collated arrays, not kept: no second copy of the split grows behind the caller
+            d = self._item(i)
         if self.transform is not None:            # the batch below would not see what a transform does: no mark
             return self.transform(d)
         return _tag_item(self, i, d)              # lets Graph2TrailTokenizer tokenize the item's whole split at once
