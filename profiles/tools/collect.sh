@@ -20,6 +20,7 @@ for wl in $WLS; do
   extra=""; [ $wl = synth_mix ] && extra="--no-cpu-baseline"
   step run_to $out/bench_$wl.json timeout -k 10 600 python3 bench.py $(steps_of $wl) --workload $wl $extra
 done
+if [ "${BENCH_ONLY:-0}" = 1 ]; then du -sh $out; echo collected; exit 0; fi      # (the bench lines alone: after a change that no counter pass would see)
 prof() { local log=$1; shift; "$@" > $log 2>&1; local rc=$?; find $out -name '*_kernel_trace.csv' -delete; return $rc; }
 # counters are collected for OUR kernels only (--kernel-include-regex gtok): the corpora are sampled by thousands of torch
 # launches, which made counter collection of synth_mix impractical before
