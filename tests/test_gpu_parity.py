@@ -306,6 +306,25 @@ def test_c_abi_error_codes():
     half.graph_ids = sb.graph_ids                                                                            # ids without a unit table
     csh = half.c_struct()
     assert L.gtok_sent(ctypes.byref(csh), ctypes.byref(lab9), ids.data_ptr(), 64, ln.data_ptr(), None) == -1
+    # ABI v4 fields: a negative epoch_count, a nonzero `reserved`, an unknown flag bit, a pad id that does not fit 16-bit rows
+    P = lib_mod.GtokSentParams
+    for bad in (P(37, 0, 0, 0, 64, 0, 5, 0, 1, 0, 0, None, -1, 0), P(37, 0, 0, 0, 64, 0, 5, 0, 1, 0, 0, None, 1, 7),
+                P(37, 0, 0, 0, 64, 0, 5, 4, 1, 0, 0, None, 1, 0), P(37, 0, 0, 0, 64, 0, 70000, lib_mod.SENT_U16, 1, 0, 0, None, 1, 0)):
+        assert L.gtok_sent(ctypes.byref(cs), ctypes.byref(bad), ids.data_ptr(), 64, ln.data_ptr(), None) == -1
+    ok2 = P(37, 0, 0, 0, 64, 0, 5, lib_mod.SENT_U16 | lib_mod.SENT_NO_PAD, 1, 0, 0, None, 2, 0)                  # 2 epochs of 16-bit rows
+    ids16 = torch.empty((16, 64), dtype=torch.int16, device=DEV); ln2 = torch.empty(16, dtype=torch.int32, device=DEV)
+    assert L.gtok_sent(ctypes.byref(cs), ctypes.byref(ok2), ids16.data_ptr(), 64, ln2.data_ptr(), None) == 0
+    # a per-unit record table without the unit table it describes
+    orphan = gtok.GraphBatch(b.num_graphs, b.max_nodes, b.max_edges, b.node_ptr, b.edge_ptr, b.rowptr, b.col, None, b.nattr, b.eattr)
+    orphan.unit_info = sb.unit_info
+    cso = orphan.c_struct()
+    assert L.gtok_sent(ctypes.byref(cso), ctypes.byref(p), ids.data_ptr(), 64, ln.data_ptr(), None) == -1
+    # the strided readers refuse segments (a slab has none); the checked unpack takes a NULL status
+    st = torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert L.gtok_unpack_rows_checked(ids16.data_ptr(), 2, None, ln2.data_ptr(), 16, 4, 64, 0, 5, ids.data_ptr(), 64, st.data_ptr(), None) == -1
+    wide = torch.empty((16, 64), dtype=torch.int32, device=DEV)
+    assert L.gtok_unpack_rows_checked(ids16.data_ptr(), 2, None, ln2.data_ptr(), 16, 0, 0, 16 * 64, 5, wide.data_ptr(), 64, None, None) == 0
+    assert L.gtok_pack_rows_u16(ids16.data_ptr(), 64, ln2.data_ptr(), 16, None, 2, wide.data_ptr(), 16 * 64, st.data_ptr(), None) == -1   # no row_ptr
     torch.cuda.synchronize()
     with pytest.raises(gtok.GtokError):
         gtok.ops.sent(big, 37, 64, 0)
