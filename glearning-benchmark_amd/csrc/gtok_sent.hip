@@ -207,10 +207,11 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
       const bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       int occ16 = 0;
       const char *ww = std::getenv("GTOK_LANE_WG_WAVES");   // tuning knob: 8 = two 8-wave workgroups per CU
-      const int wgw = (ww && ww[0] == '8') ? 8 : 16;
+      const int wgw = (ww && ww[0] == '8') ? 8 : (ww && ww[0] == '1' && ww[1] == '2') ? 12 : 16;   // 12: three waves per SIMD
+      const int per_cu = wgw == 8 ? 2 : 1;
       const size_t wg_lds = (size_t)a.lds * wgw + kLaneWgShared;
-      if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 64 * wgw, wg_lds) == hipSuccess && occ16 >= 16 / wgw) {
-        hipLaunchKernelGGL(kern, dim3(ncu * (16 / wgw)), dim3(64 * wgw), wg_lds, (hipStream_t)stream, a);
+      if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 64 * wgw, wg_lds) == hipSuccess && occ16 >= per_cu) {
+        hipLaunchKernelGGL(kern, dim3(ncu * per_cu), dim3(64 * wgw), wg_lds, (hipStream_t)stream, a);
         return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
       }
       (void)hipGetLastError();

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   // (GTOK_LANE_WG_WAVES=8: two 8-wave workgroups per CU, each balanced in itself - quarters 0 + 3 or 1 + 2 on every SIMD)
   const int wg_waves = (int)(blockDim.x >> 6), wgs_per_cu = wg_waves == 8 ? 2 : 1;
   const int cus = (int)gridDim.x / wgs_per_cu, wg_type = (int)blockIdx.x % wgs_per_cu, wg_cu = (int)blockIdx.x / wgs_per_cu;
-  const int nslots = cus * 16, qsize = cus * 4;
+  const int nslots = (int)gridDim.x * wg_waves, qsize = cus * 4;   // (GTOK_LANE_WG_WAVES=12: three waves per SIMD, the rest of the units dealt dynamically)
   const int quarter = wg_waves == 8 ? (wg_type == 0 ? ((wave >> 2) ? 3 : 0) : ((wave >> 2) ? 2 : 1)) : wave >> 2;
   const int jq = (wave & 3) * cus + wg_cu;
   // K epochs in one launch: the launch walks (unit, epoch) pairs, unit-major - the K walks of a unit are neighbours in the
@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     if (percu) {
       int t = 0;
       if (lane == 0) t = __hip_atomic_fetch_add(wg_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      vu = (int)gridDim.x * (16 / wgs_per_cu) + uni(t) * (int)gridDim.x + (int)blockIdx.x;
+      vu = nslots + uni(t) * (int)gridDim.x + (int)blockIdx.x;
 #ifndef GTOK_LANE_NO_PRIO
       __builtin_amdgcn_s_setprio(0);   // dynamic rounds: whoever is free takes the longest unit left
 #endif
