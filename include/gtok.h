@@ -23,11 +23,13 @@
  *                      (gather rows of a batch, pad to the batch max, bool mask)
  *   gtok_parse_graph_text  graph_token_dataset_autograph.py:14-158 (text -> edges, query, label)
  *   gtok_find_token    the `<q>` search of trainer/train_ibtt.py:88-103 on a collated batch
- *   gtok_row_offsets / gtok_pack_rows / gtok_unpack_rows / gtok_collate_packed
+ *   gtok_row_offsets / gtok_pack_rows / gtok_pack_rows_u16 / gtok_unpack_rows / gtok_unpack_rows_checked / gtok_collate_packed
  *                      (no reference counterpart) the packed form of a token slab - rows back to back, 16 or 32
  *                      bits per id - for the copies that leave the GPU: the all-gather that reassembles the rows of
  *                      every rank in dataset order (val/test loaders, trainer/train_agtt.py:602-607) and the D2H
- *                      copy behind TokenizedGraphDataset.__getitem__ (trainer/train_agtt.py:246-273)
+ *                      copy behind TokenizedGraphDataset.__getitem__ (trainer/train_agtt.py:246-273); the readers also
+ *                      take a [rows, ld] slab of 16-bit ids in place (row_ptr NULL): the per-batch collate of
+ *                      trainer/train_agtt.py:276-302 straight over GTOK_SENT_U16 rows
  *   gtok_ids_to_text   graph_data_loader/zinc_dataset_indexbase.py:143-227, the STRING form (ids rendered through a string table)
  *   gtok_csr_pack8     (no reference counterpart) byte-packed mirror of the CSR index arrays of small-graph batches
  *   gtok_csr_adjbits   (no reference counterpart) adjacency bit-matrix mirror of batches of graphs with <= 256 nodes
@@ -47,7 +49,9 @@
  * [rows, ld] int32 slab; row g receives its first min(out_len[g], ld) ids and
  * pad_id after them; out_len[g] is the TRUE sequence length (already cut at
  * max_len as the reference does), so out_len[g] > ld tells the caller that
- * the slab was too narrow for that row.
+ * the slab was too narrow for that row.  gtok_sent only (ABI v4): epoch_count = K
+ * makes that K slabs back to back ([K, G, ld], out_len [K, G]); GTOK_SENT_U16
+ * makes the ids 16 bits wide; GTOK_SENT_NO_PAD leaves the pad tails unwritten.
  *
  * Batched CSR layout (gtok_csr), G graphs, graph g has N_g nodes and E_g
  * directed adjacency entries exactly as the source edge_index lists them:
