@@ -123,6 +123,19 @@ def test_graph_token_split_with_queries_through_the_reference_loop(tmp_path):
         assert np.array_equal(r.numpy(), ids[i, :int(ln[i])].cpu().numpy()), i
     fast = gtok.agtt.TokenizedGraphDataset(pyg, tok, task="shortest_path", device=DEV)
     assert all(torch.equal(fast[i][0], rows[i]) for i in range(len(pyg)))
+    # the same split behind the stock DataLoader (batch-level fetch): rows incl. their query tails, int64 labels, and the
+    # `data_list[0].num_nodes` the model computes its <q> id from (train_agtt.py:127-133)
+    from torch.utils.data import DataLoader
+    fast2 = gtok.agtt.TokenizedGraphDataset(pyg, tok, task="shortest_path", device=DEV)
+    seen = 0
+    for X, A, Y, datas in DataLoader(fast2, batch_size=32, shuffle=False, num_workers=0, collate_fn=gtok.agtt.collate_fn):
+        for b in range(X.shape[0]):
+            r = rows[seen + b]
+            assert torch.equal(X[b, :r.numel()].cpu(), r) and bool(A[b, :r.numel()].all()) and not bool(A[b, r.numel():].any())
+            assert int(Y[b]) == pyg[seen + b].y.item()
+        assert Y.dtype == torch.long and datas[0].num_nodes == pyg[seen].num_nodes and int(X[0, rows[seen].numel() - 3]) == tok.idx_offset + datas[0].num_nodes
+        seen += X.shape[0]
+    assert seen == len(pyg)
 
 
 def test_zinc_full_ingestion_from_collated_storage_under_a_second():
