@@ -22,6 +22,10 @@
 // lane's own slab row (lines are written in whole 16-byte pieces, each once); the pad tails of the 64 rows are
 // filled cooperatively (coalesced) at the end of the unit.  Limits: maxn <= 64, maxe <= 255 (u8 indices),
 // degree < 2^P (the launcher picks P from gtok_csr.max_degree).
+// Round 4 (ABI v4): a launch walks (unit, epoch) pairs (gtok_sent_params.epoch_count: K epochs of a split in one launch);
+// pairs beyond the first round of resident waves are drawn from a ticket counter in the workgroup's LDS; rows may be
+// 16 bits wide (GTOK_SENT_U16: the windows are stored as they stand); the padding of the last units is shared by the
+// waves of a CU; slabs beyond the memory-side cache are padded with non-temporal stores.
 #pragma once
 #include <type_traits>
 #include "gtok_sent_reg.hpp"
@@ -337,18 +341,20 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   // SIMD lets it be (alone ~2.5 k cycles per step, with three others ~5.2 k): every SIMD should hold one unit of each
   // quarter of that order.  HIP gives no say in which one-wave workgroups share a SIMD, but inside ONE workgroup the waves
   // w, w + 4, w + 8, w + 12 share one (observed on gfx950: profiles/tools/probes/wave_simd_probe.hip; speed only) - so the
-  // launch is 256 workgroups of 16 waves, one per CU with all of its LDS, and wave w of workgroup b takes, per round of
-  // 4,096 units, rank (w >> 2) * 1024 + j of the stored order, j = (w & 3) * 256 + b, odd quarters backwards (long with
-  // short).  The quarter is also the wave's issue priority: the stragglers-to-be get the slots their SIMD-mates can spare.
+  // launch is 256 workgroups of 16 waves, one per CU with all of its LDS, and wave w of workgroup b takes, in the FIRST round
+  // of 4,096 units, rank (w >> 2) * 1024 + j of the stored order, j = (w & 3) * 256 + b, odd quarters backwards (long with
+  // short).  The quarter is also the wave's issue priority in that round: the stragglers-to-be get the slots their SIMD-mates
+  // can spare.  (Three waves per SIMD - GTOK_LANE_WG_WAVES=12 - with the rest of the units dealt dynamically were measured: worse.)
   const bool percu = blockDim.x > 64;
   // (GTOK_LANE_WG_WAVES=8: two 8-wave workgroups per CU, each balanced in itself - quarters 0 + 3 or 1 + 2 on every SIMD)
   const int wg_waves = (int)(blockDim.x >> 6), wgs_per_cu = wg_waves == 8 ? 2 : 1;
   const int cus = (int)gridDim.x / wgs_per_cu, wg_type = (int)blockIdx.x % wgs_per_cu, wg_cu = (int)blockIdx.x / wgs_per_cu;
-  const int nslots = (int)gridDim.x * wg_waves, qsize = cus * 4;   // (GTOK_LANE_WG_WAVES=12: three waves per SIMD, the rest of the units dealt dynamically)
+  const int nslots = (int)gridDim.x * wg_waves, qsize = cus * 4;
   const int quarter = wg_waves == 8 ? (wg_type == 0 ? ((wave >> 2) ? 3 : 0) : ((wave >> 2) ? 2 : 1)) : wave >> 2;
   const int jq = (wave & 3) * cus + wg_cu;
-  // K epochs in one launch: the launch walks (unit, epoch) pairs, unit-major - the K walks of a unit are neighbours in the
-  // order (same CSR chunk: L2 hits; same length class)
+  // K epochs in one launch: the launch walks (unit, epoch) pairs - unit-major (the K walks of a unit are neighbours in the
+  // deal: it stays sorted by walk length; same CSR chunk: L2 hits), or epoch-major when one epoch fills half of the resident
+  // waves or more (the first round is then the tuned one-epoch deal): the launcher picks (a.epoch_major)
   const int K = a.epochs, vunits = a.units * K;
   // Beyond the first round of resident waves (more than nslots pairs: corpora of > 260 k molecules, or K epochs of a
   // smaller one) the pairs are handed out DYNAMICALLY: workgroup b owns the pairs nslots + t * gridDim + b, t = 0, 1, ...
