@@ -164,3 +164,47 @@ def test_packed_rows_and_strings_at_zinc_full_size(zinc_full):
     keep = torch.arange(w, device=g_len.device)[None, :] < g_len[:, None]
     assert torch.equal(td_all.ids[:, :w][keep], g_ids[:, :w][keep])
     assert torch.equal(td_all.seqs[ZINC_FULL - 1], g_ids[ZINC_FULL - 1, :int(g_len[-1])].long().cpu())
+
+
+def test_sent_zinc_full_four_epochs_per_launch_as_16_bit_rows(zinc_full):
+    """What an epoch of the dataset classes runs at ZINC-full size (tokenizer.epochs_for(249,456) = 4 epochs per launch, 16-bit rows,
+    no padding; ~1 M walks in several rounds of resident waves, the (unit, epoch) pairs epoch-major): every epoch slice
+    bit-exact against the oracle inside the row lengths, and every un-remapped row of every slice decodes back to its molecule."""
+    d, host, dev, coo = zinc_full
+    K, ld = 4, 192
+    assert gtok.Graph2TrailTokenizer(dataset_names=[], max_length=1024, labeled_graph=True).epochs_for(ZINC_FULL) == K
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ids, ln = gtok.ops.sent(dev, 37, 1024, 7, 100, ld=ld, epochs=K, u16=True, pad=False, **kw)
+    assert ids.dtype == torch.int16 and tuple(ids.shape) == (K, ZINC_FULL, ld) and int(ln.max()) <= ld
+    inside = None
+    for e in range(K):
+        ref, rln = orc.sent(coo, 37, 1024, 7, 100 + e, ld=ld, nthreads=THREADS, **kw)
+        assert np.array_equal(ln[e].cpu().numpy(), rln), e
+        got = ids[e].cpu().numpy().view(np.uint16)
+        inside = np.arange(ld)[None, :] < rln[:, None]
+        assert np.array_equal(np.where(inside, got, 0), np.where(inside, ref, 0)), e
+    # the round trip on the un-remapped flavour (the decoder reads raw SENT ids), all four epochs in one launch
+    raw, rl = gtok.ops.sent(dev, 37, 1024, 11, 40, labeled=True, num_node_types=28, num_edge_types=6, ld=ld, epochs=K, u16=True)
+    for e in range(K):
+        rows = raw[e].cpu().numpy().view(np.uint16).astype(np.int32)
+        st = orc.sent_roundtrip(coo, rows, rl[e].cpu().numpy(), 37, 1024, 11, 40 + e, labeled=True, num_node_types=28, nthreads=THREADS)
+        assert not st.any(), (e, int((st != 0).sum()))
+    assert bool((raw.view(K * ZINC_FULL, ld)[torch.arange(K * ZINC_FULL, device=DEV), (rl.view(-1) - 1).long()] == 4).all())
+
+
+def test_large_graphs_eight_epochs_per_launch():
+    """BASELINE config 5 shape through the bit-matrix lane kernel with 8 epochs per launch (what the dataset classes run for a
+    125 k-graph shard; here 24 k graphs: pairs beyond the first round come from the ticket counters): 16-bit rows, every slice
+    == the oracle, rows cut at max_len decode to a part of their graph."""
+    G, K = 24000, 8
+    d = gtok.synth.er_batch_device(G, torch.device(DEV), seed=77)
+    batch, coo = both(d, False)
+    dev = batch.to(DEV)
+    assert gtok.ops.sent_kernel_name(dev, 256, 600, epochs=K) in ("sent_blane_kernel<W=4>", "sent_lds_kernel<W=4>")
+    ids, ln = gtok.ops.sent(dev, 256, 600, 3, 5, ld=608, epochs=K, u16=True)
+    assert gtok.ops.sent_kernel_name(dev, 256, 600, epochs=K) == "sent_blane_kernel<W=4>"      # (the mirror exists now)
+    for e in (0, 3, K - 1):
+        ref, rln = orc.sent(coo, 256, 600, 3, 5 + e, ld=608, nthreads=THREADS)
+        assert np.array_equal(ln[e].cpu().numpy(), rln) and np.array_equal(ids[e].cpu().numpy().view(np.uint16), ref), e
+        st = orc.sent_roundtrip(coo, ref, rln, 256, 600, 3, 5 + e, nthreads=THREADS)
+        assert not st.any()
