@@ -306,6 +306,77 @@ __global__ void __launch_bounds__(256) ids_to_text_kernel(const TextArgsR a) {
   }
 }
 
+// ---- the tail of a ZINC text (zinc_dataset_indexbase.py:186-195: `<p> val_X_XX <eos>`, :217-221: a text of more than
+// max_len tokens keeps max_len - 1 of them and `<eos>`).  The serialiser's rows end with `<p>`; what follows differs per
+// molecule, so it is rendered here, thread per row, instead of one Python format call per molecule on the host.
+// `f"val_{label:.2f}".replace('.', '_').replace('-', 'neg')` (:192) on the float32 label: "%.2f" of the EXACT value, ties to
+// even - 24 bits of mantissa times 100 fit 31 bits, so below 2^24 the hundredths are one shift with a remainder test, and
+// from 2^23 on the value is an integer of up to 128 bits, printed in full as Python does.
+__device__ int zinc_label_token(float v, uint8_t *buf) {            // buf: >= 49 bytes; returns the length
+  const uint32_t b = __float_as_uint(v);
+  const bool neg = (b >> 31) != 0u;
+  const uint32_t ex = (b >> 23) & 255u, mant = b & 0x7FFFFFu;
+  int n = 0;
+  buf[n++] = 'v'; buf[n++] = 'a'; buf[n++] = 'l'; buf[n++] = '_';
+  if (ex == 255u && mant) { buf[n++] = 'n'; buf[n++] = 'a'; buf[n++] = 'n'; return n; }   // (Python prints nan without a sign)
+  if (neg) { buf[n++] = 'n'; buf[n++] = 'e'; buf[n++] = 'g'; }     // the sign bit: -0.001 is val_neg0_00
+  if (ex == 255u) { buf[n++] = 'i'; buf[n++] = 'n'; buf[n++] = 'f'; return n; }
+  const uint32_t m = ex ? (mant | 0x800000u) : mant;
+  const int e = (ex ? (int)ex : 1) - 150;                           // value = m * 2^e
+  uint32_t limb[4] = {0u, 0u, 0u, 0u};                              // integer part, least significant first
+  uint32_t frac = 0u;
+  if (e >= 0) {
+    const int w = e >> 5, sh = e & 31;                              // e <= 104: w <= 3, and at w == 3 the shift is <= 8
+    limb[w] = m << sh;
+    if (sh && w < 3) limb[w + 1] = m >> (32 - sh);
+  } else {
+    const int sh = -e;
+    uint32_t h = 0u;
+    if (sh < 64) {
+      const uint64_t q = (uint64_t)m * 100u;
+      h = (uint32_t)(q >> sh);
+      const uint64_t rem = q & ((1ull << sh) - 1ull), half = 1ull << (sh - 1);
+      if (rem > half || (rem == half && (h & 1u))) ++h;
+    }
+    limb[0] = h / 100u; frac = h % 100u;
+  }
+  uint8_t dig[40];
+  int nd = 0;
+  do {
+    uint32_t r = 0u;
+    for (int k = 3; k >= 0; --k) { const uint64_t cur = ((uint64_t)r << 32) | limb[k]; limb[k] = (uint32_t)(cur / 10u); r = (uint32_t)(cur % 10u); }
+    dig[nd++] = (uint8_t)('0' + r);
+  } while (limb[0] | limb[1] | limb[2] | limb[3]);
+  for (int k = nd - 1; k >= 0; --k) buf[n++] = dig[k];
+  buf[n++] = '_'; buf[n++] = (uint8_t)('0' + frac / 10u); buf[n++] = (uint8_t)('0' + frac % 10u);
+  return n;
+}
+
+struct TailArgs {
+  const float *y; const int32_t *len; int64_t rows; int max_len;
+  int32_t *take; const int64_t *suf_ptr; uint8_t *out; int64_t *suf_len;
+};
+
+__global__ void __launch_bounds__(256) zinc_text_tails_kernel(const TailArgs a) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + (int)threadIdx.x;
+  if (r >= a.rows) return;
+  const int n = max(a.len[r], 0);
+  const bool cut = (int64_t)n + 2 > (int64_t)a.max_len;             // tokens = the row's ids + [label, <eos>]
+  const int take = cut ? a.max_len - 1 : n;
+  uint8_t buf[64];
+  int k = 0;
+  if (take > 0) buf[k++] = ' ';
+  if (!cut) { k += zinc_label_token(a.y[r], buf + k); buf[k++] = ' '; }
+  buf[k++] = '<'; buf[k++] = 'e'; buf[k++] = 'o'; buf[k++] = 's'; buf[k++] = '>';
+  if (a.out) {
+    uint8_t *__restrict__ p = a.out + a.suf_ptr[r];
+    for (int j = 0; j < k; ++j) p[j] = buf[j];
+  } else {
+    a.take[r] = take;
+    a.suf_len[r] = k;
+  }
+}
+
 static int tpr_shift_for(int ld) {
   const int pieces = (ld + 7) / 8;
   int s = 0;
@@ -424,5 +495,20 @@ extern "C" int gtok_ids_to_text(const int32_t *ids, int32_t ld, const int32_t *t
   a.ids = ids; a.ld = ld; a.take = take; a.rows = num_rows; a.tab_bytes = tab_bytes; a.tab_ptr = tab_ptr; a.num_strings = num_strings;
   a.suf_bytes = suf_bytes; a.suf_ptr = suf_ptr; a.text_ptr = text_ptr; a.out = out_bytes; a.text_len = text_len;
   hipLaunchKernelGGL(ids_to_text_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_zinc_text_tails(const float *y, const int32_t *len, int64_t num_rows, int32_t max_len, int32_t *take,
+                                    const int64_t *suf_ptr, uint8_t *suf_bytes, int64_t *suf_len, void *stream) {
+  DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (num_rows < 0 || max_len < 1) return GTOK_E_INVAL;
+  if (num_rows == 0) return GTOK_OK;
+  if (!y || !len || (suf_bytes ? !suf_ptr : (!take || !suf_len))) return GTOK_E_INVAL;
+  const int64_t nb = (num_rows + 255) / 256;
+  if (nb > 0x7FFFFFFF) return GTOK_E_TOO_LARGE;
+  TailArgs a;
+  a.y = y; a.len = len; a.rows = num_rows; a.max_len = max_len; a.take = take; a.suf_ptr = suf_ptr; a.out = suf_bytes; a.suf_len = suf_len;
+  hipLaunchKernelGGL(zinc_text_tails_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }

@@ -86,7 +86,8 @@ class ZINCTokenizationDataset(Dataset):
         """(texts, labels) of the WHOLE split in two launches instead of a Python loop per atom and bond: the
         serialiser kernel (gtok_ibtt_zinc) emits, per molecule, the positions of its tokens in a string table, and
         gtok_ids_to_text joins the strings.  The label token and `<eos>` (one distinct string per molecule: val_x_xx,
-        reference :192) and the `max_len` cut (:217-221) are attached per row on the host.  Same strings as `_item`."""
+        reference :192) and the `max_len` cut (:217-221) are rendered per row by gtok_zinc_text_tails.  Same strings as
+        `_item`."""
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         batch = self.graph_batch(device)
@@ -95,16 +96,21 @@ class ZINCTokenizationDataset(Dataset):
             + list(_ops.ZINC_BOND_NAMES) + [str(i) for i in range(max(batch.max_nodes, 1))]
         lut = torch.arange(len(strings), dtype=torch.int32)        # the kernel's LUT position IS the string's index
         ids, ln = _ops.ibtt_zinc(batch, lut, 1 << 30, 0)
-        labels = self.labels().tolist()
-        ln_h = ln.cpu().numpy().astype(np.int64)
-        cut = ln_h + 2 > self.max_len                              # tokens = ids + [label, <eos>]
-        take = np.where(cut, self.max_len - 1, ln_h)
-        tail = [(b" <eos>" if k else b"<eos>") if c else (" " + _label_token(v) + " <eos>").encode("ascii")
-                for c, k, v in zip(cut.tolist(), take.tolist(), labels)]
-        blob, ptr = _ops.ids_to_text(ids, torch.from_numpy(take.astype(np.int32)).to(ids.device), strings, tail)
-        raw = bytes(blob.cpu().numpy())
+        y = self.labels()
+        labels = y.tolist()
+        if y.dtype == torch.float32:                               # the tails on the device too (gtok_zinc_text_tails)
+            take, sb, sp = _ops.zinc_text_tails(y.to(ids.device), ln, self.max_len)
+            blob, ptr = _ops.ids_to_text(ids, take, strings, (sb, sp))
+        else:                                                      # labels of another width: Python formats them
+            ln_h = ln.cpu().numpy().astype(np.int64)
+            cut = ln_h + 2 > self.max_len                          # tokens = ids + [label, <eos>]
+            take = np.where(cut, self.max_len - 1, ln_h)
+            tail = [(b" <eos>" if k else b"<eos>") if c else (" " + _label_token(v) + " <eos>").encode("ascii")
+                    for c, k, v in zip(cut.tolist(), take.tolist(), labels)]
+            blob, ptr = _ops.ids_to_text(ids, torch.from_numpy(take.astype(np.int32)).to(ids.device), strings, tail)
+        raw = str(memoryview(blob.cpu().numpy()), "ascii")         # one decode; the items are slices of it
         p = ptr.cpu().tolist()
-        return [raw[p[i]:p[i + 1]].decode("ascii") for i in range(G)], labels
+        return list(map(raw.__getitem__, map(slice, p[:-1], p[1:]))), labels
 
     def __getitem__(self, idx):
         """{'text','label','graph_id'} (reference :197-227).  With a GPU the whole split is rendered on the first
@@ -131,9 +137,12 @@ class ZINCTokenizationDataset(Dataset):
     def labels(self) -> torch.Tensor:
         got = _root().csr.collated_storage(self.zinc_dataset)
         if got is not None and got["y"] is not None:
-            y = torch.as_tensor(got["y"]).reshape(-1).to(torch.float32)
+            y = torch.as_tensor(got["y"]).reshape(-1)
+            y = y if y.dtype in (torch.float32, torch.float64) else y.to(torch.float64)   # (the reference formats y.item(): the stored width counts)
             return y if got["indices"] is None else y[torch.as_tensor(got["indices"], dtype=torch.int64)]
-        return torch.tensor([float(self.zinc_dataset[i].y.item()) for i in range(len(self))], dtype=torch.float32)
+        ys = [self.zinc_dataset[i].y for i in range(len(self))]
+        f32 = all(getattr(v, "dtype", None) == torch.float32 for v in ys)
+        return torch.tensor([float(v.item()) for v in ys], dtype=torch.float32 if f32 else torch.float64)
 
     def tokenize(self, vocab: Dict[str, int], max_len: Optional[int] = None, device=None,
                  ld: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -501,10 +501,34 @@ def collate_packed(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: to
     return X, A
 
 
-def ids_to_text(ids: torch.Tensor, take: torch.Tensor, strings: Sequence[str], suffixes: Optional[Sequence[bytes]] = None):
+def zinc_text_tails(y: torch.Tensor, ln: torch.Tensor, max_len: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """What follows `<p>` in every ZINC text, rendered on the device (gtok_zinc_text_tails; reference
+    zinc_dataset_indexbase.py:186-195, :217-221): y float32 [G] labels, ln int32 [G] ids per row (gtok_ibtt_zinc's lengths).
+    Returns (take int32 [G], suf_bytes uint8 [total], suf_ptr int64 [G + 1]) on the device: ids_to_text(ids, take, strings,
+    (suf_bytes, suf_ptr)) gives exactly the strings ZINCTokenizationDataset.__getitem__ returns."""
+    _need_gpu(ln, "zinc_text_tails")
+    if y.dtype != torch.float32 or ln.dtype != torch.int32 or y.numel() != ln.numel():
+        raise ValueError("zinc_text_tails expects float32 labels and int32 lengths of one size")
+    dev, G = ln.device, int(ln.numel())
+    y, ln = y.to(dev).contiguous(), ln.contiguous()
+    take = torch.empty(G, dtype=torch.int32, device=dev)
+    slen = torch.empty(G, dtype=torch.int64, device=dev)
+    L = lib()
+    check(L.gtok_zinc_text_tails(y.data_ptr(), ln.data_ptr(), G, int(max_len), take.data_ptr(), None, None, slen.data_ptr(),
+                                 _stream(dev)), "gtok_zinc_text_tails")
+    sp = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(slen, 0, out=sp[1:])
+    sb = torch.empty(max(56 * G, 1), dtype=torch.uint8, device=dev)      # a tail is at most 56 bytes: no size round trip
+    check(L.gtok_zinc_text_tails(y.data_ptr(), ln.data_ptr(), G, int(max_len), take.data_ptr(), sp.data_ptr(), sb.data_ptr(), None,
+                                 _stream(dev)), "gtok_zinc_text_tails")
+    return take, sb, sp
+
+
+def ids_to_text(ids: torch.Tensor, take: torch.Tensor, strings: Sequence[str], suffixes=None):
     """Rows of ids -> texts on the device (gtok_ids_to_text): row r = the strings of its first take[r] ids joined by single
     spaces + suffixes[r] verbatim.  Returns (blob uint8 [total], text_ptr int64 [rows + 1]) on the device; text r is
-    blob[text_ptr[r] : text_ptr[r + 1]].  `strings[t]` is the text of id t (ASCII)."""
+    blob[text_ptr[r] : text_ptr[r + 1]].  `strings[t]` is the text of id t (ASCII).  `suffixes`: one bytes object per row,
+    or (suf_bytes uint8, suf_ptr int64 [rows + 1]) already on the device (zinc_text_tails)."""
     _need_gpu(ids, "ids_to_text")
     if ids.dtype != torch.int32 or ids.dim() != 2 or not ids.is_contiguous() or take.dtype != torch.int32:
         raise ValueError("ids_to_text expects a contiguous int32 [rows, ld] slab and int32 counts")
@@ -514,7 +538,12 @@ def ids_to_text(ids: torch.Tensor, take: torch.Tensor, strings: Sequence[str], s
     tab = torch.frombuffer(bytearray(b"".join(enc) or b"\0"), dtype=torch.uint8).to(dev)
     tab_ptr = torch.from_numpy(tptr).to(dev)
     sb = sp = None
-    if suffixes is not None:
+    if isinstance(suffixes, tuple) and len(suffixes) == 2 and torch.is_tensor(suffixes[0]):
+        sb, sp = suffixes
+        if sb.dtype != torch.uint8 or sp.dtype != torch.int64 or sp.numel() != rows + 1 or sb.device != dev or sp.device != dev:
+            raise ValueError("device suffixes are (uint8 bytes, int64 [rows + 1] offsets) on the ids' device")
+        sb, sp = sb.contiguous(), sp.contiguous()
+    elif suffixes is not None:
         if len(suffixes) != rows:
             raise ValueError("one suffix per row")
         sptr = np.zeros(rows + 1, np.int64); np.cumsum(np.fromiter(map(len, suffixes), np.int64, rows), out=sptr[1:])
@@ -527,9 +556,10 @@ def ids_to_text(ids: torch.Tensor, take: torch.Tensor, strings: Sequence[str], s
     check(L.gtok_ids_to_text(*args, None, None, tlen.data_ptr(), _stream(dev)), "gtok_ids_to_text")
     text_ptr = torch.zeros(rows + 1, dtype=torch.int64, device=dev)
     torch.cumsum(tlen, 0, out=text_ptr[1:])
-    blob = torch.empty(max(int(text_ptr[-1]), 1), dtype=torch.uint8, device=dev)
+    total = int(text_ptr[-1])
+    blob = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
     check(L.gtok_ids_to_text(*args, text_ptr.data_ptr(), blob.data_ptr(), None, _stream(dev)), "gtok_ids_to_text")
-    return blob[:int(text_ptr[-1])], text_ptr
+    return blob[:total], text_ptr
 
 
 # ------------------------------------------------------------------------------------------------

@@ -31,6 +31,7 @@
  *                      take a [rows, ld] slab of 16-bit ids in place (row_ptr NULL): the per-batch collate of
  *                      trainer/train_agtt.py:276-302 straight over GTOK_SENT_U16 rows
  *   gtok_ids_to_text   graph_data_loader/zinc_dataset_indexbase.py:143-227, the STRING form (ids rendered through a string table)
+ *   gtok_zinc_text_tails   zinc_dataset_indexbase.py:186-195, :217-221 (label token + <eos> / the max_len cut, per molecule)
  *   gtok_csr_pack8     (no reference counterpart) byte-packed mirror of the CSR index arrays of small-graph batches
  *   gtok_csr_adjbits   (no reference counterpart) adjacency bit-matrix mirror of batches of graphs with <= 256 nodes
  *   gtok_vocab_stats_text   the corpus pass of build_vocab_from_texts / the ZINC dynamic-token scan over arbitrary texts
@@ -352,6 +353,18 @@ int gtok_pack_rows_u16(const uint16_t *ids16, int32_t ld, const int32_t *len, in
 int gtok_ids_to_text(const int32_t *ids, int32_t ld, const int32_t *take, int64_t num_rows, const uint8_t *tab_bytes,
                      const int32_t *tab_ptr, int32_t num_strings, const uint8_t *suf_bytes, const int64_t *suf_ptr,
                      const int64_t *text_ptr, uint8_t *out_bytes, int64_t *text_len, void *stream);
+
+/* The per-molecule TAIL of a ZINC text, for gtok_ids_to_text's suffixes: zinc_dataset_indexbase.py:186-195 (`... <p> val_X_XX
+ * <eos>`, the label token being f"val_{label:.2f}" with '.' -> '_' and '-' -> 'neg', :192) and :217-221 (a text of more than
+ * max_len tokens keeps its first max_len - 1 tokens and `<eos>`).  len[r] = the ids row r holds (gtok_ibtt_zinc's length: up
+ * to and including `<p>`), y[r] = the molecule's float32 label.  With cut = len[r] + 2 > max_len: take[r] = cut ? max_len - 1 :
+ * len[r]; suffix r = [" " if take[r] > 0] + (cut ? "" : label token + " ") + "<eos>" (at most 56 bytes).  The label is "%.2f" of
+ * the float's exact value with ties to even, as Python formats the double that holds it: the sign bit alone decides `neg`
+ * (-0.001 -> val_neg0_00), values of any magnitude print in full, nan / inf / -inf -> val_nan / val_inf / val_neginf.
+ * Two passes like gtok_ids_to_text: suf_bytes == NULL writes take[r] and suf_len[r]; the caller prefix-sums suf_len into
+ * suf_ptr[num_rows+1] and calls again with suf_bytes (capacity suf_ptr[num_rows]).  max_len >= 1.                              */
+int gtok_zinc_text_tails(const float *y, const int32_t *len, int64_t num_rows, int32_t max_len, int32_t *take,
+                         const int64_t *suf_ptr, uint8_t *suf_bytes, int64_t *suf_len, void *stream);
 
 /* First position of `token` in every row of an int64 [rows, ld] batch (what gtok_collate
  * returns): pos[r] = the smallest i with x[r, i] == token, -1 if there is none.  This is the

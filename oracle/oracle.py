@@ -342,6 +342,21 @@ def ids_to_text(ids, take, strings, suffixes=None):
     return out
 
 
+def zinc_text_tails(y, ln, max_len):
+    """What follows the serialiser's ids in a ZINC text (include/gtok.h, gtok_zinc_text_tails): the label token
+    f"val_{label:.2f}" with '.' -> '_' and '-' -> 'neg' (zinc_dataset_indexbase.py:192; label = data.y.item(), :205: the
+    Python float that holds the stored value exactly) and `<eos>` (:195); a text of more than max_len tokens keeps max_len - 1
+    of them and `<eos>` (:217-221).  ln[r] = ids of row r (up to and including `<p>`).  Returns (take int32 [G], [bytes])."""
+    ln = np.asarray(ln, np.int64)
+    cut = ln + 2 > max_len
+    take = np.where(cut, max_len - 1, ln)
+    tails = []
+    for c, k, v in zip(cut.tolist(), take.tolist(), [float(v) for v in np.asarray(y).tolist()]):
+        label = f"val_{v:.2f}".replace(".", "_").replace("-", "neg")
+        tails.append(((" " if k > 0 else "") + ("" if c else label + " ") + "<eos>").encode("ascii"))
+    return take.astype(np.int32), tails
+
+
 # ---- packed rows (include/gtok.h, "packed (ragged) rows"): numpy restatement of the format itself ----------------
 def row_offsets(ln, ld, align=8):
     n = np.clip(np.asarray(ln, np.int64), 0, ld)

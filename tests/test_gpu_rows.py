@@ -172,3 +172,47 @@ def test_ids_to_text_against_the_python_statement_of_the_format():
     e_ids = torch.empty((0, 8), dtype=torch.int32, device=DEV)
     blob, ptr = gtok.ops.ids_to_text(e_ids, torch.empty(0, dtype=torch.int32, device=DEV), strings, [])
     assert blob.numel() == 0 and ptr.tolist() == [0]
+
+
+def test_zinc_text_tails_format_labels_as_python_does():
+    """gtok_zinc_text_tails against the reference's own expression (zinc_dataset_indexbase.py:192, f"val_{label:.2f}" with
+    '.' -> '_' and '-' -> 'neg', restated in oracle.zinc_text_tails): "%.2f" of the float's exact value with ties to even.
+    Random bit patterns of every exponent (denormals, huge values printed in full, nan / inf), exact ties (k / 8: 0.125 ->
+    0.12, 0.375 -> 0.38), values next to a hundredth, signed zeros and tiny negatives (val_neg0_00), ZINC-like labels; the cut
+    rule (:217-221) at max_len 1 / 2 / around the row lengths; then ids_to_text with the device tails == with host bytes."""
+    rng = np.random.default_rng(23)
+    bits = rng.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    ties = (rng.integers(-40000, 40000, 50000) / 8.0).astype(np.float32)
+    near = (rng.integers(-10 ** 6, 10 ** 6, 50000) / 100.0).astype(np.float32)
+    near = np.concatenate([near, np.nextafter(near, np.float32(np.inf)), np.nextafter(near, np.float32(-np.inf))])
+    halves = ((rng.integers(-10 ** 5, 10 ** 5, 50000) * 2 + 1) / 200.0).astype(np.float32)       # x.xx5 as float32 sees it
+    special = np.array([0.0, -0.0, -0.001, 0.004999, 0.005, 0.015, 0.125, 0.375, 2.675, -2.675, 1e-45, -1e-45, 1e10, -1e20, 3.4028235e38,
+                        -3.4028235e38, np.inf, -np.inf, np.nan, 8388608.0, 16777216.0, 16777215.0, 8388607.5, 4194303.75, 99.995,
+                        999999.995, 0.994999, 0.995, 1.005, 4.23, -2.1], np.float32)
+    zinc = rng.normal(0.0, 2.0, 100000).astype(np.float32)
+    y = np.concatenate([bits, ties, near, halves, special, zinc])
+    G = y.size
+    ln = rng.integers(1, 120, G).astype(np.int32)
+    d_y, d_ln = torch.from_numpy(y).to(DEV), torch.from_numpy(ln).to(DEV)
+    for max_len in (1 << 30, 60, 2, 1):
+        take, sb, sp = gtok.ops.zinc_text_tails(d_y, d_ln, max_len)
+        want_take, want = orc.zinc_text_tails(y, ln, max_len)
+        assert np.array_equal(take.cpu().numpy(), want_take)
+        p, b = sp.cpu().numpy(), sb.cpu().numpy().tobytes()
+        assert p[0] == 0 and p[-1] == sum(map(len, want))
+        got = [b[p[r]:p[r + 1]] for r in range(G)]
+        assert got == want, next((r, y[r], got[r], want[r]) for r in range(G) if got[r] != want[r])
+    strings = ["<bos>", "C", "single", "<p>"] + [str(i) for i in range(40)]
+    ids = rng.integers(0, len(strings), (4000, 120)).astype(np.int32)
+    d_ids = torch.from_numpy(ids).to(DEV)
+    for max_len in (1 << 30, 60):
+        take, sb, sp = gtok.ops.zinc_text_tails(d_y[:4000], d_ln[:4000], max_len)
+        blob, ptr = gtok.ops.ids_to_text(d_ids, take, strings, (sb, sp))
+        want_take, tails = orc.zinc_text_tails(y[:4000], ln[:4000], max_len)
+        blob2, ptr2 = gtok.ops.ids_to_text(d_ids, take, strings, tails)
+        assert torch.equal(blob, blob2) and torch.equal(ptr, ptr2)
+        want = orc.ids_to_text(ids, want_take, strings, tails)
+        b, p = blob.cpu().numpy().tobytes(), ptr.cpu().numpy()
+        assert [b[p[r]:p[r + 1]] for r in range(4000)] == want
+    with pytest.raises(gtok.GtokError):
+        gtok.ops.zinc_text_tails(d_y, d_ln, 0)

@@ -43,11 +43,9 @@ def test_ids_to_text_statement_renders_the_reference_strings(max_len):
     strings = ["<bos>", "<eos>", "<atom>", "<bond>", "<q>", "regression", "<p>"] + list(gtok.ops.ZINC_ATOM_SYMBOLS) \
         + list(gtok.ops.ZINC_BOND_NAMES) + [str(i) for i in range(int(d["node_counts"].max()))]
     ids, ln = orc.ibtt_zinc(coo, np.arange(len(strings), dtype=np.int32), 1 << 30, 0, 6 + 6 * int(d["node_counts"].max()) + 8)
-    ln = ln.astype(np.int64)
-    cut = ln + 2 > max_len                                      # tokens = ids + [label, <eos>]
-    take = np.where(cut, max_len - 1, ln)
-    tail = [(b" <eos>" if k else b"<eos>") if c else (" " + zmod._label_token(float(v)) + " <eos>").encode("ascii")
-            for c, k, v in zip(cut.tolist(), take.tolist(), d["y"].tolist())]
+    take, tail = orc.zinc_text_tails(d["y"], ln, max_len)       # label token + <eos> / the cut, as stated in the oracle
+    assert tail == [(b" <eos>" if k else b"<eos>") if c else (" " + zmod._label_token(float(v)) + " <eos>").encode("ascii")
+                    for c, k, v in zip((ln.astype(np.int64) + 2 > max_len).tolist(), take.tolist(), d["y"].tolist())]
     texts = [t.decode("ascii") for t in orc.ids_to_text(ids, take, strings, tail)]
     assert texts == meta[f"zinc_L{max_len}_texts"]
 
