@@ -1259,8 +1259,10 @@ enum { T_INT = 0, T_BOS, T_E, T_N, T_Q, T_P, T_EOS, T_OTHER };
 constexpr int32_t kNoLabel = INT32_MIN;
 // ---------------------------------------------------------------------------------------------
 // number of `<e>` tokens per text = the number of edges of a text in the canonical graph-token form: the sizing pass
-// of gtok_parse_graph_text without the parse.  Streaming: every lane looks at 16 bytes (plus one byte before and three
-// after, overlapping loads) and tests the 16 positions for  [space|start] < e > [space|end].
+// of gtok_parse_graph_text without the parse.  Streaming: every lane looks at 16 bytes (plus two after) and counts the
+// positions where the three bytes `<e>` begin - one byte-aligned dword and one compare per position.  What stands around the
+// three bytes is not looked at: the count is exact for canonical texts and never BELOW the number of `<e>` tokens of any text,
+// which is what a sizing pass owes (a text with `x<e>` in a word gets a slot too many; gtok.ops squeezes such ranges).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) count_edge_tokens_kernel(const uint8_t *__restrict__ bytes, const int64_t *__restrict__ text_ptr,
                                                                 int num_texts, int32_t *__restrict__ num_edges) {
@@ -1271,25 +1273,26 @@ __global__ void __launch_bounds__(256) count_edge_tokens_kernel(const uint8_t *_
   const uint8_t *__restrict__ s = bytes + t0;
   int cnt = 0;
   for (int64_t b0 = (int64_t)lane * 16; b0 < n; b0 += kWave * 16) {
-    uint32_t w[6];                                   // bytes b0-4 .. b0+19; outside the text = space
-    if (b0 >= 4 && b0 + 20 <= n) {
+    uint32_t w[5];                                   // bytes b0 .. b0+19; outside the text = space
+    if (b0 + 20 <= n) {
       const U8x16 x = *reinterpret_cast<const U8x16 *>(s + b0);
-      __builtin_memcpy(&w[0], s + b0 - 4, 4);
-      w[1] = x.a; w[2] = x.b; w[3] = x.c; w[4] = x.d;
-      __builtin_memcpy(&w[5], s + b0 + 16, 4);
+      w[0] = x.a; w[1] = x.b; w[2] = x.c; w[3] = x.d;
+      __builtin_memcpy(&w[4], s + b0 + 16, 4);
     } else {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < 5; ++k) {
         uint32_t v = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int64_t i = b0 - 4 + 4 * k + j; v |= ((i >= 0 && i < n) ? (uint32_t)s[i] : 32u) << (8 * j); }
+        for (int j = 0; j < 4; ++j) { const int64_t i = b0 + 4 * k + j; v |= (i < n ? (uint32_t)s[i] : 32u) << (8 * j); }
         w[k] = v;
       }
     }
-    auto at = [&](int j) -> uint32_t { return (w[(j + 4) >> 2] >> (8 * ((j + 4) & 3))) & 255u; };   // byte b0 + j, j in -4..19
+    constexpr uint32_t kTag = ((uint32_t)'<' << 8) | ((uint32_t)'e' << 16) | ((uint32_t)'>' << 24);   // the three bytes, shifted up by one
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      cnt += (at(j) == '<' && at(j + 1) == 'e' && at(j + 2) == '>' && py_isspace(at(j - 1)) && py_isspace(at(j + 3))) ? 1 : 0;
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t x = (j & 3) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], (uint32_t)(j & 3)) : w[j >> 2];   // bytes b0+j .. b0+j+3
+      cnt += ((x << 8) == kTag) ? 1 : 0;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
   if (lane == 0) num_edges[g] = cnt;

@@ -292,10 +292,11 @@ int gtok_collate(const int32_t *ids, int32_t ld, const int32_t *len,
  * edge_ptr[G+1] and calls again with src/dst to receive the edges in text order.  status 1 marks a
  * text that is not in that form (token out of place, integer of more than 9 digits, several
  * <n>/<q>/<p>, `len` + junk): its other outputs are undefined and the host parser must take it. */
-/* Sizing pass for gtok_parse_graph_text without the parse: num_edges[g] = number of `<e>` tokens of text g (for a
- * text in the canonical form: its number of edges).  A streaming kernel (0.3 ms per 600 MB of text, against one full
- * parse per pass of gtok_parse_graph_text): prefix-sum it into edge_ptr and make ONE parsing call with src / dst.  For a
- * text that turns out not to be canonical (status 1) the count is only an upper bound of what that call writes.       */
+/* Sizing pass for gtok_parse_graph_text without the parse: num_edges[g] = the number of places in text g where the three
+ * bytes `<e>` stand (for a text in the canonical form: its number of `<e>` tokens = its number of edges; for any text: never
+ * less than its `<e>` tokens, so a range sized by it holds whatever the parse writes).  A streaming kernel, against one full
+ * parse per pass of gtok_parse_graph_text: prefix-sum it into edge_ptr and make ONE parsing call with src / dst; a text's
+ * edges are its first num_edges[g] slots as that call reports them (squeeze the ranges where the two counts differ).        */
 int gtok_count_edge_tokens(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts, int32_t *num_edges,
                            void *stream);
 int gtok_parse_graph_text(const uint8_t *bytes, const int64_t *text_ptr, int32_t num_texts,

@@ -613,7 +613,9 @@ def test_graph_token_text_parser_on_the_device():
               "<bos> 3 4 <e> <n> 0 1 2 3 4 <q> shortest_distance 0 3 <p> INF <eos>",
               "<bos> 0 1 <e> <n> 0 1 <p> Len12 <eos>", "<bos> <n> <eos>", "<bos> 007 8 <e> <n> 0 8 <p> no",
               "<bos> 0 1 <e> 1 2 <e> <n> 0 1 2 <q> <e> <p> yes <eos>",          # a stray <e> where any word may stand: not an edge
-              "<bos> 5 6 <e> <n> 5 6 <q> has_cycle <p> <e>"]
+              "<bos> 5 6 <e> <n> 5 6 <q> has_cycle <p> <e>",
+              "<bos> 0 1 <e> <n> 0 1 <q> x<e>y <p> yes <eos>",                  # the sizing pass counts the bytes `<e>`: a slot too many, squeezed
+              "<bos>\t0 1\t<e>\n<n> 0 1 <p> yes"]                               # any Python whitespace separates tokens
     canonical = len(texts)
     texts += ["0 1 <e> <n> 0 1 <q> has_cycle <p> yes <eos>",                     # no <bos>
               "<bos> 0 1 <e> 2 <e> <n> 0 1 2 <p> yes", "<bos> 0 1 2 <e> <n> 0 1 2 <p> no",   # tokens out of place
