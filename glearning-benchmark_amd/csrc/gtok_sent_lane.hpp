@@ -54,20 +54,34 @@ __device__ __forceinline__ int kth_bit32(uint32_t x, int k) {
   // of popcount - k - 1 is moved onto the level's bit with a right shift and merged with one bitop3 (was ashr + and_or).
   const uint32_t nk = ~(uint32_t)k;                       // -k - 1
   const uint32_t y = __builtin_bitreverse32(x);
-  uint32_t base = 0;
-#define GTOK_KTH_LEVEL(HALF, LOG)                                                                  \
-  {                                                                                                \
-    uint32_t mid, t, d;                                                                            \
-    asm("v_sub_u32 %0, %4, %3\n\t"         /* 32 - (base + half) */                               \
-        "v_lshrrev_b32 %1, %0, %5\n\t"     /* the low base + half bits of x */                    \
-        "v_bcnt_u32_b32 %2, %1, %6\n\t"    /* their popcount - k - 1: negative = bit k is above */ \
-        "v_lshrrev_b32 %2, %7, %2\n\t"     /* sign -> the level's bit */                          \
-        "v_bitop3_b32 %0, %2, %8, %3 bitop3:0xea"   /* base | (sign & half) */                      \
-        : "=&v"(mid), "=&v"(t), "=&v"(d) : "v"(base), "n"(32 - HALF), "v"(y), "v"(nk), "n"(31 - LOG), "n"(HALF)); \
-    base = mid;                                                                                    \
-  }
-  GTOK_KTH_LEVEL(16, 4) GTOK_KTH_LEVEL(8, 3) GTOK_KTH_LEVEL(4, 2) GTOK_KTH_LEVEL(2, 1) GTOK_KTH_LEVEL(1, 0)
-#undef GTOK_KTH_LEVEL
+  // One asm statement for the five levels (the compiler closes every asm statement with a wait state of its own), and the
+  // first level - base 0: the shift is a constant, the merge a plain and - takes four instructions instead of five.
+  uint32_t base, mid, t;
+  asm("v_lshrrev_b32 %2, 16, %3\n\t"                    /* the low 16 bits of x */
+      "v_bcnt_u32_b32 %2, %2, %4\n\t"                   /* their popcount - k - 1: negative = bit k is above */
+      "v_lshrrev_b32 %2, 27, %2\n\t"                    /* sign -> bit 4 */
+      "v_and_b32 %0, 16, %2\n\t"
+      "v_sub_u32 %1, 24, %0\n\t"                        /* 32 - (base + 8) */
+      "v_lshrrev_b32 %2, %1, %3\n\t"                    /* the low base + 8 bits of x */
+      "v_bcnt_u32_b32 %2, %2, %4\n\t"
+      "v_lshrrev_b32 %2, 28, %2\n\t"
+      "v_bitop3_b32 %0, %2, 8, %0 bitop3:0xea\n\t"      /* base | (sign & half) */
+      "v_sub_u32 %1, 28, %0\n\t"
+      "v_lshrrev_b32 %2, %1, %3\n\t"
+      "v_bcnt_u32_b32 %2, %2, %4\n\t"
+      "v_lshrrev_b32 %2, 29, %2\n\t"
+      "v_bitop3_b32 %0, %2, 4, %0 bitop3:0xea\n\t"
+      "v_sub_u32 %1, 30, %0\n\t"
+      "v_lshrrev_b32 %2, %1, %3\n\t"
+      "v_bcnt_u32_b32 %2, %2, %4\n\t"
+      "v_lshrrev_b32 %2, 30, %2\n\t"
+      "v_bitop3_b32 %0, %2, 2, %0 bitop3:0xea\n\t"
+      "v_sub_u32 %1, 31, %0\n\t"
+      "v_lshrrev_b32 %2, %1, %3\n\t"
+      "v_bcnt_u32_b32 %2, %2, %4\n\t"
+      "v_lshrrev_b32 %2, 31, %2\n\t"
+      "v_bitop3_b32 %0, %2, 1, %0 bitop3:0xea"
+      : "=&v"(base), "=&v"(mid), "=&v"(t) : "v"(y), "v"(nk));
   return (int)base;
 }
 

@@ -159,6 +159,11 @@ class GraphTokenDatasetForAutoGraph:
         self._items = {}
         self._coll = self._load_cache() if use_cache else None
         if self._coll is None:
+            self._coll = self._process_collated()  # text records parsed on the device, no object per record (None: not applicable)
+            self._plain = self._coll is not None
+            if self._plain and use_cache:
+                self._save_cache()
+        if self._coll is None:
             data_list = self.process()
             self._plain = all(type(d) is Data and set(d.__dict__) <= {"edge_index", "y", "num_nodes", "query_u", "query_v"}
                               for d in data_list)
@@ -273,7 +278,8 @@ class GraphTokenDatasetForAutoGraph:
             return None
         return self.pre_transform(d) if self.pre_transform is not None else d
 
-    def process(self) -> List[Data]:
+    def _list_files(self) -> List[str]:
+        """The split's JSON files in the reference's order, with its per-algorithm sampling (:300-318)."""
         files: List[str] = []
         for algo in self.algorithms:
             pattern = os.path.join(self._split_dir(algo), "*.json")
@@ -286,6 +292,102 @@ class GraphTokenDatasetForAutoGraph:
         if not files:
             raise RuntimeError(f"No JSON files found for algorithms {self.algorithms}. "
                                f"Did you run the graph-token task generator?")
+        return files
+
+    def _process_collated(self):
+        """process() and collate() in one go, without a Data object (and a tuple list) per record: the text records of all
+        files are parsed by one pair of launches and the collated arrays - which are this class's storage - are cut straight
+        out of the parser's edge arrays; records the device does not take (explicit `edges` / `nodes`, texts outside the
+        canonical grammar) are parsed on the host and spliced in.  Same records, same order, same per-file pair sampling as
+        process() (tests/test_gpu_boundary.py compares item for item).  None when this route does not apply: no GPU, too
+        few text records to pay for two launches, or a pre_filter / pre_transform that needs the objects."""
+        if self.pre_filter is not None or self.pre_transform is not None or not torch.cuda.is_available():
+            return None
+        files = self._list_files()
+        per_file: List[list] = []
+        texts: List[str] = []
+        for fp in files:
+            with open(fp, "r") as f:
+                content = json.load(f)
+            recs = content if isinstance(content, list) else [content]
+            per_file.append(recs)
+            for r in recs:
+                if isinstance(r, dict) and not r.get("edges") and not r.get("nodes") and isinstance(r.get("text"), str) and r["text"]:
+                    texts.append(r["text"])
+        if len(texts) < self.DEVICE_PARSE_MIN or not all(t.isascii() for t in texts):
+            return None
+        print(f"[GraphTokenDatasetForAutoGraph] Processing {len(files)} graph files from {len(self.algorithms)} algorithm(s)")
+        ops = _root().ops
+        tb, tp = ops.pack_texts(texts)
+        res = ops.parse_graph_texts(tb.to(torch.device("cuda", torch.cuda.current_device())), tp)
+        st = res["status"].cpu().tolist(); nn = res["num_nodes"].cpu().tolist(); lab = res["label"].cpu().tolist()
+        qn = res["query"].cpu().tolist(); ep = res["edge_ptr"].cpu().tolist()
+        src, dst = res["src"].cpu().numpy(), res["dst"].cpu().numpy()
+        extra_s: List[int] = []
+        extra_d: List[int] = []
+        base = int(src.shape[0])                      # host-parsed edges live behind the device's
+        kept: List[tuple] = []                        # (first edge, edges, num_nodes, label, query)
+        rng = random.Random(self.seed)
+        pairs_mode = self.task == "shortest_path" and self.num_pairs_per_graph is not None
+        sp = self.task == "shortest_path"
+        b = 0
+        for recs in per_file:
+            parsed = []
+            for r in recs:
+                text = r.get("text", "")
+                in_bulk = isinstance(r, dict) and not r.get("edges") and not r.get("nodes") and isinstance(text, str) and text
+                if in_bulk and st[b] == 0:
+                    start, cnt, n = ep[b], ep[b + 1] - ep[b], nn[b]
+                    label = r.get("label")
+                    if label is None:
+                        label = None if lab[b] == ops.NO_LABEL else lab[b]
+                    q = (qn[b][0], qn[b][1]) if (sp and qn[b][0] >= 0) else None
+                    b += 1
+                else:
+                    if in_bulk:                       # outside the canonical grammar: the host parsers take it
+                        b += 1
+                        edges, n, tlabel = parse_graph_from_json({"text": text})
+                        label = r.get("label")
+                        if label is None:
+                            label = tlabel
+                    else:
+                        edges, n, label = parse_graph_from_json(r, task=self.task)
+                    q = parse_query_nodes_from_text(text) if (sp and text) else None
+                    start, cnt = base + len(extra_s), len(edges)
+                    extra_s += [e[0] for e in edges]
+                    extra_d += [e[1] for e in edges]
+                if n == 0 or label is None:
+                    continue
+                if pairs_mode and q is None:
+                    continue
+                parsed.append((start, cnt, n, label, q))
+            if pairs_mode and len(parsed) > self.num_pairs_per_graph:
+                parsed = rng.sample(parsed, self.num_pairs_per_graph)
+            kept += parsed
+        n_items = len(kept)
+        starts = np.fromiter((k[0] for k in kept), np.int64, n_items)
+        counts = np.fromiter((k[1] for k in kept), np.int64, n_items)
+        es = np.zeros(n_items + 1, np.int64)
+        np.cumsum(counts, out=es[1:])
+        all_s = np.concatenate([src.astype(np.int64), np.asarray(extra_s, np.int64)])
+        all_d = np.concatenate([dst.astype(np.int64), np.asarray(extra_d, np.int64)])
+        idx = np.repeat(starts - es[:-1], counts) + np.arange(int(es[-1]), dtype=np.int64)
+        has_q = [k[4] is not None for k in kept]
+        data = {
+            "edge_index": torch.from_numpy(np.stack([all_s[idx], all_d[idx]])) if n_items else torch.empty((2, 0), dtype=torch.long),
+            "y": torch.tensor([k[3] for k in kept], dtype=torch.long) if n_items else torch.empty((0,), dtype=torch.long),
+            "num_nodes": torch.tensor([int(k[2]) for k in kept], dtype=torch.long),
+            "query_u": torch.tensor([int(k[4][0]) if k[4] is not None else -1 for k in kept], dtype=torch.long),
+            "query_v": torch.tensor([int(k[4][1]) if k[4] is not None else -1 for k in kept], dtype=torch.long),
+            "has_query": torch.tensor(has_q, dtype=torch.bool),
+        }
+        one = torch.arange(n_items + 1, dtype=torch.long)
+        slices = {"edge_index": torch.from_numpy(es), "y": one, "num_nodes": one, "query_u": one, "query_v": one, "has_query": one}
+        print(f"[GraphTokenDatasetForAutoGraph] Processed {n_items} data samples")
+        return data, slices
+
+    def process(self) -> List[Data]:
+        files = self._list_files()
         print(f"[GraphTokenDatasetForAutoGraph] Processing {len(files)} graph files from {len(self.algorithms)} algorithm(s)")
         out: List[Data] = []
         rng = random.Random(self.seed)

@@ -201,17 +201,26 @@ def test_process_parses_text_records_on_the_device(task, tmp_path):
     kw = dict(root=str(tmp_path), task=task, algorithm=["er", "ba", "sbm", "path"], split="train", use_cache=False,
               num_pairs_per_graph=2 if task == "shortest_path" else None)
     calls = []
-    real = gdl.graph_token_dataset_autograph.parse_texts_on_device
-    gdl.graph_token_dataset_autograph.parse_texts_on_device = lambda *a, **k: (calls.append(len(a[0])), real(*a, **k))[1]
+    real = gtok.ops.parse_graph_texts
+    gtok.ops.parse_graph_texts = lambda *a, **k: (calls.append(int(a[1].numel()) - 1), real(*a, **k))[1]
     try:
-        dev_ds = G(**kw)
+        dev_ds = G(**kw)                                           # collated storage cut straight out of the parser's arrays
+        obj_ds = G(**kw, pre_transform=lambda d: d)                # the route that needs objects: device parse, then one Data per record
         G.DEVICE_PARSE_MIN = 10 ** 9
         host_ds = G(**kw)
     finally:
         G.DEVICE_PARSE_MIN = 256
-        gdl.graph_token_dataset_autograph.parse_texts_on_device = real
-    assert len(calls) == 1 and calls[0] > 200, "the device parser took the text records of every file in one call"
-    assert len(dev_ds) == len(host_ds) > 100
+        gtok.ops.parse_graph_texts = real
+    assert len(calls) == 2 and calls[0] == calls[1] > 200, "the device parser took the text records of every file in one call"
+    assert len(dev_ds) == len(host_ds) == len(obj_ds) > 100
+    for a, b in zip(obj_ds, host_ds):
+        assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.y, b.y) and a.num_nodes == b.num_nodes
+        assert (getattr(a, "query_u", None), getattr(a, "query_v", None)) == (getattr(b, "query_u", None), getattr(b, "query_v", None))
+    hc = G.collate(list(host_ds))                                  # and the collated pair itself, array for array
+    for k in hc[0]:
+        assert torch.equal(dev_ds._coll[0][k], hc[0][k]) and dev_ds._coll[0][k].dtype == hc[0][k].dtype, k
+    for k in hc[1]:
+        assert torch.equal(dev_ds._coll[1][k], hc[1][k]), k
     for a, b in zip(dev_ds, host_ds):
         assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.y, b.y) and a.num_nodes == b.num_nodes
         assert (getattr(a, "query_u", None), getattr(a, "query_v", None)) == (getattr(b, "query_u", None), getattr(b, "query_v", None))
