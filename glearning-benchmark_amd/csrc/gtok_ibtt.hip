@@ -1272,8 +1272,7 @@ __global__ void __launch_bounds__(256) count_edge_tokens_kernel(const uint8_t *_
   const int64_t t0 = text_ptr[g], n = text_ptr[g + 1] - t0;
   const uint8_t *__restrict__ s = bytes + t0;
   int cnt = 0;
-  for (int64_t b0 = (int64_t)lane * 16; b0 < n; b0 += kWave * 16) {
-    uint32_t w[5];                                   // bytes b0 .. b0+19; outside the text = space
+  auto load = [&](int64_t b0, uint32_t (&w)[5]) __attribute__((always_inline)) {   // bytes b0 .. b0+19; outside the text = space
     if (b0 + 20 <= n) {
       const U8x16 x = *reinterpret_cast<const U8x16 *>(s + b0);
       w[0] = x.a; w[1] = x.b; w[2] = x.c; w[3] = x.d;
@@ -1287,12 +1286,21 @@ __global__ void __launch_bounds__(256) count_edge_tokens_kernel(const uint8_t *_
         w[k] = v;
       }
     }
-    constexpr uint32_t kTag = ((uint32_t)'<' << 8) | ((uint32_t)'e' << 16) | ((uint32_t)'>' << 24);   // the three bytes, shifted up by one
+  };
+  constexpr uint32_t kTag = ((uint32_t)'<' << 8) | ((uint32_t)'e' << 16) | ((uint32_t)'>' << 24);   // the three bytes, shifted up by one
+  auto tags = [&](const uint32_t (&w)[5]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const uint32_t x = (j & 3) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], (uint32_t)(j & 3)) : w[j >> 2];   // bytes b0+j .. b0+j+3
       cnt += ((x << 8) == kTag) ? 1 : 0;
     }
+  };
+  for (int64_t b0 = (int64_t)lane * 16; b0 < n; b0 += 2 * kWave * 16) {   // two 1 KB steps per turn: both loads are out before the first is looked at
+    uint32_t w0[5], w1[5];
+    load(b0, w0);
+    load(b0 + kWave * 16, w1);                                             // (wholly behind the text: reads as spaces)
+    tags(w0);
+    tags(w1);
   }
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
   if (lane == 0) num_edges[g] = cnt;
@@ -1309,6 +1317,19 @@ struct ParseArgs {
 // graph-token text -> edge list, phase 1: the edge zone, streamed (wave per text, 1 KB per step, registers only: a light
 // kernel with many waves per SIMD, so that the loads of one wave travel behind the work of the others)
 // ---------------------------------------------------------------------------------------------
+// `INT INT <e>` triples are nearly all of a text.  The stream walks TAGS, not bytes (round 4; the byte walk it replaces -
+// value / length / all-digits carried over 32 bytes per lane, eight token slots - cost ~750 vector instructions per step):
+//   * every lane classes its 16 bytes with three masks - spaces, digits, bytes of a `<e>` (one byte-aligned dword compare per
+//     position, as the sizing pass does) - and the window passes only if every byte is one of the three (plus `<bos> ` at the
+//     very start of the text);
+//   * for each `<e>` that STARTS in its bytes (at most two: a triple is >= 8 bytes) the lane reads backwards
+//     `> u v <e> ` - a space, v (1-4 digits), a space, u (1-4 digits, at most 7 with v), a space, and the `>` that ends the tag
+//     before (or <bos>) - out of the 12 bytes in front of the tag, with 4-byte SWAR arithmetic for the two numbers; so the
+//     bytes between two consecutive tags are exactly one edge, single spaces, and the edge's index is the tag's rank.
+// The first window in which anything fails - another token, a tab, a double space, a 5-digit id, a tag out of place - and
+// everything behind it go through parse_graph_text_kernel's general loop, which starts right behind the last tag the stream
+// took with the token count where the stream left it: same results, byte for byte.  Integers behind a window's last tag are
+// not taken here; their tag takes them (next window) or the general loop does.
 __global__ void __launch_bounds__(256) parse_edge_zone_kernel(const ParseArgs a) {
   const int lane = lane_id();
   const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave_id();
@@ -1318,109 +1339,135 @@ __global__ void __launch_bounds__(256) parse_edge_zone_kernel(const ParseArgs a)
   const int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
   const int64_t ebase = fill ? a.edge_ptr[g] : 0;
   const int64_t ecap = fill ? a.edge_ptr[g + 1] - ebase : 0;
-  {
-    // ---- the edge zone, streamed.  `INT INT <e>` triples are nearly all of a text, and as long as a 1 KB window holds
-    // nothing but them (and <bos> as token 0) it needs no structure tracking at all: every lane takes 16 bytes - and the 16
-    // before them: a plain token is at most 9 bytes long, so one that ends in the lane's bytes began inside that view - walks
-    // them once (value, length, all-digits, unrolled: every byte sits in a register at a fixed place), notes the tokens that
-    // END in its bytes (at most 8: slot = position / 2), a wave prefix sum numbers them, the triple rule is checked, and only
-    // if the whole window passes are its endpoints stored.  The first window that holds anything else (<n>, a word, a tab, a
-    // long number, a token out of place) and everything after it go through the general loop below, which starts right
-    // behind the last token the stream took, with the token count where the stream left it: same results, byte for byte.
-    int64_t handover = 0;
-    int count = 0, max_end = -1;
-    for (int64_t wb = 0; wb < n; wb += 1024) {
-      const int64_t o = wb + 16 * lane;
-      uint32_t w[8];                                              // bytes o - 16 .. o + 15; outside the text: spaces
+  auto spaces4 = [](uint32_t x) __attribute__((always_inline)) -> uint32_t {   // 0x80 in every byte that is a space
+    const uint32_t y = x ^ 0x20202020u;
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+  };
+  auto nondig4 = [](uint32_t x) __attribute__((always_inline)) -> uint32_t {   // 0x80 in every byte that is NOT a digit
+    const uint32_t t = x ^ 0x30303030u;
+    return (((t & 0x7F7F7F7Fu) + 0x76767676u) | t) & 0x80808080u;
+  };
+  auto nib = [](uint32_t m) __attribute__((always_inline)) -> uint32_t { return (((m >> 7) * 0x00204081u) >> 21) & 15u; };   // 0x80-per-byte -> 4 bits
+  auto atoi4 = [](uint32_t d) __attribute__((always_inline)) -> uint32_t {   // up to four digits, first digit in the lowest byte, bytes in front zeroed
+    d &= 0x0F0F0F0Fu;
+    const uint32_t t = (d * 10u + (d >> 8)) & 0x00FF00FFu;
+    return (t * 100u + (t >> 16)) & 0xFFFFu;
+  };
+  int64_t handover = 0;
+  int tags = 0, max_end = -1;
+  for (int64_t wb = 0; wb < n; wb += 1024) {
+    const int64_t o = wb + 16 * lane;
+    uint32_t w[9];                                              // bytes o - 16 .. o + 19; outside the text: spaces
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int64_t rel = o - 16 + 16 * half;
-        if (rel >= 0 && rel + 16 <= n) {
-          const U8x16 x = *reinterpret_cast<const U8x16 *>(s + rel);
-          w[4 * half] = x.a; w[4 * half + 1] = x.b; w[4 * half + 2] = x.c; w[4 * half + 3] = x.d;
-        } else {
+    for (int half = 0; half < 2; ++half) {
+      const int64_t rel = o - 16 + 16 * half;
+      if (rel >= 0 && rel + 16 <= n) {
+        const U8x16 x = *reinterpret_cast<const U8x16 *>(s + rel);
+        w[4 * half] = x.a; w[4 * half + 1] = x.b; w[4 * half + 2] = x.c; w[4 * half + 3] = x.d;
+      } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            uint32_t v = 0;
+        for (int k = 0; k < 4; ++k) {
+          uint32_t v = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int64_t i = rel + 4 * k + j; v |= ((i >= 0 && i < n) ? (uint32_t)s[i] : 32u) << (8 * j); }
-            w[4 * half + k] = v;
-          }
+          for (int j = 0; j < 4; ++j) { const int64_t i = rel + 4 * k + j; v |= ((i >= 0 && i < n) ? (uint32_t)s[i] : 32u) << (8 * j); }
+          w[4 * half + k] = v;
         }
       }
-      const uint32_t after = (o + 16 < n) ? (uint32_t)s[o + 16] : 32u;
-      auto at = [&](int p) __attribute__((always_inline)) -> uint32_t { return (w[(p + 16) >> 2] >> (8 * ((p + 16) & 3))) & 255u; };   // byte o + p
-      uint32_t val = 0, vals[8] = {0, 0, 0, 0, 0, 0, 0, 0}, endm = 0, kinds = 0;
-      int len = 0, lastp = -1;
-      bool dig = true;
+    }
+    if (o + 20 <= n) {
+      __builtin_memcpy(&w[8], s + o + 16, 4);
+    } else {
+      uint32_t v = 0;
 #pragma unroll
-      for (int p = -16; p < 16; ++p) {
-        const uint32_t c = at(p);
-        const bool sp = c == 32u;
-        const uint32_t dd = c - '0';
-        val = sp ? 0u : val * 10u + dd;
-        len = sp ? 0 : len + 1;
-        dig = sp ? true : (dig && dd < 10u);
-        if (p >= 0) {
-          const uint32_t nx = p < 15 ? at(p + 1) : after;
-          const bool is_end = !sp && nx == 32u;
-          const bool is_e = len == 3 && c == '>' && at(p - 1) == 'e' && at(p - 2) == '<';
-          const bool is_bos = len == 5 && c == '>' && at(p - 1) == 's' && at(p - 2) == 'o' && at(p - 3) == 'b' && at(p - 4) == '<';
-          const uint32_t kind = is_e ? 1u : ((dig && len <= 9) ? 0u : (is_bos ? 2u : 3u));
-          const int slot = p >> 1;
-          vals[slot] = is_end ? val : vals[slot];
-          endm |= is_end ? 1u << slot : 0u;
-          kinds |= is_end ? kind << (2 * slot) : 0u;
-          lastp = is_end ? p : lastp;
+      for (int j = 0; j < 4; ++j) { const int64_t i = o + 16 + j; v |= (i < n ? (uint32_t)s[i] : 32u) << (8 * j); }
+      w[8] = v;
+    }
+    // ---- byte classes of the lane's 16 bytes (sp: and of the four behind them)
+    const uint32_t sp = nib(spaces4(w[4])) | (nib(spaces4(w[5])) << 4) | (nib(spaces4(w[6])) << 8) | (nib(spaces4(w[7])) << 12) |
+                        (nib(spaces4(w[8])) << 16);
+    const uint32_t nd = nib(nondig4(w[4])) | (nib(nondig4(w[5])) << 4) | (nib(nondig4(w[6])) << 8) | (nib(nondig4(w[7])) << 12);
+    constexpr uint32_t kTag = ((uint32_t)'<' << 8) | ((uint32_t)'e' << 16) | ((uint32_t)'>' << 24);   // the three bytes, shifted up by one
+    uint32_t tall = 0;                                          // bit j + 2: `<e>` starts at byte o + j, j = -2 .. 15
+#pragma unroll
+    for (int j = -2; j < 16; ++j) {
+      const int b = 16 + j;
+      const uint32_t x = (b & 3) ? __builtin_amdgcn_alignbyte(w[(b >> 2) + 1], w[b >> 2], (uint32_t)(b & 3)) : w[b >> 2];
+      tall |= ((x << 8) == kTag ? 1u : 0u) << (j + 2);
+    }
+    const uint32_t town = tall >> 2;                            // tags that start in this lane's bytes
+    uint32_t cover = (sp & 0xFFFFu) | (~nd & 0xFFFFu) | (((tall | (tall << 1) | (tall << 2)) >> 2) & 0xFFFFu);
+    bool wrong = false;
+    if (wb == 0) {                                              // the text opens with `<bos> ` (or is `<bos>`)
+      const bool bos = w[4] == 0x736F623Cu && (w[5] & 0xFFFFu) == 0x203Eu;
+      if (lane == 0) { wrong = !bos; cover |= 0x1Fu; }
+    }
+    wrong = wrong || cover != 0xFFFFu || __popc(town) > 2;
+    // ---- the (at most two) tags that start here: `> u v <e> ` read backwards
+    uint32_t eu[2] = {0u, 0u}, ev[2] = {0u, 0u};
+    uint32_t tm = town;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const bool has = tm != 0u;
+      const int j = has ? (int)__builtin_ctz(tm) : 0;
+      tm &= tm - 1u;
+      const int b = (j + 4) >> 2;                               // w[b] holds byte o + j - 12
+      const uint32_t sh = (uint32_t)(j & 3);
+      const bool b1 = b == 1, b2 = b == 2, b3 = b == 3;
+      const uint32_t y0 = b1 ? w[1] : (b2 ? w[2] : (b3 ? w[3] : w[4]));
+      const uint32_t y1 = b1 ? w[2] : (b2 ? w[3] : (b3 ? w[4] : w[5]));
+      const uint32_t y2 = b1 ? w[3] : (b2 ? w[4] : (b3 ? w[5] : w[6]));
+      const uint32_t y3 = b1 ? w[4] : (b2 ? w[5] : (b3 ? w[6] : w[7]));
+      const uint32_t x0 = __builtin_amdgcn_alignbyte(y1, y0, sh);   // bytes j - 12 .. j - 9
+      const uint32_t x1 = __builtin_amdgcn_alignbyte(y2, y1, sh);   //       j -  8 .. j - 5
+      const uint32_t x2 = __builtin_amdgcn_alignbyte(y3, y2, sh);   //       j -  4 .. j - 1
+      bool ok = ((sp >> (j + 3)) & 1u) != 0u && (x2 >> 24) == 32u;   // a space (or the text's end) behind the tag, a space in front
+      // v: the digits that end at byte j - 2
+      const uint32_t v4 = __builtin_amdgcn_alignbyte(x2, x1, 3u);   // bytes j - 5 .. j - 2
+      const uint32_t vs = spaces4(v4) & 0x00808080u;
+      const int lv = vs ? 3 - (int)((31u - (uint32_t)__builtin_clz(vs)) >> 3) : 4;
+      const uint32_t vkeep = 0xFFFFFFFFu << (8 * (4 - lv));
+      ok = ok && (nondig4(v4) & vkeep) == 0u && (lv < 4 || ((x1 >> 16) & 255u) == 32u);
+      // u: the digits that end at byte j - 3 - lv
+      const uint32_t u4 = lv <= 2 ? __builtin_amdgcn_alignbyte(x2, x1, (uint32_t)(2 - lv)) : __builtin_amdgcn_alignbyte(x1, x0, (uint32_t)(6 - lv));
+      const uint32_t us = spaces4(u4) & 0x00808080u;
+      const int lu = us ? 3 - (int)((31u - (uint32_t)__builtin_clz(us)) >> 3) : 4;
+      const uint32_t ukeep = 0xFFFFFFFFu << (8 * (4 - lu));
+      ok = ok && (nondig4(u4) & ukeep) == 0u && lv + lu <= 7;
+      // `> ` in front of u: bytes j - 4 - lv - lu, j - 3 - lv - lu
+      const int pq = 8 - lv - lu;                               // their offset behind byte j - 12: 1 .. 6 when lv + lu <= 7
+      const uint32_t pp = pq < 4 ? __builtin_amdgcn_alignbyte(x1, x0, (uint32_t)(pq & 3)) : __builtin_amdgcn_alignbyte(x2, x1, (uint32_t)(pq & 3));
+      ok = ok && (pp & 0xFFFFu) == 0x203Eu;
+      wrong = wrong || (has && !ok);
+      ev[q] = atoi4(v4 & vkeep);
+      eu[q] = atoi4(u4 & ukeep);
+    }
+    const int nt = __popc(town);
+    int incl = nt;
+#pragma unroll
+    for (int dsh = 1; dsh < kWave; dsh <<= 1) { const int up = __shfl_up(incl, dsh); if (lane >= dsh) incl += up; }
+    if (__ballot(wrong) != 0) break;
+    {
+      const int64_t k0 = (int64_t)tags + incl - nt;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (q < nt) {
+          max_end = max(max_end, (int)max(eu[q], ev[q]));
+          if (fill && k0 + q < ecap) { a.src[ebase + k0 + q] = (int)eu[q]; a.dst[ebase + k0 + q] = (int)ev[q]; }
         }
-      }
-      const int nt = __popc(endm);
-      int incl = nt;
-#pragma unroll
-      for (int dsh = 1; dsh < kWave; dsh <<= 1) { const int up = __shfl_up(incl, dsh); if (lane >= dsh) incl += up; }
-      const int first_idx = count + incl - nt;
-      bool wrong = false;
-      {
-        int t = first_idx;
-#pragma unroll
-        for (int slot = 0; slot < 8; ++slot)
-          if ((endm >> slot) & 1u) {
-            const uint32_t kind = (kinds >> (2 * slot)) & 3u;
-            const uint32_t r = (uint32_t)(t - 1) - 3u * (__umulhi((uint32_t)(t - 1), 0xAAAAAAABu) >> 1);
-            wrong = wrong || (t == 0 ? kind != 2u : kind != (r == 2u ? 1u : 0u));
-            ++t;
-          }
-      }
-      if (__ballot(wrong) != 0) break;
-      {
-        int t = first_idx;
-#pragma unroll
-        for (int slot = 0; slot < 8; ++slot)
-          if ((endm >> slot) & 1u) {
-            if (t > 0) {
-              const uint32_t k = __umulhi((uint32_t)(t - 1), 0xAAAAAAABu) >> 1, r = (uint32_t)(t - 1) - 3u * k;
-              if (r != 2u) {
-                max_end = max(max_end, (int)vals[slot]);
-                if (fill && (int64_t)k < ecap) { if (r == 0u) a.src[ebase + k] = (int)vals[slot]; else a.dst[ebase + k] = (int)vals[slot]; }
-              }
-            }
-            ++t;
-          }
-      }
-      count += __builtin_amdgcn_readlane(incl, 63);
-      const uint64_t holders = __ballot(endm != 0u);
-      if (holders) {
-        const int l = 63 - __builtin_clzll(holders);
-        handover = wb + 16 * l + __builtin_amdgcn_readlane(lastp, l) + 1;
-      }
     }
-    for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
-    if (lane == 0) {   // state for parse_graph_text_kernel (which overwrites these slots with the text's results)
-      a.num_edges[g] = count;
-      a.num_nodes[g] = max_end;
-      a.query[2 * (int64_t)g] = (int32_t)(uint32_t)handover;
-      a.query[2 * (int64_t)g + 1] = (int32_t)(handover >> 32);
+    tags += __builtin_amdgcn_readlane(incl, 63);
+    const uint64_t holders = __ballot(town != 0u);
+    if (holders) {
+      const int l = 63 - __builtin_clzll(holders);
+      handover = wb + 16 * l + (31 - __builtin_clz((uint32_t)__builtin_amdgcn_readlane((int)town, l))) + 3;
     }
+  }
+  for (int off = 32; off > 0; off >>= 1) max_end = max(max_end, __shfl_xor(max_end, off));
+  if (lane == 0) {   // state for parse_graph_text_kernel (which overwrites these slots with the text's results)
+    a.num_edges[g] = tags ? 1 + 3 * tags : 0;                   // tokens taken: <bos> and the triples
+    a.num_nodes[g] = max_end;
+    a.query[2 * (int64_t)g] = (int32_t)(uint32_t)handover;
+    a.query[2 * (int64_t)g + 1] = (int32_t)(handover >> 32);
   }
 }
 
@@ -1451,10 +1498,14 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
     int64_t n = a.text_ptr[g + 1] - a.text_ptr[g];
     const int64_t ebase = fill ? a.edge_ptr[g] : 0;
     const int64_t ecap = fill ? a.edge_ptr[g + 1] - ebase : 0;
+    // a token's bytes, read again (tags, label words): out of the ring when they lie in the chunk being split or the one
+    // behind it - a byte from HBM per step of these compare loops made them the kernel's time: ~100 dependent loads per text
+    int64_t ring_lo = 0;                                          // first byte (of the text as this loop sees it) the ring holds
+    auto tb = [&](int64_t i) __attribute__((always_inline)) -> uint32_t { return i >= ring_lo ? (uint32_t)ring[i & (kTextRing - 1)] : (uint32_t)s[i]; };
     auto lit = [&](int64_t i, int len, const char *w, int wl) -> bool {   // token == literal (upper-cased text)
       if (len != wl) return false;
       for (int j = 0; j < wl; ++j) {
-        uint32_t c = s[i + j];
+        uint32_t c = tb(i + j);
         if (c >= 'a' && c <= 'z') c -= 32;
         if (c != (uint32_t)w[j]) return false;
       }
@@ -1489,6 +1540,7 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
         wave_sync();
         ring16[(cdone & 1) * 64 + lane] = U8x16a{nxt.a, nxt.b, nxt.c, nxt.d};
         wave_sync();
+        ring_lo = b0;                                             // chunk cdone is gone from the ring
         nxt = load16(t0 + (cdone + 3) * kTextChunk + lane * 16);
       }
       const int64_t i = b0 + lane;
@@ -1562,6 +1614,16 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
           continue;
         }
       }
+      // ---- likewise the node list behind <n>: pieces that hold nothing but integers (the list's end - the first token that
+      // is not one - is still ahead, so neither <q> nor <p> has been seen)
+      if (tn >= 0 && tq < 0 && count > tn) {
+        const bool plain = !start || (alldig && len <= 9);
+        if (__ballot(!plain) == 0) {
+          if (start) { max_node = max(max_node, (int)h); ++nnodes; }
+          count += __popcll(em);
+          continue;
+        }
+      }
       int type = T_OTHER, val = (int)h, lab = kNoLabel;
       bool is_sd = false;
       if (start) {
@@ -1569,7 +1631,7 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
         if (alldig) { type = T_INT; if (len > 9) bad = 1; }
         else if (len == 3 && lane >= 2) {                           // a tag inside this piece: bytes are in registers
           if (p2 == '<' && c == '>') type = p1 == 'e' ? T_E : p1 == 'n' ? T_N : p1 == 'q' ? T_Q : p1 == 'p' ? T_P : T_OTHER;
-        } else if (s[ts] == '<') {                                  // <bos> / <eos>, or a tag across two pieces
+        } else if (tb(ts) == '<') {                                  // <bos> / <eos>, or a tag across two pieces
           if (lit(ts, len, "<E>", 3)) type = T_E;
           else if (lit(ts, len, "<N>", 3)) type = T_N;
           else if (lit(ts, len, "<Q>", 3)) type = T_Q;
@@ -1577,17 +1639,17 @@ __global__ void __launch_bounds__(256) parse_graph_text_kernel(const ParseArgs a
           else if (lit(ts, len, "<BOS>", 5)) type = T_BOS;
           else if (lit(ts, len, "<EOS>", 5)) type = T_EOS;
           // the reference compares these tags case-sensitively: an upper-case variant is not a tag
-          if (type != T_OTHER) for (int j = 1; j < len - 1; ++j) if (s[ts + j] < 'a') type = T_OTHER;
+          if (type != T_OTHER) for (int j = 1; j < len - 1; ++j) if (tb(ts + j) < 'a') type = T_OTHER;
         }
         if (type == T_OTHER && !alldig) {
           is_sd = len == 17;
-          if (is_sd) { const char *w = "shortest_distance"; for (int j = 0; j < 17; ++j) is_sd = is_sd && s[ts + j] == (uint8_t)w[j]; }
+          if (is_sd) { const char *w = "shortest_distance"; for (int j = 0; j < 17; ++j) is_sd = is_sd && tb(ts + j) == (uint32_t)(uint8_t)w[j]; }
           // label words (reference :80-113, upper-cased): YES / NO / LENk / INF / INFINITY
           if (lit(ts, len, "YES", 3)) lab = 1;
           else if (lit(ts, len, "NO", 2)) lab = 0;
           else if (len > 3 && len <= 12 && lit(ts, 3, "LEN", 3)) {
             int k = 0; bool ok = true;
-            for (int j = 3; j < len; ++j) { const uint32_t cj = s[ts + j]; ok = ok && cj >= '0' && cj <= '9'; k = k * 10 + (int)(cj - '0'); }
+            for (int j = 3; j < len; ++j) { const uint32_t cj = tb(ts + j); ok = ok && cj >= '0' && cj <= '9'; k = k * 10 + (int)(cj - '0'); }
             if (ok) lab = k - 1; else lab = kNoLabel + 1;     // LEN<junk>: the reference tries the next <p>: not canonical
           }
         }

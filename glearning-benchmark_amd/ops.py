@@ -588,18 +588,32 @@ def parse_graph_texts(text_bytes: torch.Tensor, text_ptr: torch.Tensor) -> Dict[
     cnt = i32(G)
     _lib.check(L.gtok_count_edge_tokens(text_bytes.data_ptr(), text_ptr.data_ptr(), G, cnt.data_ptr(), _stream(dev)),
                "gtok_count_edge_tokens")
-    torch.cumsum(cnt.to(torch.int64), 0, out=edge_ptr[1:])
-    cap = int(edge_ptr[-1])
-    src, dst = i32(max(cap, 1)), i32(max(cap, 1))
-    _lib.check(L.gtok_parse_graph_text(text_bytes.data_ptr(), text_ptr.data_ptr(), G, edge_ptr.data_ptr(), src.data_ptr(),
-                                       dst.data_ptr(), ne.data_ptr(), nn.data_ptr(), q.data_ptr(), lab.data_ptr(),
-                                       st.data_ptr(), _stream(dev)), "gtok_parse_graph_text")
+    torch.cumsum(cnt, 0, dtype=torch.int64, out=edge_ptr[1:])
+    # No host round trip for the size: an edge of a text the parser accepts is at least 8 bytes (`0 1 <e> `), so the edge
+    # arrays are sized by the bytes; a corpus with enough junk to count more `<e>` than that has its ranges clamped for this
+    # pass and is parsed again with exact arrays (seen in the one read-back below).
+    bound = int(text_bytes.numel()) // 8 + G + 1
+    clamped = edge_ptr.clamp(max=bound)
+
+    def parse(ptr, n_edges):
+        s_, d_ = i32(max(n_edges, 1)), i32(max(n_edges, 1))
+        _lib.check(L.gtok_parse_graph_text(text_bytes.data_ptr(), text_ptr.data_ptr(), G, ptr.data_ptr(), s_.data_ptr(),
+                                           d_.data_ptr(), ne.data_ptr(), nn.data_ptr(), q.data_ptr(), lab.data_ptr(),
+                                           st.data_ptr(), _stream(dev)), "gtok_parse_graph_text")
+        return s_, d_
+    src, dst = parse(clamped, bound)
     # every canonical text owns exactly its first num_edges slots; normally that is its whole range (one `<e>` token per
     # edge).  Texts outside the grammar (status != 0) own nothing, and a canonical text may carry a stray `<e>` where the
     # grammar allows any word (right after <q> / <p>): then the ranges are squeezed.
-    keep = torch.where(st == 0, ne, torch.zeros_like(ne)).to(torch.int64)
-    if bool((keep == cnt.to(torch.int64)).all()):
+    keep = torch.where(st == 0, ne, torch.zeros_like(ne))
+    cap, differ = torch.stack([edge_ptr[-1], (keep != cnt).any().to(torch.int64)]).tolist()
+    if cap > bound:
+        src, dst = parse(edge_ptr, cap)
+        keep = torch.where(st == 0, ne, torch.zeros_like(ne))
+        differ = int(not torch.equal(keep, cnt))
+    if not differ:
         return dict(num_edges=ne, num_nodes=nn, query=q, label=lab, status=st, edge_ptr=edge_ptr, src=src[:cap], dst=dst[:cap])
+    keep = keep.to(torch.int64)
     new_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
     torch.cumsum(keep, 0, out=new_ptr[1:])
     total = int(new_ptr[-1])

@@ -643,6 +643,25 @@ def test_graph_token_text_parser_on_the_device():
         assert (oe, on, ol, oq) == (edges, n, label, gm.parse_query_nodes_from_text(text)), g   # oracle == mirror too
 
 
+def test_graph_token_text_parser_with_more_tag_bytes_than_edges_fit():
+    """ops.parse_graph_texts sizes its edge arrays by the bytes (an accepted edge is >= 8 bytes) instead of reading the
+    count back; a corpus whose junk holds more `<e>` than that is parsed a second time with exact arrays: the canonical
+    texts behind the junk keep every edge."""
+    good = gtok.synth.graph_token_like(20, seed=5, task="cycle_check", min_nodes=5, max_nodes=40)["texts"]
+    texts = ["<e>" * 4000, "<bos> " + "<e> " * 500 + "<n> 0 <p> yes"] + good
+    tb, tp = gtok.ops.pack_texts(texts)
+    assert 4000 + 500 > tb.numel() // 8 + len(texts) + 1          # the case is the one meant
+    r = gtok.ops.parse_graph_texts(tb.to(DEV), tp)
+    st = r["status"].cpu().numpy()
+    assert st[0] == 1 and st[1] == 1 and not st[2:].any()
+    ep = r["edge_ptr"].cpu().numpy(); src = r["src"].cpu().numpy(); dst = r["dst"].cpu().numpy()
+    assert ep[1] == ep[0] and ep[2] == ep[1] and ep[-1] == src.size == dst.size
+    for g in range(2, len(texts)):
+        edges, n, query, label = orc.parse_graph_text(texts[g])
+        assert list(zip(src[ep[g]:ep[g + 1]].tolist(), dst[ep[g]:ep[g + 1]].tolist())) == edges, g
+        assert int(r["num_nodes"][g]) == n
+
+
 def test_sent_decode_kernel_equals_the_oracle_decoder():
     """§8f-4: gtok_sent_decode == oracle_sent_decode on the GPU's own SENT rows (labelled, unlabelled, cut at max_len,
     large graphs), on damaged rows (same status, same partial output) and when the output capacities are too small; and
@@ -1122,10 +1141,18 @@ def test_graph_token_text_parser_streamed_edge_zone_against_the_host_parser():
     for task in ("cycle_check", "shortest_path"):
         base += gtok.synth.graph_token_like(60, seed=91, task=task, min_nodes=40, max_nodes=230)["texts"]
     assert max(len(t) for t in base) > 12000
+    # ids of one to five digits (the stream reads numbers of up to four digits, at most seven per edge; longer ones go to the
+    # general loop), every tag position modulo 16 and every window border
+    for k in range(40):
+        m = int(rng.integers(3, 1500))
+        hi = [10, 100, 1000, 10000, 100000][k % 5]
+        e = rng.integers(0, hi, (m, 2))
+        nn = int(e.max()) + 1
+        base.append("<bos> " + " ".join(f"{a} {b} <e>" for a, b in e.tolist()) + " <n> " + " ".join(map(str, range(min(nn, 300)))) + " <q> has_cycle <p> yes <eos>")
     texts = list(base)
     junk = ["x", "12345678901", "1234567890", "007", "<e>", "<n>", "<q>", "+1", "-2", "3.5", "<bos>", "<E>", "9" * 9, "\x01", "<e", "e>"]
     for t in base:
-        for _ in range(3):
+        for _ in range(6):
             u = t
             for _ in range(int(rng.integers(1, 4))):
                 k = int(rng.integers(0, len(u)))
