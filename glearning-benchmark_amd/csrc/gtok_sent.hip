@@ -206,8 +206,15 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
       // (the opt-in to more than 64 KB of dynamic LDS is per kernel and per device: a host-side call of a microsecond)
       const bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       int occ16 = 0;
+      // One 16-wave workgroup per CU, except where ONE nearly full round of units ends in the int32 slab's padding (ZINC-full x 1
+      // epoch, a 31 k shard x 8): there two 8-wave workgroups per CU let one half of a CU pad while the other still walks
+      // (0.0740 against 0.0769 ms, 8.98 against 9.50 us per epoch; every other shape - fewer units, several rounds, 16-bit rows,
+      // no padding - is 1-4 % better with 16: profiles/r04/wg_waves.txt)
+      const int slots = ncu * 16;
+      const bool one_full_round = vunits <= slots && 4 * (int64_t)vunits > 3 * (int64_t)slots;
       const char *ww = std::getenv("GTOK_LANE_WG_WAVES");   // tuning knob: 8 = two 8-wave workgroups per CU
-      const int wgw = (ww && ww[0] == '8') ? 8 : (ww && ww[0] == '1' && ww[1] == '2') ? 12 : 16;   // 12: three waves per SIMD
+      const int wgw = ww ? ((ww[0] == '8') ? 8 : (ww[0] == '1' && ww[1] == '2') ? 12 : 16)   // 12: three waves per SIMD
+                         : (one_full_round && !u16 && !(p->flags & GTOK_SENT_NO_PAD) ? 8 : 16);
       const int per_cu = wgw == 8 ? 2 : 1;
       const size_t wg_lds = (size_t)a.lds * wgw + kLaneWgShared;
       if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 64 * wgw, wg_lds) == hipSuccess && occ16 >= per_cu) {

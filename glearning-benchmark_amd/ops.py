@@ -514,6 +514,7 @@ def zinc_text_tails(y: torch.Tensor, ln: torch.Tensor, max_len: int) -> Tuple[to
     take = torch.empty(G, dtype=torch.int32, device=dev)
     slen = torch.empty(G, dtype=torch.int64, device=dev)
     L = lib()
+    max_len = int(min(max_len, 2 ** 31 - 1))
     check(L.gtok_zinc_text_tails(y.data_ptr(), ln.data_ptr(), G, int(max_len), take.data_ptr(), None, None, slen.data_ptr(),
                                  _stream(dev)), "gtok_zinc_text_tails")
     sp = torch.zeros(G + 1, dtype=torch.int64, device=dev)
