@@ -430,7 +430,7 @@ def main():
     # what an epoch of the dataset classes costs on the device: Graph2TrailTokenizer.epochs_for(G) epochs per launch as 16-bit
     # rows without padding (agtt.TokenizedGraphDataset.tokenize_epoch_u16 / the tokenizer's _serve) - every workload
     if not args.no_unpadded and not rows_u16:
-        Kd = max(1, min(32, gtok.Graph2TrailTokenizer.EPOCH_WALKS // max(1, G)))
+        Kd = gtok.Graph2TrailTokenizer.epochs_for_shape(G, ld)
         idsk = torch.empty((Kd * G, ld), dtype=torch.int16, device=dev)
         lnk = torch.empty((Kd * G,), dtype=torch.int32, device=dev)
         fk = lambda j: gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=j * Kd, ld=ld, out=(idsk, lnk), pad=False, epochs=Kd, u16=True, **kw)
@@ -733,7 +733,7 @@ def main():
         # buffer is [Es, per, ld] (epoch-major); the gathered slab is rank-major: epoch e of graph g sits at row
         # ((g // per) * Es + e) * per + g % per - consumers index it (gtok_collate takes any row list).
         Gs, per = hi - lo, -(-Gt // world)
-        Es = max(1, min(32, gtok.Graph2TrailTokenizer.EPOCH_WALKS // max(1, Gs))) if Gt % world == 0 else 1
+        Es = gtok.Graph2TrailTokenizer.epochs_for_shape(Gs, ld) if Gt % world == 0 else 1
         if os.environ.get("GTOK_BENCH_STRONG_EPOCHS"):
             Es = max(1, int(os.environ["GTOK_BENCH_STRONG_EPOCHS"]))
         sids = torch.empty((Es * Gs, ld), dtype=torch.int16, device=dev)

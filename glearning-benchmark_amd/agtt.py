@@ -93,7 +93,10 @@ class TokenizedGraphDataset(Dataset):
         batch = self._graphs()
         sl = self._slab
         if sl is None or not sl[2] <= epoch < sl[2] + sl[0].shape[0]:
-            K = self.tokenizer.epochs_for(batch.num_graphs) if hasattr(self.tokenizer, "epochs_for") else 1
+            K = 1
+            if hasattr(self.tokenizer, "epochs_for"):
+                K = self.tokenizer.epochs_for(batch.num_graphs, _ops.sent_safe_ld(batch, self.tokenizer.labeled_graph, self.tokenizer._max_len(),
+                                                                                   self._query is not None))
             ids, ln = self.tokenizer.tokenize_batch(batch, epoch=epoch, remap_zinc=self.remap_to_fixed_vocab, query=self._query,
                                                     pad=False, epochs=K, u16=True)
             G = batch.num_graphs

@@ -96,17 +96,27 @@ class Graph2TrailTokenizer:
                          remap_zinc=remap_zinc, pad_id=self.pad, graph_base=graph_base, query=query, ld=ld, out=out, pad=pad,
                          epochs=epochs, u16=u16)
 
-    EPOCH_WALKS = 1 << 20         # walks per launch: four rounds of the 4,096 resident waves x 64 lanes of sent_lane_kernel - units that
-                                  # are staged and padded while other waves walk cost less than those of a one-round launch (ZINC-full as
-                                  # 16-bit rows: 0.0573 ms per epoch at 4 epochs per launch against 0.0648 at one)
+    EPOCH_WALKS = 1 << 22         # walks per launch: sixteen rounds of the 4,096 resident waves x 64 lanes of sent_lane_kernel - units that
+                                  # are staged and padded while other waves walk cost less than those of a one-round launch, and the
+                                  # launch's ragged end is shared by more epochs (ZINC-full as 16-bit rows, per epoch: 0.0653 ms at one
+                                  # epoch per launch, 0.0573 at 4, 0.0535 at 8, 0.0516 at 16)
+    EPOCH_SLAB_BYTES = 2 << 30    # ... as long as the K-epoch slab of 16-bit rows stays below this (125 k graph-token graphs x 1,032 ids: 8)
 
-    def epochs_for(self, num_graphs: int) -> int:
-        """How many epochs of a split of `num_graphs` graphs one launch should carry.  The reference re-tokenizes a split
-        every epoch (trainer/train_agtt.py:246-250, epoch loop :676-680) and a trail depends on (seed, epoch, graph) only:
-        a 12 k-molecule split (configs/agtt_zinc.yaml:4 `subset: true`) tokenizes 32 epochs in the time of four."""
+    @classmethod
+    def epochs_for_shape(cls, num_graphs: int, ld: Optional[int] = None) -> int:
+        k = cls.EPOCH_WALKS // max(1, int(num_graphs))
+        if ld:
+            k = min(k, cls.EPOCH_SLAB_BYTES // max(1, 2 * int(num_graphs) * int(ld)))
+        return max(1, min(32, k))
+
+    def epochs_for(self, num_graphs: int, ld: Optional[int] = None) -> int:
+        """How many epochs of a split of `num_graphs` graphs (rows of `ld` ids) one launch should carry.  The reference
+        re-tokenizes a split every epoch (trainer/train_agtt.py:246-250, epoch loop :676-680) and a trail depends on (seed,
+        epoch, graph) only: a 12 k-molecule split (configs/agtt_zinc.yaml:4 `subset: true`) tokenizes 32 epochs in the time of
+        four."""
         if self.epochs_per_launch is not None:
             return max(1, int(self.epochs_per_launch))
-        return max(1, min(32, self.EPOCH_WALKS // max(1, int(num_graphs))))
+        return self.epochs_for_shape(num_graphs, ld)
 
     # ---- reference call site: one Data in, one 1-D LongTensor out, a fresh random trail per call
     def _signature(self):
@@ -130,7 +140,7 @@ class Graph2TrailTokenizer:
         if row is None:
             sp.epoch += 1
             if sp.slab is None or not sp.first <= sp.epoch < sp.first + sp.slab[0].shape[0]:
-                K = self.epochs_for(sp.batch.num_graphs)
+                K = self.epochs_for(sp.batch.num_graphs, _ops.sent_safe_ld(sp.batch, self.labeled_graph, self._max_len()))
                 ids, ln = self.tokenize_batch(sp.batch, epoch=sp.epoch, pad=False, epochs=K, u16=True)
                 G = sp.batch.num_graphs
                 sp.slab, sp.first = (ids.view(K, G, -1), ln.view(K, G)), sp.epoch

@@ -166,13 +166,15 @@ def test_packed_rows_and_strings_at_zinc_full_size(zinc_full):
     assert torch.equal(td_all.seqs[ZINC_FULL - 1], g_ids[ZINC_FULL - 1, :int(g_len[-1])].long().cpu())
 
 
-def test_sent_zinc_full_four_epochs_per_launch_as_16_bit_rows(zinc_full):
-    """What an epoch of the dataset classes runs at ZINC-full size (tokenizer.epochs_for(249,456) = 4 epochs per launch, 16-bit rows,
-    no padding; ~1 M walks in several rounds of resident waves, the (unit, epoch) pairs epoch-major): every epoch slice
-    bit-exact against the oracle inside the row lengths, and every un-remapped row of every slice decodes back to its molecule."""
+def test_sent_zinc_full_sixteen_epochs_per_launch_as_16_bit_rows(zinc_full):
+    """What an epoch of the dataset classes runs at ZINC-full size (tokenizer.epochs_for(249,456, ld) = 16 epochs per launch, 16-bit
+    rows, no padding; ~4 M walks in sixteen rounds of resident waves, the (unit, epoch) pairs epoch-major): every epoch slice
+    bit-exact against the oracle inside the row lengths, and every un-remapped row of the first, a middle and the last slice
+    decodes back to its molecule."""
     d, host, dev, coo = zinc_full
-    K, ld = 4, 192
-    assert gtok.Graph2TrailTokenizer(dataset_names=[], max_length=1024, labeled_graph=True).epochs_for(ZINC_FULL) == K
+    K, ld = 16, 192
+    tok = gtok.Graph2TrailTokenizer(dataset_names=[], max_length=1024, labeled_graph=True)
+    assert tok.epochs_for(ZINC_FULL, ld) == K == tok.epochs_for(ZINC_FULL) and tok.epochs_for(125000, 1040) == 8 and tok.epochs_for(12000, 208) == 32
     kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
     ids, ln = gtok.ops.sent(dev, 37, 1024, 7, 100, ld=ld, epochs=K, u16=True, pad=False, **kw)
     assert ids.dtype == torch.int16 and tuple(ids.shape) == (K, ZINC_FULL, ld) and int(ln.max()) <= ld
@@ -183,9 +185,10 @@ def test_sent_zinc_full_four_epochs_per_launch_as_16_bit_rows(zinc_full):
         got = ids[e].cpu().numpy().view(np.uint16)
         inside = np.arange(ld)[None, :] < rln[:, None]
         assert np.array_equal(np.where(inside, got, 0), np.where(inside, ref, 0)), e
-    # the round trip on the un-remapped flavour (the decoder reads raw SENT ids), all four epochs in one launch
+    del ids, ln
+    # the round trip on the un-remapped flavour (the decoder reads raw SENT ids), all sixteen epochs in one launch
     raw, rl = gtok.ops.sent(dev, 37, 1024, 11, 40, labeled=True, num_node_types=28, num_edge_types=6, ld=ld, epochs=K, u16=True)
-    for e in range(K):
+    for e in (0, 7, K - 1):
         rows = raw[e].cpu().numpy().view(np.uint16).astype(np.int32)
         st = orc.sent_roundtrip(coo, rows, rl[e].cpu().numpy(), 37, 1024, 11, 40 + e, labeled=True, num_node_types=28, nthreads=THREADS)
         assert not st.any(), (e, int((st != 0).sum()))
