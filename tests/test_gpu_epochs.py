@@ -263,3 +263,29 @@ def test_blane_kernel_beyond_one_round_of_resident_waves(monkeypatch):
     ref, rln = orc.sent(coo, 40, 1024, 3, 17, ld=ld, nthreads=8)
     _eq(one, l1, ref, rln, "blane single epoch")
     _eq(ids[7], ln[7], ref, rln, "blane slice 7 == single-epoch launch", inside_only=True)
+
+
+@pytest.mark.parametrize("wg_waves", ["", "8", "16"])
+def test_lane_kernel_one_nearly_full_round_into_the_padded_int32_slab(wg_waves, monkeypatch):
+    """The launch shape gtok_sent gives two 8-wave workgroups per CU instead of one of 16 - (unit, epoch) pairs filling 75-100 %
+    of the resident wave slots once, int32 rows with padding: 70 k molecules x 3 epochs = 3,282 pairs of 4,096 - under the
+    launcher's own choice and under both pinned workgroup sizes (GTOK_LANE_WG_WAVES): every slice == the oracle, padding
+    included, and the query tail rides along."""
+    if wg_waves:
+        monkeypatch.setenv("GTOK_LANE_WG_WAVES", wg_waves)
+    else:
+        monkeypatch.delenv("GTOK_LANE_WG_WAVES", raising=False)
+    G, K = 70000, 3
+    d = gtok.synth.zinc_like(G, seed=4321)
+    batch, coo = both(d, True)
+    dev = batch.to(DEV)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    rng = np.random.default_rng(5)
+    nc = np.maximum(np.asarray(d["node_counts"]), 1)
+    query = np.stack([rng.integers(0, nc), rng.integers(0, nc)], 1).astype(np.int32)
+    assert gtok.ops.sent_kernel_name(dev, 37, 1024, epochs=K, **kw).startswith("sent_lane_kernel")
+    for q in (None, query):
+        ids, ln = gtok.ops.sent(dev, 37, 1024, 17, 9, epochs=K, query=None if q is None else torch.from_numpy(q), **kw)
+        for e in range(K):
+            ref, rln = orc.sent(coo, 37, 1024, 17, 9 + e, ld=ids.shape[-1], nthreads=min(32, orc.num_threads()), query=q, **kw)
+            _eq(ids.view(K, G, -1)[e], ln.view(K, G)[e], ref, rln, f"wg_waves={wg_waves or 'auto'} epoch {e} query={q is not None}")
