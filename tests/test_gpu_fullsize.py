@@ -211,3 +211,30 @@ def test_large_graphs_eight_epochs_per_launch():
         assert np.array_equal(ln[e].cpu().numpy(), rln) and np.array_equal(ids[e].cpu().numpy().view(np.uint16), ref), e
         st = orc.sent_roundtrip(coo, ref, rln, 256, 600, 3, 5 + e, nthreads=THREADS)
         assert not st.any()
+
+
+def test_config5_share_at_the_epochs_per_launch_the_dataset_classes_use():
+    """A 125,000-graph share of BASELINE config 5 (10..256 nodes, max_len 600) the way the dataset classes tokenize it:
+    epochs_for(125000, 608) = 14 epochs in one gtok_sent launch (the 2 GiB slab bound), 16-bit rows without padding, 1.75 M walks
+    through sent_blane_kernel with every pair beyond the first round drawn from the ticket counters - first, a middle and the last
+    slice bit-exact against the oracle inside the row lengths, lengths of every slice equal, rows cut at max_len decode to a part
+    of their graph."""
+    G, ld = 125000, 608
+    tok = gtok.Graph2TrailTokenizer(dataset_names=[], max_length=600, labeled_graph=False)
+    K = tok.epochs_for(G, ld)
+    assert K == 14
+    d = gtok.synth.er_batch_device(G, torch.device(DEV), seed=1000)
+    batch, coo = both(d, False)
+    dev = batch.to(DEV)
+    ids, ln = gtok.ops.sent(dev, 256, 600, 5, 20, ld=ld, epochs=K, u16=True, pad=False)
+    assert gtok.ops.sent_kernel_name(dev, 256, 600, epochs=K) == "sent_blane_kernel<W=4>" and tuple(ids.shape) == (K, G, ld)
+    for e in (0, 6, K - 1):
+        ref, rln = orc.sent(coo, 256, 600, 5, 20 + e, ld=ld, nthreads=THREADS)
+        assert np.array_equal(ln[e].cpu().numpy(), rln), e
+        got = ids[e].cpu().numpy().view(np.uint16)
+        inside = np.arange(ld)[None, :] < rln[:, None]
+        assert np.array_equal(np.where(inside, got, 0), np.where(inside, ref, 0)), e
+        if e == K - 1:
+            st = orc.sent_roundtrip(coo, ref, rln, 256, 600, 5, 20 + e, nthreads=THREADS)
+            assert not st.any()
+    assert int(ln.min()) >= 2 and int(ln.max()) <= 600
