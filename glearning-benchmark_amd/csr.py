@@ -390,6 +390,8 @@ def collated_storage(dataset):
         data = dataset.__dict__.get("_data", None) if hasattr(dataset, "__dict__") else None
         if data is None:
             data = getattr(dataset, "_data", None)
+        if data is None:                          # torch_geometric < 2.3 keeps the collated Data under `data` alone
+            data = dataset.__dict__.get("data", None) if hasattr(dataset, "__dict__") else None
         if data is None or slices is None or getattr(dataset, "transform", None) is not None:
             return None
         get = (lambda k: data.get(k)) if isinstance(data, dict) else (lambda k: getattr(data, k, None))

@@ -135,3 +135,150 @@ def zinc_data_list(d):
 
 def unpad(ids2d, lens):
     return [ids2d[i, :l].tolist() for i, l in enumerate(lens)]
+
+
+# ---- torch_geometric is not installed here.  What follows restates, from its documented behaviour, the
+# ATTRIBUTE SEMANTICS of torch_geometric.data.Data / BaseStorage and the storage layout of InMemoryDataset that this
+# package's ingestion and item marking depend on - attribute access routed through a storage mapping, names with a leading
+# underscore kept out of the mapping (and out of keys()), missing attributes raising AttributeError, num_nodes inferred, copies
+# made per fetch - so that the host tests meet objects that behave like the real ones rather than a plain attribute bag.
+class PygStorageLike:
+    def __init__(self, _parent=None, **kw):
+        self.__dict__["_mapping"] = {}
+        if _parent is not None:
+            self._parent = _parent
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def __setattr__(self, key, value):
+        if key == "_parent":
+            import weakref
+            self.__dict__[key] = weakref.ref(value)
+        elif key[:1] == "_":
+            self.__dict__[key] = value
+        elif value is None:
+            self._mapping.pop(key, None)
+        else:
+            self._mapping[key] = value
+
+    def __getattr__(self, key):
+        if key == "_mapping":
+            self.__dict__["_mapping"] = {}
+            return self.__dict__["_mapping"]
+        try:
+            return self._mapping[key]
+        except KeyError:
+            raise AttributeError(f"'{type(self).__name__}' object has no attribute '{key}'") from None
+
+    def __getitem__(self, key):
+        return self._mapping[key]
+
+    def keys(self):
+        return list(self._mapping.keys())
+
+    def __copy__(self):
+        out = type(self).__new__(type(self))
+        for k, v in self.__dict__.items():
+            out.__dict__[k] = v
+        out.__dict__["_mapping"] = dict(self._mapping)
+        return out
+
+
+class PygDataLike:
+    def __init__(self, x=None, edge_index=None, edge_attr=None, y=None, **kw):
+        self.__dict__["_store"] = PygStorageLike(_parent=self)
+        for k, v in dict(x=x, edge_index=edge_index, edge_attr=edge_attr, y=y, **kw).items():
+            if v is not None:
+                setattr(self, k, v)
+
+    def __getattr__(self, key):
+        if "_store" not in self.__dict__:
+            raise RuntimeError("the 'data' object was created by an older version")
+        return getattr(self._store, key)
+
+    def __setattr__(self, key, value):
+        prop = getattr(type(self), key, None)
+        if prop is not None and getattr(prop, "fset", None) is not None:
+            prop.fset(self, value)
+        else:
+            setattr(self._store, key, value)
+
+    def __getitem__(self, key):
+        return self._store[key]
+
+    def keys(self):
+        return self._store.keys()
+
+    @property
+    def num_nodes(self):
+        m = self._store._mapping
+        if "num_nodes" in m:
+            return m["num_nodes"]
+        if "x" in m:
+            return int(m["x"].shape[0])
+        return int(m["edge_index"].max()) + 1 if m["edge_index"].numel() else 0
+
+    @num_nodes.setter
+    def num_nodes(self, v):
+        self._store._mapping["num_nodes"] = v
+
+    def __copy__(self):
+        import copy
+        out = type(self).__new__(type(self))
+        for k, v in self.__dict__.items():
+            out.__dict__[k] = v
+        out.__dict__["_store"] = copy.copy(self._store)
+        out._store._parent = out
+        return out
+
+    def clone(self):
+        import copy
+        out = copy.copy(self)
+        for k, v in list(out._store._mapping.items()):
+            out._store._mapping[k] = v.clone() if hasattr(v, "clone") else copy.deepcopy(v)
+        return out
+
+
+class PygInMemoryLike:
+    """InMemoryDataset as torch_geometric >= 2.3 lays it out: `_data` (one Data with every attribute concatenated, edge_index
+    with LOCAL node ids), `slices`, `_indices`, `transform`; items separated on demand and copied per fetch; an index list or a
+    slice returns a shallow copy of the dataset with `_indices` set (index_select).  legacy=True: only `data` exists (< 2.3)."""
+
+    def __init__(self, d, legacy=False, transform=None):
+        import torch
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+        data = PygDataLike(x=t(d["x"], torch.long).view(-1, 1), edge_index=torch.stack([t(d["src"], torch.long), t(d["dst"], torch.long)]),
+                           edge_attr=t(d["edge_attr"], torch.long), y=t(d["y"], torch.float32))
+        ptr = lambda c: torch.from_numpy(np.concatenate([[0], np.cumsum(np.asarray(c))]).astype(np.int64))
+        nptr, eptr = ptr(d["node_counts"]), ptr(d["edge_counts"])
+        if legacy:
+            self.data = data
+        else:
+            self._data = data
+        self.slices = {"x": nptr, "edge_index": eptr, "edge_attr": eptr, "y": torch.arange(len(d["node_counts"]) + 1)}
+        self._indices, self.transform = None, transform
+
+    def _storage(self):
+        return self.__dict__.get("_data", None) or self.__dict__["data"]
+
+    def indices(self):
+        return range(int(self.slices["x"].numel()) - 1) if self._indices is None else self._indices
+
+    def __len__(self):
+        return len(self.indices())
+
+    def get(self, g):
+        import copy
+        dt, s = self._storage(), self.slices
+        n0, n1, e0, e1 = int(s["x"][g]), int(s["x"][g + 1]), int(s["edge_index"][g]), int(s["edge_index"][g + 1])
+        return copy.copy(PygDataLike(x=dt.x[n0:n1], edge_index=dt.edge_index[:, e0:e1], edge_attr=dt.edge_attr[e0:e1], y=dt.y[g:g + 1]))
+
+    def __getitem__(self, idx):
+        import copy
+        if isinstance(idx, (int, np.integer)):
+            item = self.get(self.indices()[idx])
+            return item if self.transform is None else self.transform(item)
+        out = copy.copy(self)
+        base = list(self.indices())
+        out._indices = base[idx] if isinstance(idx, slice) else [base[int(i)] for i in idx]
+        return out

@@ -4,6 +4,7 @@ the split they come from; the graph-token dataset's cache never shadows the refe
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from _util import gtok, zinc_data_list
@@ -112,3 +113,40 @@ def test_graph_token_cache_does_not_shadow_the_reference_file(tmp_path):
     assert gtok.rows.item_source(again[3]) == (again, 3)
     _same(again.graph_batch(), gtok.GraphBatch.from_data_list([again[i] for i in range(len(again))], labeled=False))
     assert again.queries().shape == (len(again), 2)
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_ingestion_and_item_marks_on_objects_with_torch_geometric_semantics(legacy):
+    """The reference hands over torch_geometric.datasets.ZINC (zinc_dataset_autograph.py:44, zinc_dataset_indexbase.py:79);
+    torch_geometric is not installed here, so the layout and attribute semantics this package relies on are restated in
+    tests/_util.py (PygDataLike / PygInMemoryLike: attribute access through a storage mapping, underscore names kept out of
+    keys(), AttributeError for missing names, num_nodes inferred from x, a copy per fetch, index_select through `_indices`,
+    `_data` or - before 2.3 - only `data`).  On such objects: the collated storage is ingested without touching an item,
+    subsets follow `_indices`, item marks survive copy / clone and stay out of the item's keys, foreign items are strangers."""
+    import copy
+    from _util import PygDataLike, PygInMemoryLike
+    d = gtok.synth.zinc_like(300, seed=9)
+    ref = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+    pyg = PygInMemoryLike(d, legacy=legacy)
+    got = gtok.csr.collated_storage(pyg)
+    assert got is not None and got["indices"] is None and got["x"] is not None
+    _same(gtok.GraphBatch.from_dataset(pyg, labeled=True), ref)
+    sub = pyg[[5, 3, 250, 7]]                                    # index_select: a shallow copy with _indices
+    picked = [pyg[i] for i in (5, 3, 250, 7)]
+    _same(gtok.GraphBatch.from_dataset(sub, labeled=True), gtok.GraphBatch.from_data_list(picked, labeled=True))
+    assert gtok.csr.collated_storage(PygInMemoryLike(d, legacy=legacy, transform=lambda it: it)) is None     # a transform: item by item
+    gdl = gtok.graph_data_loader
+    ds = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=pyg)
+    _same(ds.graph_batch(), ref)
+    it = ds[11]
+    assert isinstance(it, PygDataLike) and gtok.rows.item_source(it) == (ds, 11)
+    assert sorted(it.keys()) == ["edge_attr", "edge_index", "x", "y"] and it.edge_attr.dim() == 1 and it.num_nodes == int(d["node_counts"][11])
+    assert gtok.rows.item_source(copy.copy(it)) == (ds, 11) and gtok.rows.item_source(it.clone()) == (ds, 11)
+    assert gtok.rows.item_source(pyg[11]) is None                # fetched from the torch_geometric dataset itself: no mark
+    with pytest.raises(AttributeError):
+        it.no_such_attribute
+    ib = gdl.ZINCTokenizationDataset(split="train", zinc_dataset=pyg)
+    _same(ib.graph_batch(), ref)
+    assert ib.labels().dtype == torch.float32 and torch.equal(ib.labels(), torch.from_numpy(d["y"]))
+    item = ib._item(4)                                           # the per-item Python of the IBTT dataset on such an object
+    assert item["text"].startswith("<bos> <atom> ") and item["text"].endswith(" <eos>") and item["graph_id"] == "zinc_train_4"
