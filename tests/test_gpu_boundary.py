@@ -363,3 +363,39 @@ def test_token_dataset_batches_through_getitems_equal_per_item_collate():
         dl = DataLoader(td, batch_size=50, shuffle=False, num_workers=workers, collate_fn=lambda b: gdl.collate(b, pad))
         for (X, A, Y), (rX, rA, rY) in zip(dl, per_item):
             assert torch.equal(X, rX) and torch.equal(A, rA) and torch.equal(Y, rY)
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_agtt_flow_over_a_dataset_with_torch_geometric_semantics(legacy):
+    """The whole AGTT boundary on objects that behave like torch_geometric's (tests/_util.py: PygDataLike / PygInMemoryLike -
+    attribute access through a storage mapping, a copy per fetch, `_data` or, before 2.3, `data`): the reference's per-item
+    loop and the stock DataLoader over agtt.TokenizedGraphDataset give the oracle's rows with one launch per K epochs, items
+    the torch_geometric dataset hands out itself are tokenized on their own."""
+    from torch.utils.data import DataLoader
+    from _util import PygInMemoryLike
+    G = 3000
+    d = gtok.synth.zinc_like(G, seed=41)
+    batch, coo = both(d)
+    pyg = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=PygInMemoryLike(d, legacy=legacy))
+    tok = _zinc_tokenizer(37)
+    got = [_reference_getitem(pyg, tok, i, remap=True) for i in range(G)]
+    assert tok.launches == 1
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    ref, rln = orc.sent(coo, 37, 1024, 5, 0, ld=gtok.ops.sent_safe_ld(batch, True, 1024), nthreads=8, **kw)
+    for i, (tokens, mask, label, data) in enumerate(got):
+        assert np.array_equal(tokens.numpy(), ref[i, :rln[i]]) and label == pytest.approx(float(d["y"][i])) and data.num_nodes == int(d["node_counts"][i])
+    loose = pyg.zinc_dataset[5]                                    # not handed out by this package's class: a launch of its own
+    before = tok.launches
+    one = tok(loose)
+    assert tok.launches == before + 1 and one[0] == 0 and one[-1] == 4
+    ds = gtok.agtt.TokenizedGraphDataset(pyg, _zinc_tokenizer(37), task="zinc", remap_to_fixed_vocab=True)
+    seen = 0
+    for X, A, Y, data_list in DataLoader(ds, batch_size=128, shuffle=False, num_workers=0, collate_fn=gtok.agtt.collate_fn):
+        B = X.shape[0]
+        for b in (0, B - 1):
+            i = seen + b
+            n = int(A[b].sum())
+            assert n == rln[i] and np.array_equal(X[b, :n].cpu().numpy(), ref[i, :n]) and float(Y[b]) == pytest.approx(float(d["y"][i]))
+            assert data_list[b].num_nodes == int(d["node_counts"][i])
+        seen += B
+    assert seen == G and ds.tokenizer.launches == 1
