@@ -399,3 +399,19 @@ def test_agtt_flow_over_a_dataset_with_torch_geometric_semantics(legacy):
             assert data_list[b].num_nodes == int(d["node_counts"][i])
         seen += B
     assert seen == G and ds.tokenizer.launches == 1
+
+
+def test_ibtt_strings_over_a_dataset_with_torch_geometric_semantics():
+    """ZINCTokenizationDataset over the same kind of objects: the strings rendered for the whole split on the device (serialiser +
+    gtok_zinc_text_tails + gtok_ids_to_text) equal the restated per-item Python on every item, at a max_len that cuts some texts."""
+    from _util import PygInMemoryLike
+    d = gtok.synth.zinc_like(800, seed=43)
+    for max_len in (2048, 60):
+        ds = gdl.ZINCTokenizationDataset(split="val", zinc_dataset=PygInMemoryLike(d), max_len=max_len)
+        items = [ds[i] for i in range(len(ds))]
+        assert ds._texts is not None, "rendered in bulk on the first fetch"
+        for i in range(0, len(ds), 7):
+            want = ds._item(i)
+            assert items[i]["text"] == want["text"] and items[i]["label"] == pytest.approx(want["label"]) and items[i]["graph_id"] == want["graph_id"]
+        if max_len == 60:
+            assert any(len(it["text"].split()) == 60 for it in items)
