@@ -385,6 +385,15 @@ def collated_storage(dataset):
     fn = getattr(dataset, "collated", None)
     if callable(fn):
         return fn()
+    if isinstance(dataset, torch.utils.data.Subset):     # a subset of a collated dataset: its storage, the indices composed
+        inner = collated_storage(dataset.dataset)
+        if inner is None:
+            return None
+        base = inner["indices"]
+        pick = [int(i) for i in dataset.indices]
+        inner = dict(inner)
+        inner["indices"] = pick if base is None else [base[i] for i in pick]
+        return inner
     try:
         slices = getattr(dataset, "slices", None)
         data = dataset.__dict__.get("_data", None) if hasattr(dataset, "__dict__") else None

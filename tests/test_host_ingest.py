@@ -135,6 +135,10 @@ def test_ingestion_and_item_marks_on_objects_with_torch_geometric_semantics(lega
     picked = [pyg[i] for i in (5, 3, 250, 7)]
     _same(gtok.GraphBatch.from_dataset(sub, labeled=True), gtok.GraphBatch.from_data_list(picked, labeled=True))
     assert gtok.csr.collated_storage(PygInMemoryLike(d, legacy=legacy, transform=lambda it: it)) is None     # a transform: item by item
+    from torch.utils.data import Subset
+    nested = Subset(Subset(sub, [3, 0, 2]), [1, 2])              # torch's own subsets compose with index_select: graphs 5, 250
+    assert gtok.csr.collated_storage(nested)["indices"] == [5, 250]
+    _same(gtok.GraphBatch.from_dataset(nested, labeled=True), gtok.GraphBatch.from_data_list([pyg[5], pyg[250]], labeled=True))
     gdl = gtok.graph_data_loader
     ds = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=pyg)
     _same(ds.graph_batch(), ref)
