@@ -513,7 +513,8 @@ def main():
 
     # roofline of the dominant kernel (sent_kernel<1,true>): algorithmic bytes / launch duration
     read_b = host.algorithmic_read_bytes(ibtt=False, labeled=zinc)
-    write_b = 4.0 * tokens_per_step_rank + 4.0 * G
+    id_bytes = 2.0 if rows_u16 else 4.0               # (--rows u16 | u16padded, the counter-pass flavours: rows of 16-bit ids)
+    write_b = id_bytes * tokens_per_step_rank + 4.0 * G
     # per LAUNCH: the figure of SURVEY section 8d per graph x the graphs one launch processes (E epochs of the corpus: every
     # (unit, epoch) pair stages its CSR chunk and writes its rows) over the average launch duration
     epl = args.steps / n_launch                       # epochs per launch, averaged over the timed region (= E when E divides K)
@@ -554,13 +555,13 @@ def main():
                     algorithmic_bytes_per_launch=int(read_b + write_b), kernel_ms=round(kern_s * 1e3, 4),
                     kernel_ms_event_pair_per_launch=round(float(np.mean(kern_each_ms)), 4),
                     epochs_per_launch=E, launches=n_launch, kernel_ms_per_epoch=round(kern_s * 1e3 / epl, 5),
-                    padded_slab_bytes_per_launch=int(4 * G * ld * epl))
+                    padded_slab_bytes_per_launch=int(id_bytes * G * ld * epl))
     if trunc is not None:
         roofline["truncation_aware"] = trunc
 
     out = dict(metric="graphs_tokenized_per_sec", value=round(value, 1), unit="graphs/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 5),
-               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u16" if rows_u16 else "int32", data="synthetic",
                tokens_per_sec=round(tokens_per_sec, 1),
                config=dict(workload=f"{args.workload}: {wl['desc']}" + ("" if args.rows == "padded" else f" [--rows {args.rows}]"), graphs_per_gpu=G, max_len=max_len,
                            slab_width=ld, slab_width_mode=args.ld, avg_tokens_per_graph=round(tokens_per_step_rank / G, 2),
