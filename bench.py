@@ -229,26 +229,58 @@ def boundary_section(d, G, dev, max_nodes, max_len):
     return out
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, argv=None, script=None, poll_s=0.2):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves - fresh child processes, started BEFORE
     this process has touched the GPU (nothing above this line initialises HIP), one per GPU, rendezvous on 127.0.0.1 -
-    relay rank 0's JSON line and exit non-zero if any rank failed."""
+    relay rank 0's JSON line and exit non-zero if any rank failed.  All children are polled: as soon as ONE exits non-zero
+    the others are terminated (a rank that died before or inside the rendezvous would otherwise leave its siblings in
+    init_process_group / a collective until the process-group timeout, holding their GPUs) and the run ends with that rank's
+    exit code and the tail of its stderr."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
+    argv = sys.argv[1:] if argv is None else list(argv)
+    script = os.path.abspath(__file__) if script is None else script
+    procs, errs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+        errs.append(tempfile.TemporaryFile())
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        for p in procs:                      # the exact children started above, nothing matched by name
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill(); p.wait()
+    for r, f in enumerate(errs):             # children's stderr: relayed in rank order once they are done
+        f.seek(0)
+        data = f.read().decode(errors="replace")
+        if failed is not None and r == failed[0]:
+            sys.stderr.write(f"[bench] rank {r} exited with code {failed[1]}; the last lines of its stderr:\n" + "\n".join(data.splitlines()[-25:]) + "\n")
+        elif failed is None:
+            sys.stderr.write(data)
+    sys.stderr.flush()
+    if failed is not None:
+        raise SystemExit(f"bench.py: rank {failed[0]} failed with exit code {failed[1]}; the other ranks were terminated")
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
 
 
 def main():
@@ -299,7 +331,9 @@ def main():
     # GTOK_BENCH_FORCE_DIST=1 runs the collective legs even with one rank (rehearsal of the N>1 path on a 1-GPU box)
     multi = world > 1 or os.environ.get("GTOK_BENCH_FORCE_DIST") == "1"
     if multi:
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        # a short rendezvous / collective timeout: a rank that never arrives must fail this run in minutes, not in the default 10
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=int(os.environ.get("GTOK_BENCH_PG_TIMEOUT", "180"))))
 
     wl = WORKLOADS[args.workload]
     G = args.graphs or wl["graphs"]
@@ -500,6 +534,46 @@ def main():
                 else:
                     os.environ[k] = v
         step(args.warmup, scratch_len)      # back on the resident layouts for the legs below
+
+    # the same K steps through the PyTorch custom op (north_star: "exposed as PyTorch-ROCm custom ops"): torch.ops.gtok.sent on
+    # the arrays torch.ops.gtok.csr_prepare hands back (prepared once, like the CSR build), and on the raw tensors alone (the op
+    # prepares behind the call on first use and finds the batch again by tensor identity) - same launches, same output buffers
+    torch_op = None
+    if zinc and E == 1 and not rows_u16 and rows_pad:
+        try:
+            raw = dict(node_ptr=batch.node_ptr, edge_ptr=batch.edge_ptr, rowptr=batch.rowptr, col=batch.col, nattr=batch.nattr, eattr=batch.eattr)
+            t0p = time.perf_counter()
+            P = gtok.torch_ops.prepared_args(**raw, max_nodes=batch.max_nodes, max_edges=batch.max_edges)
+            torch.cuda.synchronize()
+            prep_ms = (time.perf_counter() - t0p) * 1e3
+            t0p = time.perf_counter()
+            P = gtok.torch_ops.prepared_args(**raw, max_nodes=batch.max_nodes, max_edges=batch.max_edges)
+            torch.cuda.synchronize()
+            prep_ms = min(prep_ms, (time.perf_counter() - t0p) * 1e3)
+            opkw = dict(query=None, max_num_nodes=max_nodes, max_len=max_len, ld=ld, seed=0, labeled=True, num_node_types=ntypes,
+                        num_edge_types=etypes, remap_zinc=True, pad_id=5, graph_base=graph_base)
+            res = {}
+            for label, arrays in (("prepared", P), ("raw_tensors", dict(raw, max_nodes=batch.max_nodes, max_edges=batch.max_edges))):
+                f = lambda k: torch.ops.gtok.sent(**arrays, epoch=args.warmup + k, **opkw)
+                for w in range(args.warmup):
+                    f(w)
+                kname_op = gtok.ops.last_sent_kernel()
+                _, om = timed_loop(f, args.steps, multi, per_launch_events=False)
+                res[label] = dict(ms_per_step=round(float(np.mean(om)), 5), kernel=kname_op)
+            o_ids, o_ln = torch.ops.gtok.sent(**P, epoch=args.warmup + args.steps - 1, **opkw)
+            step(args.warmup + args.steps - 1, scratch_len)
+            same = bool(torch.equal(o_ids, ids[:G]) and torch.equal(o_ln, scratch_len[:G]))
+            torch_op = dict(ms_per_step=res["prepared"]["ms_per_step"], kernel=res["prepared"]["kernel"], graphs_per_sec=round(G / res["prepared"]["ms_per_step"] * 1e3, 1),
+                            raw_tensors_ms_per_step=res["raw_tensors"]["ms_per_step"], raw_tensors_kernel=res["raw_tensors"]["kernel"],
+                            csr_prepare_ms=round(prep_ms, 3), equals_ops_sent=same,
+                            note="torch.ops.gtok.sent over K steps, one HIP event pair around them; output allocated by the op each call (torch's "
+                                 "caching allocator); prepared = torch_ops.prepared_args (gtok_csr_lane_sort on the device) once, raw_tensors = "
+                                 "the op prepares behind the first call and finds the batch again by tensor identity")
+            del o_ids, o_ln, P
+        except Exception as ex:      # a secondary leg must never cost the run its headline line
+            import traceback
+            traceback.print_exc()
+            torch_op = {"error": f"{type(ex).__name__}: {ex}"}
 
     all_len = lens_all[:args.steps]
     if int(all_len.max().item()) > ld:
@@ -804,6 +878,8 @@ def main():
             import traceback
             traceback.print_exc()
             out["boundary"] = {"error": f"{type(ex).__name__}: {ex}"}
+    if torch_op is not None:
+        out.setdefault("boundary", {})["torch_op_sent"] = torch_op
 
     # CPU baseline: the oracle (a port, not the reference's Python) on a bounded sample, rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not rows_u16:

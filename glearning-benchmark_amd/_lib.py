@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 # GTOK_LIB: load another build of the same ABI (profiling builds of profiles/tools, e.g. -DGTOK_PHASE_TIMING)
 LIB_PATH = os.environ.get("GTOK_LIB") or os.path.join(_HERE, "csrc", "libgtok.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("gtok_sent.hip", "gtok_ibtt.hip", "gtok_rows.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("gtok_sent.hip", "gtok_ibtt.hip", "gtok_rows.hip", "gtok_csr.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "gtok_common.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_blane.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_reg.hpp"), os.path.join(_HERE, "csrc", "gtok_sent_lds.hpp"),
            os.path.join(_HERE, "csrc", "gtok_sent_lane.hpp"),
            os.path.join(_ROOT, "include", "gtok.h")]
@@ -42,6 +42,12 @@ class GtokCsr(ctypes.Structure):
 CSR_SIMPLE_SYMMETRIC = 1
 SENT_NO_PAD = 1
 SENT_U16 = 2
+
+
+class GtokCsrSorted(ctypes.Structure):
+    """include/gtok.h: gtok_csr_sorted - the output arrays of gtok_csr_lane_sort."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("graph_ids", "node_ptr", "edge_ptr", "rowptr", "col", "nattr", "eattr", "rowptr8", "col8",
+                                               "unit_ptr", "unit_info", "info")]
 
 
 class GtokVocabTable(ctypes.Structure):
@@ -79,6 +85,9 @@ SYMBOLS = {
     "gtok_find_token": (_I, [_P, _I, _I, ctypes.c_int64, _P, _P]),
     "gtok_vocab_stats_synth": (_I, [ctypes.POINTER(GtokCsr), _P, ctypes.c_int64, _I, _P, _P, _P]),
     "gtok_vocab_stats_text": (_I, [_P, _P, _I, ctypes.c_int64, _I, _P, _P, _P, _P, _P, _P]),
+    "gtok_csr_check": (_I, [ctypes.POINTER(GtokCsr), _P, _P]),
+    "gtok_csr_lane_sort_workspace": (ctypes.c_int64, [_I]),
+    "gtok_csr_lane_sort": (_I, [ctypes.POINTER(GtokCsr), _I, _I, ctypes.POINTER(GtokCsrSorted), _P, ctypes.c_int64, _P]),
     "gtok_csr_adjbits": (_I, [ctypes.POINTER(GtokCsr), _I, _P, _P, _P, _P]),
     "gtok_csr_pack8": (_I, [ctypes.POINTER(GtokCsr), ctypes.c_int64, ctypes.c_int64, _P, _P, _P]),
     "gtok_row_offsets": (_I, [_P, ctypes.c_int64, _I, _I, _P, _P]),
@@ -149,22 +158,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 _lib = None
+_lib_version = 0
 
 
-ABI_VERSION = 4     # include/gtok.h: GTOK_ABI_VERSION
+ABI_VERSION = 5     # include/gtok.h: GTOK_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:
     """Load libgtok.so; raise loudly when it has not been built."""
-    global _lib
+    global _lib, _lib_version
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise GtokError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         h = ctypes.CDLL(LIB_PATH)
-        # GTOK_LIB (A/B timing against the build of an earlier git ref, profiles/tools/ab_build.sh): an ABI v3 library reads a
+        # GTOK_LIB (A/B timing against the build of an earlier git ref, profiles/tools/ab_build.sh): an ABI v3 / v4 library reads a
         # prefix of today's structs and lacks the newer entry points - accepted for the calls both have, nothing else
+        # (library_version() gates the inputs an older library would silently ignore: ops.sent)
         older_ok = bool(os.environ.get("GTOK_LIB")) and 3 <= h.gtok_version() < ABI_VERSION
         for name, (res, args) in SYMBOLS.items():
             if older_ok and not hasattr(h, name):
@@ -174,8 +185,14 @@ def lib() -> ctypes.CDLL:
         if h.gtok_version() != ABI_VERSION and not older_ok:      # struct layouts below would not match the library's
             raise GtokError(f"{LIB_PATH} has ABI version {h.gtok_version()}, this binding needs {ABI_VERSION}: rebuild it "
                             "(`python -c 'import __graft_entry__ as g; g.build()'`)")
-        _lib = h
+        _lib, _lib_version = h, int(h.gtok_version())
     return _lib
+
+
+def library_version() -> int:
+    """gtok_version() of the loaded library (== ABI_VERSION unless GTOK_LIB points at an older build)."""
+    lib()
+    return _lib_version
 
 
 def check(code: int, what: str) -> None:

@@ -73,6 +73,8 @@ class GraphBatch:
     unit_info: Optional[torch.Tensor] = None     # int32 [units, 8]: per-unit descriptor (include/gtok.h: gtok_csr.unit_info)
     lane_sorted: Optional["GraphBatch"] = None   # the reordered copy of THIS batch (device batches, made on first use)
     adj_unusable: bool = False                   # gtok_csr_adjbits found a closure degree above 255: do not try again
+    checked: bool = False                        # flags were established on the device (gtok_csr_check; torch_ops: raw-tensor calls)
+    prepared: bool = False                       # the caller built the layouts itself (torch.ops.gtok.csr_prepare): ops.sent prepares nothing
 
     @property
     def device(self) -> torch.device:
@@ -94,13 +96,25 @@ class GraphBatch:
                           mv(self.adj_rows), mv(self.adj_planes), mv(self.lane_order), self.adj_words, self.adj_max_degree,
                           0, mv(self.graph_ids), mv(self.unit_ptr), self.num_units, mv(self.unit_info))
 
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name != "_cs":
+            object.__setattr__(self, "_cs", None)     # any change of a field drops the cached C struct
+
     def c_struct(self) -> GtokCsr:
+        """The batch as the C ABI's gtok_csr (include/gtok.h).  Built once and kept until a field is assigned: a launch
+        through ops.* costs tens of microseconds of Python, and 27 data_ptr() calls were a fifth of that."""
+        cs = self.__dict__.get("_cs")
+        if cs is not None:
+            return cs
         p = lambda t: None if t is None else t.data_ptr()
-        return GtokCsr(self.num_graphs, self.max_nodes, self.max_edges, self.flags, p(self.node_ptr), p(self.edge_ptr),
-                       p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr),
-                       self.chunk_nodes, self.chunk_edges, self.max_degree, 0, p(self.rowptr8), p(self.col8),
-                       p(self.adj_rows), p(self.adj_planes), p(self.lane_order), self.adj_words, self.adj_max_degree,
-                       p(self.graph_ids), p(self.unit_ptr), self.num_units, 0, p(self.unit_info))
+        cs = GtokCsr(self.num_graphs, self.max_nodes, self.max_edges, self.flags, p(self.node_ptr), p(self.edge_ptr),
+                     p(self.rowptr), p(self.col), p(self.eorder), p(self.nattr), p(self.eattr),
+                     self.chunk_nodes, self.chunk_edges, self.max_degree, 0, p(self.rowptr8), p(self.col8),
+                     p(self.adj_rows), p(self.adj_planes), p(self.lane_order), self.adj_words, self.adj_max_degree,
+                     p(self.graph_ids), p(self.unit_ptr), self.num_units, 0, p(self.unit_info))
+        object.__setattr__(self, "_cs", cs)
+        return cs
 
     def node_counts(self) -> torch.Tensor:
         return self.node_ptr[1:] - self.node_ptr[:-1]
@@ -241,21 +255,22 @@ class GraphBatch:
         if eattr is not None:
             eattr = take(eattr)
         max_nodes = int(nc.max()) if G else 0
-        flags = 0
-        if check_symmetric and E and not bool((s == d).any()):
-            m = max_nodes + 1
-            fwd = torch.sort((gid_e * m + s) * m + d).values
-            if not bool((fwd[1:] == fwd[:-1]).any()):
-                rev = torch.sort((gid_e * m + d) * m + s).values
-                flags = CSR_SIMPLE_SYMMETRIC if bool(torch.equal(fwd, rev)) else 0
 
         def chunk_max(c):
             if c.numel() == 0:
                 return 0
             pad = (-c.numel()) % 64
             return int(torch.nn.functional.pad(c, (0, pad)).reshape(-1, 64).sum(1).max())
-        return GraphBatch(G, max_nodes, int(ec.max()) if G else 0, node_ptr.to(torch.int32), edge_ptr, rowptr, col, eorder,
-                          nattr, eattr, flags, chunk_max(nc), chunk_max(ec), int(cnt.max()) if N else 0)
+        out = GraphBatch(G, max_nodes, int(ec.max()) if G else 0, node_ptr.to(torch.int32), edge_ptr, rowptr, col, eorder,
+                         nattr, eattr, 0, chunk_max(nc), chunk_max(ec), int(cnt.max()) if N else 0)
+        if check_symmetric and E and dev.type == "cuda":
+            # simple + stored in both directions: verified by gtok_csr_check on the arrays just built (round 4 sorted the
+            # entry list twice with torch for this: 2 x 12 M int64 keys for ZINC-full)
+            from . import ops
+            if ops.csr_check(out)["violations"] == 0:
+                out.flags |= CSR_SIMPLE_SYMMETRIC
+            out.checked = True
+        return out
 
     @staticmethod
     def from_collated(node_counts, edge_index, edge_slices, x=None, edge_attr=None, indices=None, device=None,

@@ -253,6 +253,57 @@ struct DeviceScope {
   ~DeviceScope() { if (prev >= 0 && dev >= 0 && dev != prev) (void)hipSetDevice(prev); }
   bool ok() const { return dev >= 0; }
 };
+// ---- launch-time queries, answered once.  A lane-kernel launch asked the runtime five questions (device, CU count, two
+// occupancy calculations, the dynamic-LDS opt-in) - a few microseconds each, every epoch, for answers that never change; the
+// torch custom-op route, which spends ~30 us in the dispatcher before it gets here, was host-bound behind them.
+inline int device_cu_count(int dev) {
+  static std::atomic<int> memo[kMaxDev];
+  if (dev < 0 || dev >= kMaxDev) return 256;
+  int n = memo[dev].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  n = 256;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+  memo[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
+struct LaunchMemo {
+  struct Entry { const void *kern; int dev, block; size_t lds; int occ; };
+  std::mutex mu;
+  Entry e[64];
+  int n = 0;
+  const void *raised[64];        // kernels whose dynamic-LDS limit was raised to 160 KB (per device: the attribute is per code object)
+  int raised_dev[64];
+  int nr = 0;
+};
+inline LaunchMemo &launch_memo() { static LaunchMemo m; return m; }
+// hipOccupancyMaxActiveBlocksPerMultiprocessor, remembered per (kernel, device, block size, LDS bytes); 0 = the query failed
+inline int occupancy_of(const void *kern, int dev, int block, size_t lds) {
+  LaunchMemo &m = launch_memo();
+  {
+    std::lock_guard<std::mutex> lock(m.mu);
+    for (int i = 0; i < m.n; ++i)
+      if (m.e[i].kern == kern && m.e[i].dev == dev && m.e[i].block == block && m.e[i].lds == lds) return m.e[i].occ;
+  }
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, block, lds) != hipSuccess || occ < 0) { (void)hipGetLastError(); occ = 0; }
+  std::lock_guard<std::mutex> lock(m.mu);
+  if (m.n < 64) m.e[m.n++] = LaunchMemo::Entry{kern, dev, block, lds, occ};
+  return occ;
+}
+// the opt-in to more than 64 KB of dynamic LDS, once per kernel and device
+inline bool raise_lds_limit(const void *kern, int dev) {
+  LaunchMemo &m = launch_memo();
+  {
+    std::lock_guard<std::mutex> lock(m.mu);
+    for (int i = 0; i < m.nr; ++i)
+      if (m.raised[i] == kern && m.raised_dev[i] == dev) return true;
+  }
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
+  std::lock_guard<std::mutex> lock(m.mu);
+  if (m.nr < 64) { m.raised[m.nr] = kern; m.raised_dev[m.nr] = dev; ++m.nr; }
+  return true;
+}
+
 __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
@@ -278,6 +329,48 @@ __device__ __forceinline__ int virtual_block() {
   const int nb = (int)gridDim.x, b = (int)blockIdx.x;
   const int per = nb >> 3, rem = nb & 7, x = b & 7, j = b >> 3;
   return x * per + (x < rem ? x : rem) + j;
+}
+
+// ---- single-pass prefix sums over tiles (decoupled look-back, Merrill & Garland 2016) ----------------------------
+// One int64 status word per tile, written and read with 8-byte agent-scope atomics - the word IS the payload, so no
+// fence pairs with it (MI355X_MICROARCH.md, inter-workgroup visibility: 8-byte agent atomics on both sides):
+//   kTileEmpty (-1)   nothing published yet
+//   <= -2             the tile's own sum only: -(sum) - 2
+//   >= 0              the inclusive prefix up to and including the tile (final)
+// Tiles are numbered by a ticket drawn when the workgroup starts, so every lower tile is running or done (HIP promises
+// no dispatch order).  The words must hold kTileEmpty before the launch (a memset of 0xFF).
+constexpr int64_t kTileEmpty = -1;
+__device__ __forceinline__ int64_t wave_sum64(int64_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// Called by ONE whole wave of the tile's workgroup with the tile's sum (sum >= 0); returns the exclusive prefix of the
+// tile in every lane and leaves the inclusive prefix in the tile's word.
+__device__ __forceinline__ int64_t lookback_exclusive(int64_t *__restrict__ state, int tile, int64_t sum) {
+  const int lane = lane_id();
+  if (tile == 0) {
+    if (lane == 0) __hip_atomic_store(state, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  if (lane == 0) __hip_atomic_store(state + tile, -sum - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int64_t excl = 0;
+  int t = tile - 1;                                   // lane l looks at tile t - l
+  for (;;) {
+    const int idx = t - lane;
+    int64_t v = 0;                                    // below tile 0: a prefix of zero
+    if (idx >= 0) v = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t empty = __ballot(v == kTileEmpty), full = __ballot(v >= 0);   // (lanes below tile 0 read as full)
+    const int p = full ? __builtin_ctzll(full) : 63;  // the nearest tile with a finished prefix (lanes beyond tile 0 always are)
+    const uint64_t upto = p >= 63 ? ~0ull : ((2ull << p) - 1ull);
+    if (empty & upto) { __builtin_amdgcn_s_sleep(2); continue; }      // a tile in between has published nothing yet
+    const int64_t mine = lane > p ? 0 : (v >= 0 ? v : -v - 2);
+    excl += wave_sum64(mine);
+    if (full) break;
+    t -= kWave;
+  }
+  if (lane == 0) __hip_atomic_store(state + tile, excl + sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
 }
 
 // Philox4x32-10 (Salmon et al. 2011), the counter-based generator of the SENT spec.

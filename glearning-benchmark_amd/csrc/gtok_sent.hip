@@ -172,13 +172,11 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     KF kern = !p->labeled ? GTOK_LANE_K(false, false) : p->remap_zinc ? GTOK_LANE_K(true, true) : GTOK_LANE_K(true, false);
 #undef GTOK_LANE_K
 #undef GTOK_LANE_K2
-    int dev = 0, ncu = 256, occ = 1;
-    if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), 64,
-                                                     (size_t)a.lds) != hipSuccess || occ < 1)
-      occ = 1;
+    const int dev = device_scope.dev, ncu = device_cu_count(dev);
+    int occ = -1;                                 // occupancy of one-wave workgroups: only the fallback launch below asks
     if (const char *cs = std::getenv("GTOK_LANE_BLOCKS_PER_CU")) {   // tuning knob
+      occ = occupancy_of(reinterpret_cast<const void *>(kern), dev, 64, (size_t)a.lds);
+      if (occ < 1) occ = 1;
       const int c = std::atoi(cs);
       if (c >= 1 && c < occ) occ = c;
     }
@@ -192,7 +190,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     // need several epochs to fill the chip; epoch-major (epoch 0 of every unit, then epoch 1, ...) when one epoch fills half of
     // the resident waves or more - the first round is then the tuned one-epoch deal (249,456 molecules x 2 epochs, int32 padded:
     // 0.076 ms per epoch against 0.089; x 4 as 16-bit rows: 0.0573 against 0.0589; 12 k x 24: 0.0043 against 0.0039 the other way)
-    a.epoch_major = K > 1 && a.units >= 8 * ncu_hint();
+    a.epoch_major = K > 1 && a.units >= 8 * ncu;
     if (const char *cs = std::getenv("GTOK_LANE_PAIR_ORDER")) a.epoch_major = cs[0] == 'e';   // tuning knob: unit | epoch
     a.unit_mul = 0;
     a.prio_cut[0] = 16; a.prio_cut[1] = 32; a.prio_cut[2] = 48;   // quartiles (profiles/tools/lane_prio_sweep.sh)
@@ -204,7 +202,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     // and the words through which they share the padding of their last units)
     if (g->unit_ptr && a.lds * 16 + kLaneWgShared <= 160 * 1024 && vunits >= 4 * ncu && !(wg && wg[0] == '0')) {
       // (the opt-in to more than 64 KB of dynamic LDS is per kernel and per device: a host-side call of a microsecond)
-      const bool r = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      const bool r = raise_lds_limit(reinterpret_cast<const void *>(kern), dev);
       int occ16 = 0;
       // One 16-wave workgroup per CU, except where ONE nearly full round of units ends in the int32 slab's padding (ZINC-full x 1
       // epoch, a 31 k shard x 8): there two 8-wave workgroups per CU let one half of a CU pad while the other still walks
@@ -217,7 +215,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
                          : (one_full_round && !u16 && !(p->flags & GTOK_SENT_NO_PAD) ? 8 : 16);
       const int per_cu = wgw == 8 ? 2 : 1;
       const size_t wg_lds = (size_t)a.lds * wgw + kLaneWgShared;
-      if (r && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void *>(kern), 64 * wgw, wg_lds) == hipSuccess && occ16 >= per_cu) {
+      if (r && (occ16 = occupancy_of(reinterpret_cast<const void *>(kern), dev, 64 * wgw, wg_lds)) >= per_cu) {
         hipLaunchKernelGGL(kern, dim3(ncu * per_cu), dim3(64 * wgw), wg_lds, (hipStream_t)stream, a);
         return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
       }
@@ -228,6 +226,10 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
       int m = (int)(vunits * 0.6180339887498949);
       while (gcd(m, vunits) != 1) ++m;
       a.unit_mul = m;
+    }
+    if (occ < 0) {
+      occ = occupancy_of(reinterpret_cast<const void *>(kern), dev, 64, (size_t)a.lds);
+      if (occ < 1) occ = 1;
     }
     int nb = ncu * occ;
     if (nb > vunits) nb = vunits;

@@ -139,67 +139,65 @@ def pack8(batch: GraphBatch) -> bool:
 LANE_UNIT_LDS = 10224      # LDS bytes a unit of the reordered batch may need: 16 waves per CU stay resident (160 KB / 16, less the 16 bytes of the workgroup's ticket counter)
 
 
-def lane_sorted(batch: GraphBatch) -> Optional[GraphBatch]:
+def csr_check(batch: GraphBatch) -> Dict[str, int]:
+    """gtok_csr_check: verify on the device what GTOK_CSR_SIMPLE_SYMMETRIC claims and measure the batch maxima.  Returns
+    dict(violations, max_degree, max_nodes, max_edges); one 32-byte read-back.  violations == 0 (and at least one entry)
+    is what GraphBatch.flags |= CSR_SIMPLE_SYMMETRIC needs."""
+    _need_gpu(batch.rowptr, "csr_check")
+    dev = batch.device
+    info = torch.empty(8, dtype=torch.int32, device=dev)
+    cs = batch.c_struct()
+    check(lib().gtok_csr_check(ctypes.byref(cs), info.data_ptr(), _stream(dev)), "gtok_csr_check")
+    v = info.tolist()
+    return dict(violations=v[0], max_degree=v[1], max_nodes=v[2], max_edges=v[3])
+
+
+def lane_sorted(batch: GraphBatch, verify: bool = False) -> Optional[GraphBatch]:
     """The copy of a device batch of small symmetric graphs that sent_lane_kernel walks fastest (made once per batch,
     kept on the batch object): graphs stored by descending expected walk length - nodes + leaves, a walk restarts once
     per dead end - and dealt to waves in units of <= 64 neighbours whose staged bytes fit LANE_UNIT_LDS, so that the 64
     walks of a wave end together (in dataset order a unit of ZINC runs 41 steps for walks of 28 on average).
     `graph_ids` carries every slot's dataset index: output rows, lengths, query entries and RNG identity follow it, the
-    tokens are those of the batch in dataset order.  A layout step like the CSR build, never part of an epoch."""
+    tokens are those of the batch in dataset order.  A layout step like the CSR build, never part of an epoch.
+    Built on the device by gtok_csr_lane_sort (counting sort, single-pass scans, the byte mirror in the same pass): a dozen
+    small launches and ONE 32-byte read-back (the unit count and the LDS sizes of the launch).  verify=True: the batch's
+    flags are not trusted - the same call checks GTOK_CSR_SIMPLE_SYMMETRIC on the device and sets it on `batch`
+    (None is returned when the batch turns out not to be simple and symmetric)."""
     if batch.lane_sorted is not None:
         return batch.lane_sorted
     if batch.col.device.type != "cuda" or batch.num_graphs == 0 or batch.max_nodes > 64 or batch.max_edges > 255 \
-            or not (batch.flags & _lib.CSR_SIMPLE_SYMMETRIC) or batch.graph_ids is not None:
+            or batch.graph_ids is not None or batch.num_edges_total == 0:
+        return None
+    if not verify and not (batch.flags & _lib.CSR_SIMPLE_SYMMETRIC):
         return None
     dev, G = batch.device, batch.num_graphs
-    node_ptr, edge_ptr = batch.node_ptr.to(torch.int64), batch.edge_ptr.to(torch.int64)
-    nc, ec = node_ptr[1:] - node_ptr[:-1], edge_ptr[1:] - edge_ptr[:-1]
-    N, E = int(node_ptr[-1]), int(edge_ptr[-1])
-    ar = lambda n: torch.arange(n, device=dev, dtype=torch.int64)
-    rp_start = node_ptr[:-1] + ar(G)                                  # graph g's n + 1 row pointers start here
-    gid_n = torch.repeat_interleave(ar(G), nc, output_size=N)
-    rp_idx = rp_start[gid_n] + (ar(N) - node_ptr[gid_n])
-    deg = batch.rowptr[rp_idx + 1] - batch.rowptr[rp_idx]
-    leaves = torch.zeros(G, dtype=torch.int64, device=dev).index_add_(0, gid_n, (deg == 1).to(torch.int64))
-    perm = torch.argsort(nc + leaves, descending=True, stable=True)
-    nc2, ec2 = nc[perm], ec[perm]
-    node_ptr2 = torch.zeros(G + 1, dtype=torch.int64, device=dev); torch.cumsum(nc2, 0, out=node_ptr2[1:])
-    edge_ptr2 = torch.zeros(G + 1, dtype=torch.int64, device=dev); torch.cumsum(ec2, 0, out=edge_ptr2[1:])
-    src_n = torch.repeat_interleave(node_ptr[:-1][perm] - node_ptr2[:-1], nc2, output_size=N) + ar(N)
-    src_r = torch.repeat_interleave(rp_start[perm] - (node_ptr2[:-1] + ar(G)), nc2 + 1, output_size=N + G) + ar(N + G)
-    src_e = torch.repeat_interleave(edge_ptr[:-1][perm] - edge_ptr2[:-1], ec2, output_size=E) + ar(E)
-    take = lambda t, idx: None if t is None else t[idx].contiguous()
-    # units: greedy over the stored order, <= 64 graphs, staged bytes (row pointers + ids + edge types + node bytes) in budget
-    n_h, e_h = nc2.cpu().numpy(), ec2.cpu().numpy()
-    # the launcher sizes LDS from the largest node sum and the largest entry sum separately (gtok_sent.hip: row pointers
-    # cap_n + 64 + 16, ids and edge types cap_e + 8 each, node bytes cap_n + 8, every region 16-byte aligned): split the
-    # budget between the two in the corpus' own proportion
-    room = (LANE_UNIT_LDS - (64 + 16 + 8 + 8 + 8) - 4 * 15) // 2
-    ratio = float(e_h.sum()) / max(1.0, float(n_h.sum()))
-    ncap = max(64, int(room / (1.0 + ratio)))
-    ecap = max(255, room - ncap)
-    cn = np.concatenate([[0], np.cumsum(n_h)]); ce = np.concatenate([[0], np.cumsum(e_h)])
-    starts, i = [0], 0
-    while i < G:
-        j = min(i + 64, int(np.searchsorted(cn, cn[i] + ncap, side="right")) - 1, int(np.searchsorted(ce, ce[i] + ecap, side="right")) - 1)
-        i = max(j, i + 1)
-        starts.append(i)
-    starts = np.asarray(starts, np.int64)
-    out = GraphBatch(G, batch.max_nodes, batch.max_edges, node_ptr2.to(batch.node_ptr.dtype), edge_ptr2.to(batch.edge_ptr.dtype),
-                     batch.rowptr[src_r].contiguous(), batch.col[src_e].contiguous(), None, take(batch.nattr, src_n), take(batch.eattr, src_e),
-                     batch.flags, int((cn[starts[1:]] - cn[starts[:-1]]).max()), int((ce[starts[1:]] - ce[starts[:-1]]).max()),
-                     batch.max_degree)
-    out.graph_ids = perm.to(torch.int32)
-    out.unit_ptr = torch.from_numpy(starts.astype(np.int32)).to(dev)
-    out.num_units = int(starts.size) - 1
-    # per-unit descriptor (gtok_csr.unit_info): slots, node range and entry range of every unit in one 32-byte record
-    info = np.empty((out.num_units, 8), np.int32)
-    info[:, 0], info[:, 1] = starts[:-1], starts[1:]
-    info[:, 2], info[:, 3] = cn[starts[:-1]], cn[starts[1:]]
-    e01 = np.stack([ce[starts[:-1]], ce[starts[1:]]], 1).astype(np.int64)
-    info[:, 4:8] = e01.view(np.int32).reshape(-1, 4)          # (low, high) words of the two int64 entry offsets
-    out.unit_info = torch.from_numpy(info).to(dev)
-    pack8(out)
+    N, E = batch.num_nodes_total, batch.num_edges_total
+    L = lib()
+    i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+    o = dict(graph_ids=i32(G), node_ptr=i32(G + 1), edge_ptr=torch.empty(G + 1, dtype=torch.int64, device=dev), rowptr=i32(N + G), col=i32(E),
+             nattr=None if batch.nattr is None else u8(N), eattr=None if batch.eattr is None else u8(E),
+             rowptr8=u8(N + G + 16), col8=u8(E + 16),          # + slack: 16-byte vector loads of the last chunk may run past the end
+             unit_ptr=i32(G + 1), unit_info=i32(8 * G), info=i32(8))
+    if os.environ.get("GTOK_NO_PACK8") == "1":              # tests: the lane kernel's int32 staging path
+        o["rowptr8"] = o["col8"] = None
+    ws = torch.empty(int(L.gtok_csr_lane_sort_workspace(G)), dtype=torch.uint8, device=dev)
+    outs = _lib.GtokCsrSorted(*[None if o[n] is None else o[n].data_ptr() for n, _ in _lib.GtokCsrSorted._fields_])
+    cs = batch.c_struct()
+    check(L.gtok_csr_lane_sort(ctypes.byref(cs), LANE_UNIT_LDS, int(verify), ctypes.byref(outs), ws.data_ptr(), ws.numel(), _stream(dev)),
+          "gtok_csr_lane_sort")
+    viol, maxdeg, _, _, units, chunk_n, chunk_e, _ = o["info"].tolist()          # the one host read of the preparation
+    if verify:
+        if viol:
+            return None
+        batch.flags |= _lib.CSR_SIMPLE_SYMMETRIC
+        batch.max_degree = maxdeg
+    out = GraphBatch(G, batch.max_nodes, batch.max_edges, o["node_ptr"], o["edge_ptr"], o["rowptr"], o["col"], None, o["nattr"], o["eattr"],
+                     batch.flags, chunk_n, chunk_e, batch.max_degree or maxdeg)
+    out.graph_ids, out.num_units = o["graph_ids"], units
+    out.unit_ptr = o["unit_ptr"][:units + 1].clone()        # (the arrays are sized for one unit per graph: keep what is used)
+    out.unit_info = o["unit_info"][:8 * units].clone().view(units, 8)
+    out.rowptr8, out.col8 = o["rowptr8"], o["col8"]
     batch.lane_sorted = out
     return out
 
@@ -302,36 +300,54 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
     else:
         ids = torch.empty((K * G, ld), dtype=torch.int16 if u16 else torch.int32, device=dev)
         ln = torch.empty((K * G,), dtype=torch.int32, device=dev)
-    pack8(batch)
-    pin = os.environ.get("GTOK_SENT_KERNEL", "")
-    # the bit-matrix mirror is only built where gtok_sent would pick the kernel that reads it: unlabelled batches of
-    # >= ADJBITS_MIN_GRAPHS walks that the molecule kernel (<= 64 nodes, simple symmetric, >= LANE_MIN_GRAPHS) does not
-    # take - and never again for a batch that turned out unusable (a closure degree above 255)
+    if _lib.library_version() < 4 and (K > 1 or u16 or not pad):
+        # (GTOK_LIB pointing at an ABI v3 build: it would ignore epoch_count and the row flags and write an int32 [G, ld] slab)
+        raise _lib.GtokError(f"the loaded library has ABI version {_lib.library_version()}: epochs > 1, u16 and pad=False need version 4")
     walks = G * K
-    lane_takes = batch.max_nodes <= 64 and batch.max_edges <= 255 and bool(batch.flags & _lib.CSR_SIMPLE_SYMMETRIC) \
-        and walks >= LANE_MIN_GRAPHS
-    wants_blane = pin == "blane" or (not pin and not labeled and not remap_zinc and walks >= ADJBITS_MIN_GRAPHS and not lane_takes)
-    if wants_blane and not batch.adj_unusable:
-        if adjbits(batch):
-            if os.environ.get("GTOK_BLANE_ORDER", "1") != "0" and batch.lane_order_len != max(1, max_len):
-                batch.lane_order, batch.lane_order_len = _lane_order(batch, max(1, max_len)), max(1, max_len)   # once per (batch, max_len)
-        elif batch.col.device.type == "cuda" and batch.max_nodes <= 256 and os.environ.get("GTOK_NO_ADJBITS") != "1":
-            batch.adj_unusable = True
+    if not batch.prepared:          # (a batch prepared by the caller - torch.ops.gtok.csr_prepare - is launched as it stands)
+        pack8(batch)
+        pin = os.environ.get("GTOK_SENT_KERNEL", "")
+        # the bit-matrix mirror is only built where gtok_sent would pick the kernel that reads it: unlabelled batches of
+        # >= ADJBITS_MIN_GRAPHS walks that the molecule kernel (<= 64 nodes, simple symmetric, >= LANE_MIN_GRAPHS) does not
+        # take - and never again for a batch that turned out unusable (a closure degree above 255)
+        lane_takes = batch.max_nodes <= 64 and batch.max_edges <= 255 and bool(batch.flags & _lib.CSR_SIMPLE_SYMMETRIC) \
+            and walks >= LANE_MIN_GRAPHS
+        wants_blane = pin == "blane" or (not pin and not labeled and not remap_zinc and walks >= ADJBITS_MIN_GRAPHS and not lane_takes)
+        if wants_blane and not batch.adj_unusable:
+            if adjbits(batch):
+                if os.environ.get("GTOK_BLANE_ORDER", "1") != "0" and batch.lane_order_len != max(1, max_len):
+                    batch.lane_order, batch.lane_order_len = _lane_order(batch, max(1, max_len)), max(1, max_len)   # once per (batch, max_len)
+            elif batch.col.device.type == "cuda" and batch.max_nodes <= 256 and os.environ.get("GTOK_NO_ADJBITS") != "1":
+                batch.adj_unusable = True
     flags = (0 if pad else _lib.SENT_NO_PAD) | (_lib.SENT_U16 if u16 else 0)
     p = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc),
                        pad_id, flags, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
                        None if query is None else query.data_ptr(), K, 0)
     cs = batch.c_struct()
-    if os.environ.get("GTOK_NO_LANE_SORT") != "1" and batch.graph_ids is None \
+    if os.environ.get("GTOK_NO_LANE_SORT") != "1" and batch.graph_ids is None and not batch.prepared \
             and lib().gtok_sent_kernel_name(ctypes.byref(cs), ctypes.byref(p)) == b"sent_lane_kernel":
         sb = lane_sorted(batch)                                       # once per resident batch
         if sb is not None:
             cs = sb.c_struct()
+    global _LAST_SENT
+    _LAST_SENT = (cs, p)
     check(lib().gtok_sent(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)),
           "gtok_sent")
     if K > 1:
         return ids.view(K, G, ld), ln.view(K, G)
     return ids.view(G, ld), ln.view(G)
+
+
+_LAST_SENT = None
+
+
+def last_sent_kernel() -> str:
+    """Name of the kernel the most recent ops.sent call of this process launched (tests, bench labels): what the C ABI's
+    gtok_sent_kernel_name answers for the very structs that call passed to gtok_sent."""
+    if _LAST_SENT is None:
+        return ""
+    cs, p = _LAST_SENT
+    return lib().gtok_sent_kernel_name(ctypes.byref(cs), ctypes.byref(p)).decode()
 
 
 def sent_kernel_name(batch: GraphBatch, max_num_nodes: int, max_len: int, labeled: bool = False, num_node_types: int = 0,

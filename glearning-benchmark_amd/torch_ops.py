@@ -5,57 +5,228 @@ The ops take the batched-CSR arrays as plain tensors (layout: include/gtok.h); `
 GraphBatch-level wrappers, both end in the same C-ABI calls.  Fake (meta) implementations give output shapes,
 so the ops trace under torch.compile / FakeTensor without touching the GPU.
 """
-from typing import Optional, Tuple
+import weakref
+from typing import List, Optional, Tuple
 
 import torch
 from torch import Tensor
 
+from . import _lib
 from . import ops as _ops
 from .csr import GraphBatch
 
 
-def _batch(node_ptr, edge_ptr, rowptr, col, eorder, nattr, eattr, max_nodes, max_edges) -> GraphBatch:
-    return GraphBatch(int(node_ptr.numel()) - 1, max_nodes, max_edges, node_ptr, edge_ptr, rowptr, col, eorder, nattr, eattr)
+# A raw-tensor call carries no GraphBatch: the batch object - and with it everything ops.sent prepares once per resident
+# batch (the verified GTOK_CSR_SIMPLE_SYMMETRIC flag, the reordered copy, the byte / bit-matrix mirrors) - is kept here per
+# SET OF INPUT TENSORS: the same tensor objects, unchanged since (their version counters), find their batch again; tensors
+# that have died or were written to in place do not.  (Round 4 built a fresh flags=0 batch per call: the op then ran
+# sent_reg_kernel on ZINC - 8 x the time of the benchmarked sent_lane_kernel - and rebuilt the bit-matrix mirror every call.)
+_BATCHES: "dict[tuple, tuple]" = {}
+_BATCHES_MAX = 16
+_PREPARED: "dict[tuple, tuple]" = {}      # the same for batches the caller prepared (csr_prepare outputs passed back in)
 
 
-@torch.library.custom_op("gtok::sent", mutates_args=(), device_types="cuda")
+def _batch(node_ptr, edge_ptr, rowptr, col, eorder, nattr, eattr, max_nodes, max_edges, verify: bool = False) -> GraphBatch:
+    ts = (node_ptr, edge_ptr, rowptr, col, eorder, nattr, eattr)
+    key = tuple(id(t) for t in ts) + (int(max_nodes), int(max_edges))
+    hit = _BATCHES.get(key)
+    if hit is not None:
+        refs, vers, b = hit
+        if all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, ts)) \
+                and vers == tuple(None if t is None else t._version for t in ts):
+            if verify and not b.checked:
+                _verify(b)
+            return b
+        del _BATCHES[key]
+    b = GraphBatch(int(node_ptr.numel()) - 1, max_nodes, max_edges, node_ptr, edge_ptr, rowptr, col, eorder, nattr, eattr)
+    if verify:
+        _verify(b)
+    if len(_BATCHES) >= _BATCHES_MAX:
+        _BATCHES.pop(next(iter(_BATCHES)))
+    _BATCHES[key] = (tuple(None if t is None else weakref.ref(t) for t in ts), tuple(None if t is None else t._version for t in ts), b)
+    return b
+
+
+def _verify(b: GraphBatch) -> None:
+    """gtok_csr_check once per cached batch: what the flag claims is established on the device (one 32-byte read-back)."""
+    b.checked = True
+    if b.num_graphs == 0 or b.col.device.type != "cuda" or b.num_edges_total == 0:
+        return
+    r = _ops.csr_check(b)
+    if r["violations"] == 0 and r["max_nodes"] <= b.max_nodes and r["max_edges"] <= b.max_edges:
+        b.flags |= _lib.CSR_SIMPLE_SYMMETRIC
+        b.max_degree = r["max_degree"]
+
+
+def _prepared_batch(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes, max_edges, graph_ids, unit_ptr, unit_info, rowptr8, col8,
+                    adj_rows, adj_planes, lane_order, layout) -> GraphBatch:
+    """The batch a caller has prepared itself (csr_prepare / csr_adjbits outputs passed back in): nothing is built or cached."""
+    if layout is None or len(layout) != len(LAYOUT_FIELDS):
+        raise ValueError(f"layout must hold {LAYOUT_FIELDS}")
+    # (the batch object - and the C struct it caches - is kept per set of tensor objects, like _batch's: a call costs ~30 us of
+    # dispatcher before this function is reached, and a ZINC-full launch lasts 75)
+    ts = (node_ptr, edge_ptr, rowptr, col, nattr, eattr, graph_ids, unit_ptr, unit_info, rowptr8, col8, adj_rows, adj_planes, lane_order)
+    key = tuple(id(t) for t in ts) + (int(max_nodes), int(max_edges)) + tuple(int(v) for v in layout)
+    hit = _PREPARED.get(key)
+    if hit is not None:
+        refs, b = hit
+        if all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, ts)):
+            return b
+        del _PREPARED[key]
+    L = dict(zip(LAYOUT_FIELDS, (int(v) for v in layout)))
+    b = GraphBatch(int(node_ptr.numel()) - 1, max_nodes, max_edges, node_ptr, edge_ptr, rowptr, col, None, nattr, eattr,
+                   L["flags"], L["chunk_nodes"], L["chunk_edges"], L["max_degree"])
+    b.checked = b.prepared = True
+    b.rowptr8, b.col8 = rowptr8, col8
+    if graph_ids is not None:
+        if unit_ptr is None:
+            raise ValueError("graph_ids comes with unit_ptr (both are csr_prepare outputs)")
+        b.graph_ids, b.unit_ptr, b.unit_info, b.num_units = graph_ids, unit_ptr, unit_info, L["num_units"]
+    if adj_rows is not None:
+        b.adj_rows, b.adj_planes, b.lane_order = adj_rows, adj_planes, lane_order
+        b.adj_words, b.adj_max_degree = L["adj_words"], L["adj_max_degree"]
+    if len(_PREPARED) >= _BATCHES_MAX:
+        _PREPARED.pop(next(iter(_PREPARED)))
+    _PREPARED[key] = (tuple(None if t is None else weakref.ref(t) for t in ts), b)
+    return b
+
+
+LAYOUT_FIELDS = ("flags", "max_degree", "num_units", "chunk_nodes", "chunk_edges", "adj_words", "adj_max_degree")
+
+
+@torch.library.custom_op("gtok::csr_prepare", mutates_args=(), device_types="cuda")
+def csr_prepare(node_ptr: Tensor, edge_ptr: Tensor, rowptr: Tensor, col: Tensor, nattr: Optional[Tensor], eattr: Optional[Tensor],
+                max_nodes: int, max_edges: int) -> List[Tensor]:
+    """Everything gtok_sent's fastest kernel for a batch of small graphs needs, made ONCE per resident batch on the device
+    (gtok_csr_lane_sort with its check): -> [layout (int64 [7] on the HOST: LAYOUT_FIELDS), node_ptr, edge_ptr, rowptr, col,
+    nattr, eattr, graph_ids, unit_ptr, unit_info, rowptr8, col8] - the batch reordered by expected walk length with its unit
+    table and byte mirror.  Pass the arrays back to gtok::sent / gtok::sent_epochs in place of the originals, together with
+    graph_ids ... col8 and layout=layout.tolist() (prepared_args() does that): rows, lengths and RNG identities are those of
+    the batch in dataset order.  A batch the lane-per-graph kernel does not take (more than 64 nodes / 255 entries per graph,
+    or not simple and symmetric) comes back as empty arrays with layout[2] (num_units) == 0: keep calling with the
+    originals and flags = layout[0]."""
+    b = GraphBatch(int(node_ptr.numel()) - 1, max_nodes, max_edges, node_ptr, edge_ptr, rowptr, col, None, nattr, eattr)
+    dev = col.device
+    e = lambda dt: torch.empty(0, dtype=dt, device=dev)
+    sb = _ops.lane_sorted(b, verify=True)
+    if sb is None:
+        flags = maxdeg = 0
+        if b.num_graphs and b.num_edges_total:
+            r = _ops.csr_check(b)
+            ok = r["violations"] == 0 and r["max_nodes"] <= max_nodes and r["max_edges"] <= max_edges
+            flags, maxdeg = (_lib.CSR_SIMPLE_SYMMETRIC if ok else 0), r["max_degree"]
+        lay = torch.tensor([flags, maxdeg, 0, 0, 0, 0, 0], dtype=torch.int64)
+        return [lay, e(torch.int32), e(torch.int64), e(torch.int32), e(torch.int32), e(torch.uint8), e(torch.uint8), e(torch.int32),
+                e(torch.int32), e(torch.int32), e(torch.uint8), e(torch.uint8)]
+    lay = torch.tensor([sb.flags, sb.max_degree, sb.num_units, sb.chunk_nodes, sb.chunk_edges, 0, 0], dtype=torch.int64)
+    u8 = lambda t: e(torch.uint8) if t is None else t
+    return [lay, sb.node_ptr, sb.edge_ptr, sb.rowptr, sb.col, u8(sb.nattr), u8(sb.eattr), sb.graph_ids, sb.unit_ptr, sb.unit_info.reshape(-1),
+            u8(sb.rowptr8), u8(sb.col8)]
+
+
+@csr_prepare.register_fake
+def _(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes, max_edges):
+    ctx = torch.library.get_ctx()
+    G, U = node_ptr.shape[0] - 1, ctx.new_dynamic_size()
+    e = lambda n, dt: col.new_empty((n,), dtype=dt)
+    return [torch.empty(7, dtype=torch.int64, device="cpu"), e(G + 1, torch.int32), e(G + 1, torch.int64), e(rowptr.shape[0], torch.int32),
+            e(col.shape[0], torch.int32), e(0 if nattr is None else nattr.shape[0], torch.uint8), e(0 if eattr is None else eattr.shape[0], torch.uint8),
+            e(G, torch.int32), e(U, torch.int32), e(ctx.new_dynamic_size(), torch.int32), e(rowptr.shape[0] + 16, torch.uint8), e(col.shape[0] + 16, torch.uint8)]
+
+
+def prepared_args(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes: int, max_edges: int) -> dict:
+    """torch.ops.gtok.csr_prepare(...) as the keyword arguments of torch.ops.gtok.sent / sent_epochs: the batch arrays (the
+    reordered ones when the batch qualifies, else the originals), the unit table and mirrors, and `layout`."""
+    lay, np2, ep2, rp2, c2, na2, ea2, gid, up, ui, r8, c8 = torch.ops.gtok.csr_prepare(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes, max_edges)
+    layout = [int(v) for v in lay.tolist()]
+    if layout[2] == 0:
+        return dict(node_ptr=node_ptr, edge_ptr=edge_ptr, rowptr=rowptr, col=col, nattr=nattr, eattr=eattr, max_nodes=max_nodes,
+                    max_edges=max_edges, layout=layout)
+    opt = lambda t: t if t.numel() else None
+    return dict(node_ptr=np2, edge_ptr=ep2, rowptr=rp2, col=c2, nattr=opt(na2) if nattr is not None else None,
+                eattr=opt(ea2) if eattr is not None else None, max_nodes=max_nodes, max_edges=max_edges, graph_ids=gid, unit_ptr=up,
+                unit_info=ui, rowptr8=opt(r8), col8=opt(c8), layout=layout)
+
+
+def _sent_batch(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes, max_edges, graph_ids, unit_ptr, unit_info, rowptr8, col8,
+                adj_rows, adj_planes, lane_order, layout) -> GraphBatch:
+    if layout is not None:
+        return _prepared_batch(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes, max_edges, graph_ids, unit_ptr, unit_info,
+                               rowptr8, col8, adj_rows, adj_planes, lane_order, layout)
+    if any(t is not None for t in (graph_ids, unit_ptr, unit_info, rowptr8, col8, adj_rows, adj_planes, lane_order)):
+        raise ValueError("prepared arrays come with `layout` (torch.ops.gtok.csr_prepare / prepared_args)")
+    return _batch(node_ptr, edge_ptr, rowptr, col, None, nattr, eattr, max_nodes, max_edges, verify=True)
+
+
+# gtok::sent / gtok::sent_epochs are registered through torch.library.Library (schema + a CUDA kernel + a fake kernel) rather than
+# through torch.library.custom_op: an epoch of ZINC-full is a 75 us launch, and custom_op's wrapper costs ~30-38 us per call on
+# the host where this route costs ~15 - with it the op was host-bound (0.082 ms per step against the kernel's 0.075).
+_FRAG = torch.library.Library("gtok", "FRAGMENT")
+_PREPARED_SCHEMA = ("Tensor? graph_ids=None, Tensor? unit_ptr=None, Tensor? unit_info=None, Tensor? rowptr8=None, Tensor? col8=None, "
+                    "Tensor? adj_rows=None, Tensor? adj_planes=None, Tensor? lane_order=None, int[]? layout=None")
+
+
 def sent(node_ptr: Tensor, edge_ptr: Tensor, rowptr: Tensor, col: Tensor, nattr: Optional[Tensor],
          eattr: Optional[Tensor], query: Optional[Tensor], max_nodes: int, max_edges: int, max_num_nodes: int,
          max_len: int, ld: int, seed: int, epoch: int, labeled: bool, num_node_types: int, num_edge_types: int,
-         remap_zinc: bool, pad_id: int, graph_base: int) -> Tuple[Tensor, Tensor]:
-    b = _batch(node_ptr, edge_ptr, rowptr, col, None, nattr, eattr, max_nodes, max_edges)
+         remap_zinc: bool, pad_id: int, graph_base: int, graph_ids: Optional[Tensor] = None, unit_ptr: Optional[Tensor] = None,
+         unit_info: Optional[Tensor] = None, rowptr8: Optional[Tensor] = None, col8: Optional[Tensor] = None,
+         adj_rows: Optional[Tensor] = None, adj_planes: Optional[Tensor] = None, lane_order: Optional[Tensor] = None,
+         layout: Optional[List[int]] = None) -> Tuple[Tensor, Tensor]:
+    """gtok_sent.  Without `layout` the batch behind these tensors is prepared on the first call (verified on the device,
+    reordered / mirrored as the kernel choice needs) and found again on later calls with the SAME tensor objects; with
+    `layout` (csr_prepare / prepared_args) the call uses exactly what it is given."""
+    b = _sent_batch(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes, max_edges, graph_ids, unit_ptr, unit_info, rowptr8, col8,
+                    adj_rows, adj_planes, lane_order, layout)
     return _ops.sent(b, max_num_nodes, max_len, seed, epoch, labeled=labeled, num_node_types=num_node_types,
                      num_edge_types=num_edge_types, remap_zinc=remap_zinc, pad_id=pad_id, graph_base=graph_base,
                      query=query, ld=ld)
 
 
-@sent.register_fake
-def _(node_ptr, edge_ptr, rowptr, col, nattr, eattr, query, max_nodes, max_edges, max_num_nodes, max_len, ld, seed,
-      epoch, labeled, num_node_types, num_edge_types, remap_zinc, pad_id, graph_base):
+def _sent_fake(node_ptr, edge_ptr, rowptr, col, nattr, eattr, query, max_nodes, max_edges, max_num_nodes, max_len, ld, seed,
+               epoch, labeled, num_node_types, num_edge_types, remap_zinc, pad_id, graph_base, graph_ids=None, unit_ptr=None, unit_info=None,
+               rowptr8=None, col8=None, adj_rows=None, adj_planes=None, lane_order=None, layout=None):
     G = node_ptr.shape[0] - 1
     return node_ptr.new_empty((G, ld), dtype=torch.int32), node_ptr.new_empty((G,), dtype=torch.int32)
 
 
-@torch.library.custom_op("gtok::sent_epochs", mutates_args=(), device_types="cuda")
+_FRAG.define("sent(Tensor node_ptr, Tensor edge_ptr, Tensor rowptr, Tensor col, Tensor? nattr, Tensor? eattr, Tensor? query, int max_nodes, "
+             "int max_edges, int max_num_nodes, int max_len, int ld, int seed, int epoch, bool labeled, int num_node_types, int num_edge_types, "
+             "bool remap_zinc, int pad_id, int graph_base, " + _PREPARED_SCHEMA + ") -> (Tensor, Tensor)")
+_FRAG.impl("sent", sent, "CUDA")
+torch.library.register_fake("gtok::sent", _sent_fake, lib=_FRAG)
+
+
 def sent_epochs(node_ptr: Tensor, edge_ptr: Tensor, rowptr: Tensor, col: Tensor, nattr: Optional[Tensor],
                 eattr: Optional[Tensor], query: Optional[Tensor], max_nodes: int, max_edges: int, max_num_nodes: int,
                 max_len: int, ld: int, seed: int, epoch: int, epochs: int, labeled: bool, num_node_types: int, num_edge_types: int,
-                remap_zinc: bool, pad_id: int, graph_base: int, pad: bool, u16: bool) -> Tuple[Tensor, Tensor]:
+                remap_zinc: bool, pad_id: int, graph_base: int, pad: bool, u16: bool, graph_ids: Optional[Tensor] = None,
+                unit_ptr: Optional[Tensor] = None, unit_info: Optional[Tensor] = None, rowptr8: Optional[Tensor] = None,
+                col8: Optional[Tensor] = None, adj_rows: Optional[Tensor] = None, adj_planes: Optional[Tensor] = None,
+                lane_order: Optional[Tensor] = None, layout: Optional[List[int]] = None) -> Tuple[Tensor, Tensor]:
     """gtok_sent with ABI v4's epoch_count and row flags: epochs epoch .. epoch + epochs - 1 in ONE launch ->
     (ids [epochs * G, ld] int32 - or int16 storage holding 16-bit ids when u16 -, len int32 [epochs * G]), epoch-major;
-    pad=False leaves the pad tails unwritten (GTOK_SENT_NO_PAD)."""
-    b = _batch(node_ptr, edge_ptr, rowptr, col, None, nattr, eattr, max_nodes, max_edges)
+    pad=False leaves the pad tails unwritten (GTOK_SENT_NO_PAD).  Prepared arrays / `layout`: see gtok::sent."""
+    b = _sent_batch(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes, max_edges, graph_ids, unit_ptr, unit_info, rowptr8, col8,
+                    adj_rows, adj_planes, lane_order, layout)
     ids, ln = _ops.sent(b, max_num_nodes, max_len, seed, epoch, labeled=labeled, num_node_types=num_node_types,
                         num_edge_types=num_edge_types, remap_zinc=remap_zinc, pad_id=pad_id, graph_base=graph_base,
                         query=query, ld=ld, pad=pad, epochs=epochs, u16=u16)
     return ids.reshape(-1, ld), ln.reshape(-1)
 
 
-@sent_epochs.register_fake
-def _(node_ptr, edge_ptr, rowptr, col, nattr, eattr, query, max_nodes, max_edges, max_num_nodes, max_len, ld, seed,
-      epoch, epochs, labeled, num_node_types, num_edge_types, remap_zinc, pad_id, graph_base, pad, u16):
+def _sent_epochs_fake(node_ptr, edge_ptr, rowptr, col, nattr, eattr, query, max_nodes, max_edges, max_num_nodes, max_len, ld, seed,
+                      epoch, epochs, labeled, num_node_types, num_edge_types, remap_zinc, pad_id, graph_base, pad, u16, graph_ids=None,
+                      unit_ptr=None, unit_info=None, rowptr8=None, col8=None, adj_rows=None, adj_planes=None, lane_order=None, layout=None):
     rows = (node_ptr.shape[0] - 1) * max(1, epochs)
     return node_ptr.new_empty((rows, ld), dtype=torch.int16 if u16 else torch.int32), node_ptr.new_empty((rows,), dtype=torch.int32)
+
+
+_FRAG.define("sent_epochs(Tensor node_ptr, Tensor edge_ptr, Tensor rowptr, Tensor col, Tensor? nattr, Tensor? eattr, Tensor? query, int max_nodes, "
+             "int max_edges, int max_num_nodes, int max_len, int ld, int seed, int epoch, int epochs, bool labeled, int num_node_types, "
+             "int num_edge_types, bool remap_zinc, int pad_id, int graph_base, bool pad, bool u16, " + _PREPARED_SCHEMA + ") -> (Tensor, Tensor)")
+_FRAG.impl("sent_epochs", sent_epochs, "CUDA")
+torch.library.register_fake("gtok::sent_epochs", _sent_epochs_fake, lib=_FRAG)
 
 
 @torch.library.custom_op("gtok::ibtt_zinc", mutates_args=(), device_types="cuda")

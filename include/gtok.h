@@ -32,6 +32,12 @@
  *                      trainer/train_agtt.py:276-302 straight over GTOK_SENT_U16 rows
  *   gtok_ids_to_text   graph_data_loader/zinc_dataset_indexbase.py:143-227, the STRING form (ids rendered through a string table)
  *   gtok_zinc_text_tails   zinc_dataset_indexbase.py:186-195, :217-221 (label token + <eos> / the max_len cut, per molecule)
+ *   gtok_csr_check     (no reference counterpart; the property torch_geometric's coalesced undirected graphs have by construction -
+ *                      zinc_dataset_autograph.py:51-73 passes them through) verifies GTOK_CSR_SIMPLE_SYMMETRIC on the device and
+ *                      measures max_nodes / max_edges / max_degree
+ *   gtok_csr_lane_sort (no reference counterpart) the reordered copy of a small-graph batch that the lane-per-graph SENT kernel
+ *                      walks fastest (graph_ids / unit_ptr / unit_info + the permuted arrays and their byte mirror), built on
+ *                      the device: what a caller of trainer/train_agtt.py:246-250's tokenizer prepares once per split
  *   gtok_csr_pack8     (no reference counterpart) byte-packed mirror of the CSR index arrays of small-graph batches
  *   gtok_csr_adjbits   (no reference counterpart) adjacency bit-matrix mirror of batches of graphs with <= 256 nodes
  *   gtok_vocab_stats_text   the corpus pass of build_vocab_from_texts / the ZINC dynamic-token scan over arbitrary texts
@@ -90,7 +96,7 @@ extern "C" {
 
 #define GTOK_MAX_NODES 512 /* SENT adjacency bit-matrix rows per wave (LDS)  */
 
-/* flags: properties the HOST has verified for the whole batch */
+/* flags: properties the CALLER has verified for the whole batch (on the host, or with gtok_csr_check on the device) */
 #define GTOK_CSR_SIMPLE_SYMMETRIC 1 /* simple undirected graphs, both directions stored: no self-loop, no entry
                                        listed twice, and (v,u) is listed whenever (u,v) is - every row is the
                                        node's complete neighbour list (PyG-coalesced molecules).  A batch flagged
@@ -168,6 +174,55 @@ typedef struct gtok_csr {
  * GTOK_E_TOO_LARGE when max_edges > 255 or max_nodes > 256 (values would not fit).  No reference counterpart: a
  * data-layout step, done once when a batch becomes resident, like the CSR build itself.                       */
 int gtok_csr_pack8(const gtok_csr *g, int64_t num_rowptr, int64_t num_col, uint8_t *rowptr8, uint8_t *col8, void *stream);
+
+/* What GTOK_CSR_SIMPLE_SYMMETRIC claims, verified on the device (ABI v5), and the batch maxima a caller may not know:
+ * info = int32[8] in device memory (zeroed by the call), after the stream has run it holds
+ *   [0] violations: 0 <=> every graph is simple and stored in both directions (no self loop, no (u,v) listed twice, (v,u)
+ *       listed whenever (u,v) is) AND the arrays are well-formed (sizes >= 0, row pointers start at 0, never decrease and end
+ *       at E_g, neighbour ids inside [0, N_g)) - only then may flags carry GTOK_CSR_SIMPLE_SYMMETRIC;
+ *   [1] the longest row (max_degree)   [2] max N_g (max_nodes)   [3] max E_g (max_edges)   [4..7] 0.
+ * Of *g only num_graphs and the five array pointers are read (col may be NULL when max_edges == 0 is claimed: the entry
+ * checks are then skipped); a batch in dataset order only (graph_ids / unit_ptr set: GTOK_E_INVAL).  Nothing is read through an
+ * offset that has not been range-checked first, so a damaged batch yields violations, never a fault - PROVIDED node_ptr /
+ * edge_ptr hold num_graphs + 1 entries and rowptr / col as many elements as those two say.                                */
+int gtok_csr_check(const gtok_csr *g, int32_t *info, void *stream);
+
+/* The reordered copy of a batch of small graphs (max_nodes <= 64, max_edges <= 255: GTOK_E_TOO_LARGE otherwise) that
+ * gtok_sent's lane-per-graph kernel walks fastest, built on the device in a dozen small launches and no host round trip
+ * (ABI v5).  Graphs are stored by descending (nodes + rows of length 1) - the expected walk length: a walk restarts once per
+ * dead end - ties in dataset order, and cut greedily into units of <= 64 graphs whose node and entry sums fit `lds_budget`
+ * bytes of LDS per wave (0 = 10224: 16 resident waves per CU share its 160 KB), the budget being split between the two in
+ * the corpus' own proportion.  Outputs (device memory, caller-allocated, G = num_graphs, N / E = the batch's node / entry
+ * totals):
+ *   graph_ids int32[G]        dataset index of the graph at every stored slot
+ *   node_ptr  int32[G + 1], edge_ptr int64[G + 1], rowptr int32[N + G], col int32[E], nattr / eattr uint8[N] / [E] (only
+ *                             when the batch has them): the batch in stored order, same layout as gtok_csr
+ *   rowptr8   uint8[N + G + 16], col8 uint8[E + 16]   (optional, NULL = skip) the byte mirror of the two (gtok_csr_pack8)
+ *   unit_ptr  int32[G + 1]    first slot of every unit, num_units + 1 entries used
+ *   unit_info int32[8 G]      one record per unit (gtok_csr.unit_info), 8 num_units entries used
+ *   info      int32[8]        as gtok_csr_check ([0] only when check != 0, else 0) + [4] num_units, [5] chunk_nodes,
+ *                             [6] chunk_edges (the largest unit's node and entry sums)
+ * The caller reads `info` back once (the only host read of the whole preparation), fills a gtok_csr with the new arrays,
+ * flags (GTOK_CSR_SIMPLE_SYMMETRIC if verified), max_degree = info[1], chunk_nodes / chunk_edges, graph_ids, unit_ptr,
+ * num_units, unit_info, rowptr8 / col8, and passes that to gtok_sent.  `workspace`: gtok_csr_lane_sort_workspace(G) bytes of
+ * device memory, 16-byte aligned, free again when the stream has run the call.                                            */
+typedef struct gtok_csr_sorted {
+  int32_t *graph_ids;
+  int32_t *node_ptr;
+  int64_t *edge_ptr;
+  int32_t *rowptr;
+  int32_t *col;
+  uint8_t *nattr;
+  uint8_t *eattr;
+  uint8_t *rowptr8;
+  uint8_t *col8;
+  int32_t *unit_ptr;
+  int32_t *unit_info;
+  int32_t *info;
+} gtok_csr_sorted;
+int64_t gtok_csr_lane_sort_workspace(int32_t num_graphs);
+int gtok_csr_lane_sort(const gtok_csr *g, int32_t lds_budget, int32_t check, const gtok_csr_sorted *out, void *workspace,
+                       int64_t workspace_bytes, void *stream);
 
 /* Adjacency bit-matrix mirror (see gtok_csr.adj_rows): rows = [sum N_g][words] uint64, planes = [G][8][words] uint64,
  * info = int32[1], zeroed by the caller, receives the largest closure degree.  words = 1, 2 or 4 with 64 * words >=
@@ -435,8 +490,9 @@ const char *gtok_ibtt_zinc_kernel_name(const gtok_csr *g);
 
 /* ABI version (GTOK_ABI_VERSION of the header the library was built from: 2 since gtok_csr carries the optional
  * mirrors - a binding checks it before passing structs; 3 adds the packed-row entry points; 4: gtok_sent_params carries
- * epoch_count, GTOK_SENT_U16, the strided / checked packed-row readers) and build target string ("gfx950").                     */
-#define GTOK_ABI_VERSION 4
+ * epoch_count, GTOK_SENT_U16, the strided / checked packed-row readers; 5 adds gtok_csr_check / gtok_csr_lane_sort -
+ * structs unchanged) and build target string ("gfx950").                     */
+#define GTOK_ABI_VERSION 5
 int gtok_version(void);
 const char *gtok_target(void);
 

@@ -282,3 +282,43 @@ class PygInMemoryLike:
         base = list(self.indices())
         out._indices = base[idx] if isinstance(idx, slice) else [base[int(i)] for i in idx]
         return out
+
+
+# ------------------------------------------------------------------------------------------------ layout rules, restated
+def lane_sort_reference(batch, lds_budget=10224):
+    """The rule gtok_csr_lane_sort implements (include/gtok.h), restated with numpy on a HOST GraphBatch: graphs by
+    descending (nodes + rows of length 1), ties in dataset order; units cut greedily over that order - at most 64 graphs,
+    node and entry sums within the caps (the LDS budget split between the two in the corpus' own proportion).
+    Returns dict(graph_ids, node_ptr, edge_ptr, rowptr, col, nattr, eattr, unit_ptr, unit_info, chunk_nodes, chunk_edges)."""
+    G = batch.num_graphs
+    node_ptr, edge_ptr = batch.node_ptr.numpy().astype(np.int64), batch.edge_ptr.numpy().astype(np.int64)
+    rowptr, col = batch.rowptr.numpy(), batch.col.numpy()
+    nc, ec = np.diff(node_ptr), np.diff(edge_ptr)
+    leaves = np.zeros(G, np.int64)
+    for g in range(G):
+        rp = rowptr[node_ptr[g] + g:node_ptr[g + 1] + g + 1]
+        leaves[g] = int((np.diff(rp) == 1).sum())
+    perm = np.argsort(-(nc + leaves), kind="stable")
+    nc2, ec2 = nc[perm], ec[perm]
+    cn = np.concatenate([[0], np.cumsum(nc2)]); ce = np.concatenate([[0], np.cumsum(ec2)])
+    room = (lds_budget - (64 + 16 + 8 + 8 + 8) - 4 * 15) // 2
+    ratio = float(ec2.sum()) / max(1.0, float(nc2.sum()))
+    ncap = max(64, int(room / (1.0 + ratio)))
+    ecap = max(255, room - ncap)
+    starts, i = [0], 0
+    while i < G:
+        j = min(i + 64, int(np.searchsorted(cn, cn[i] + ncap, side="right")) - 1, int(np.searchsorted(ce, ce[i] + ecap, side="right")) - 1)
+        i = max(j, i + 1)
+        starts.append(i)
+    starts = np.asarray(starts, np.int64)
+    rp2 = np.concatenate([rowptr[node_ptr[g] + g:node_ptr[g + 1] + g + 1] for g in perm]) if G else rowptr[:0]
+    col2 = np.concatenate([col[edge_ptr[g]:edge_ptr[g + 1]] for g in perm]) if G else col[:0]
+    take_n = lambda a: None if a is None else np.concatenate([a.numpy()[node_ptr[g]:node_ptr[g + 1]] for g in perm])
+    take_e = lambda a: None if a is None else np.concatenate([a.numpy()[edge_ptr[g]:edge_ptr[g + 1]] for g in perm])
+    info = np.empty((starts.size - 1, 8), np.int32)
+    info[:, 0], info[:, 1] = starts[:-1], starts[1:]
+    info[:, 2], info[:, 3] = cn[starts[:-1]], cn[starts[1:]]
+    info[:, 4:8] = np.stack([ce[starts[:-1]], ce[starts[1:]]], 1).astype(np.int64).view(np.int32).reshape(-1, 4)
+    return dict(graph_ids=perm.astype(np.int32), node_ptr=cn.astype(np.int32), edge_ptr=ce.astype(np.int64), rowptr=rp2, col=col2,
+                nattr=take_n(batch.nattr), eattr=take_e(batch.eattr), unit_ptr=starts.astype(np.int32), unit_info=info,
+                chunk_nodes=int((cn[starts[1:]] - cn[starts[:-1]]).max()), chunk_edges=int((ce[starts[1:]] - ce[starts[:-1]]).max()))
