@@ -346,31 +346,54 @@ __device__ __forceinline__ int64_t wave_sum64(int64_t v) {
   return v;
 }
 // Called by ONE whole wave of the tile's workgroup with the tile's sum (sum >= 0); returns the exclusive prefix of the
-// tile in every lane and leaves the inclusive prefix in the tile's word.
-__device__ __forceinline__ int64_t lookback_exclusive(int64_t *__restrict__ state, int tile, int64_t sum) {
+// tile in every lane and leaves the inclusive prefix in the tile's word.  `word(t)` = the address of tile t's status word
+// (an array of its own, or - gtok_pack_rows_scan - the slot of the output array that ends up holding that very prefix).
+// The window a wave looks back through is 64 x kLookW tiles wide (kLookW words per lane, nearest first): when every tile of a
+// launch is resident at once (a 250 k-row slab: ~1,000 tiles starting together) no tile has a finished prefix to offer yet,
+// and a tile's wait is (its index / window) round trips - with 64-tile windows the last tiles of ZINC-full waited 15 of them.
+constexpr int kLookW = 4;
+template <typename W>
+__device__ __forceinline__ int64_t lookback_exclusive(W word, int tile, int64_t sum) {
   const int lane = lane_id();
   if (tile == 0) {
-    if (lane == 0) __hip_atomic_store(state, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(word(0), sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return 0;
   }
-  if (lane == 0) __hip_atomic_store(state + tile, -sum - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(word(tile), -sum - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int64_t excl = 0;
-  int t = tile - 1;                                   // lane l looks at tile t - l
+  int t = tile - 1;                                   // lane l looks at tiles t - kLookW l - k, k = 0 .. kLookW - 1
   for (;;) {
-    const int idx = t - lane;
-    int64_t v = 0;                                    // below tile 0: a prefix of zero
-    if (idx >= 0) v = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t empty = __ballot(v == kTileEmpty), full = __ballot(v >= 0);   // (lanes below tile 0 read as full)
-    const int p = full ? __builtin_ctzll(full) : 63;  // the nearest tile with a finished prefix (lanes beyond tile 0 always are)
+    int64_t v[kLookW];
+#pragma unroll
+    for (int k = 0; k < kLookW; ++k) {
+      const int idx = t - lane * kLookW - k;
+      v[k] = 0;                                       // below tile 0: a prefix of zero
+      if (idx >= 0) v[k] = __hip_atomic_load(word(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // this lane's share: the sums of its tiles up to and including its nearest finished prefix (if it has one)
+    int64_t mine = 0;
+    bool has_full = false, empty_before = false;
+#pragma unroll
+    for (int k = 0; k < kLookW; ++k) {
+      if (!has_full) {
+        if (v[k] == kTileEmpty) empty_before = true;
+        else if (v[k] >= 0) { mine += v[k]; has_full = true; }
+        else mine += -v[k] - 2;
+      }
+    }
+    const uint64_t full = __ballot(has_full);         // (lanes beyond tile 0 always are)
+    const int p = full ? __builtin_ctzll(full) : 63;  // the nearest lane that holds a finished prefix
     const uint64_t upto = p >= 63 ? ~0ull : ((2ull << p) - 1ull);
-    if (empty & upto) { __builtin_amdgcn_s_sleep(2); continue; }      // a tile in between has published nothing yet
-    const int64_t mine = lane > p ? 0 : (v >= 0 ? v : -v - 2);
-    excl += wave_sum64(mine);
+    if (__ballot(empty_before) & upto) { __builtin_amdgcn_s_sleep(2); continue; }      // a tile in between has published nothing yet
+    excl += wave_sum64(lane > p ? 0 : mine);
     if (full) break;
-    t -= kWave;
+    t -= kWave * kLookW;
   }
-  if (lane == 0) __hip_atomic_store(state + tile, excl + sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(word(tile), excl + sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return excl;
+}
+__device__ __forceinline__ int64_t lookback_exclusive(int64_t *__restrict__ state, int tile, int64_t sum) {
+  return lookback_exclusive([state](int t) { return state + t; }, tile, sum);
 }
 
 // Philox4x32-10 (Salmon et al. 2011), the counter-based generator of the SENT spec.

@@ -114,7 +114,7 @@ __device__ __forceinline__ int64_t packed_start(const int64_t *__restrict__ row_
 
 struct RowsArgs {
   const void *ids;         // pack: source slab (int32, or uint16 for gtok_pack_rows_u16); unpack: unused
-  int32_t *out_ids;        // unpack: destination slab
+  void *out_ids;           // unpack: destination slab (int32, or 16-bit ids: gtok_unpack_rows_u16)
   const int32_t *len;
   const int64_t *row_ptr;
   void *packed;
@@ -128,19 +128,7 @@ struct RowsArgs {
 // int64_t).  A thread owns pieces of 8 consecutive ids of one row: 16-byte loads and stores; 1 << tpr_shift threads
 // share a row, 256 >> tpr_shift rows a workgroup.
 template <typename S, typename E>
-__global__ void __launch_bounds__(256) pack_rows_kernel(const RowsArgs a) {
-  const int tpr = 1 << a.tpr_shift, sub = (int)threadIdx.x & (tpr - 1);
-  const int64_t r = (int64_t)blockIdx.x * (256 >> a.tpr_shift) + ((int)threadIdx.x >> a.tpr_shift);
-  if (r >= a.rows) return;
-  int n = a.len[r];
-  n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
-  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride, a.ld);
-  const S *__restrict__ row = reinterpret_cast<const S *>(a.ids) + r * (int64_t)a.ld;
-  if (start + n > a.capacity) {                      // a caller-sized buffer that turned out too small: skip, flag
-    if (sub == 0) atomicOr(a.status, 2);
-    return;
-  }
-  E *__restrict__ dst = reinterpret_cast<E *>(a.packed) + start;
+__device__ __forceinline__ uint32_t copy_row_pieces(const S *__restrict__ row, E *__restrict__ dst, int n, int sub, int tpr) {
   const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
   uint32_t wide = 0;
   for (int i = sub * 8; i < n; i += tpr * 8) {
@@ -183,13 +171,213 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const RowsArgs a) {
       }
     }
   }
+  return wide;
+}
+
+template <typename S, typename E>
+__global__ void __launch_bounds__(256) pack_rows_kernel(const RowsArgs a) {
+  const int tpr = 1 << a.tpr_shift, sub = (int)threadIdx.x & (tpr - 1);
+  const int64_t r = (int64_t)blockIdx.x * (256 >> a.tpr_shift) + ((int)threadIdx.x >> a.tpr_shift);
+  if (r >= a.rows) return;
+  int n = a.len[r];
+  n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
+  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride, a.ld);
+  const S *__restrict__ row = reinterpret_cast<const S *>(a.ids) + r * (int64_t)a.ld;
+  if (start + n > a.capacity) {                      // a caller-sized buffer that turned out too small: skip, flag
+    if (sub == 0) atomicOr(a.status, 2);
+    return;
+  }
+  const uint32_t wide = copy_row_pieces<S, E>(row, reinterpret_cast<E *>(a.packed) + start, n, sub, tpr);
   if (sizeof(E) == 2 && sizeof(S) == 4 && (wide & 0xFFFF0000u)) atomicOr(a.status, 1);     // an id that does not fit 16 bits
+}
+
+// gtok_row_offsets + gtok_pack_rows(_u16) in ONE launch (gtok_pack_rows_scan): a workgroup takes a tile of 256 rows, sums
+// their packed sizes, learns where the tile starts from the tiles before it (decoupled look-back: the status word of tile t
+// IS the row_ptr slot that closes it, which ends up holding exactly the tile's inclusive prefix), writes its row_ptr
+// entries and copies its rows.  The three scan launches and the second read of the lengths are gone; what remains is the
+// one read of the ids and the one write of the packed form.
+constexpr int kPackU = 4;
+struct PackScanArgs {
+  const void *ids; const int32_t *len; int64_t *row_ptr; void *packed; int32_t *status; int *ticket;
+  int64_t rows, capacity;
+  int ld, align_mask, tpr_shift, tiles, chunk;      // chunk: consecutive tiles per workgroup (one ticket each)
+  int fast;       // 8-id alignment, every slab row and the packed buffer on 16-byte boundaries: the flat piece loop
+};
+
+__global__ void __launch_bounds__(256) pack_scan_init_kernel(int64_t *__restrict__ row_ptr, int64_t rows, int tiles, int tile_rows, int32_t *__restrict__ status) {
+  const int t = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (t < tiles) { const int64_t end = ((int64_t)t + 1) * tile_rows; row_ptr[end < rows ? end : rows] = kTileEmpty; }
+  if (t == 0) { row_ptr[0] = 0; *status = 0; }
+}
+
+// TILE rows per tile (64, 128 or 256), 256 threads; a workgroup takes a.chunk consecutive tiles on ONE ticket (a device-wide
+// counter hands out ~88 tickets per microsecond: with a ticket per tile the 15.6 k tiles of 16 ZINC-full epochs waited 170 us
+// in line).  Tiles are numbered in ticket order, so every lower tile belongs to a workgroup that is running or done - whatever
+// order HIP dispatches workgroups in.  The sums of ALL the chunk's tiles are published before anything else is done (a
+// successor must never wait for this workgroup's copies), then ONE look-back gives the chunk's start and with it every
+// tile's inclusive prefix.
+constexpr int kPackChunkMax = 8;
+template <typename S, typename E, int TILE>
+__global__ void __launch_bounds__(256) pack_scan_kernel(const PackScanArgs a) {
+  constexpr int kPackTile = TILE, kScanWaves = TILE / kWave;
+  __shared__ int s_tile;
+  __shared__ int64_t s_wsum[4], s_base, s_start[kPackTile], s_tsum[kPackChunkMax];
+  __shared__ int s_n[kPackTile], s_p[kPackTile], s_len[kPackChunkMax][kPackTile], s_part[kPackChunkMax][4];
+  const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6;
+  if (tid == 0) {
+    const int t = atomicAdd(a.ticket, 1);
+    if (t == (a.tiles + a.chunk - 1) / a.chunk - 1) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the last draw re-arms the counter
+    s_tile = t * a.chunk;
+  }
+  __syncthreads();
+  const int tile_first = s_tile, ntile = min(a.tiles - tile_first, a.chunk);
+  int64_t *const rp = a.row_ptr;
+  const int64_t rows = a.rows;
+  auto word = [rp, rows](int t) { const int64_t end = ((int64_t)t + 1) * kPackTile; return rp + (end < rows ? end : rows); };
+  // ---- phase 1: the lengths and sums of the chunk's tiles; the sums are published at once
+  for (int i = 0; i < ntile; ++i) {
+    const int64_t r = (int64_t)(tile_first + i) * kPackTile + tid;
+    int c = 0;
+    if (tid < kPackTile) {
+      int n = 0;
+      if (r < rows) { n = a.len[r]; n = n < 0 ? 0 : (n > a.ld ? a.ld : n); c = (n + a.align_mask) & ~a.align_mask; }
+      s_len[i][tid] = n;
+    }
+    if (w < kScanWaves) {
+      const int ws = (int)wave_sum64(c);
+      if (lane == 0) s_part[i][w] = ws;
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    int64_t mysum = 0;
+    if (lane < ntile) {
+      for (int k = 0; k < kScanWaves; ++k) mysum += s_part[lane][k];
+      s_tsum[lane] = mysum;
+      if (lane > 0 || tile_first > 0)      // (tile 0's word goes straight to its prefix below)
+        __hip_atomic_store(word(tile_first + lane), -mysum - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int64_t first_sum = __shfl(mysum, 0);
+    const int64_t x = lookback_exclusive(word, tile_first, first_sum);       // (publishes the first tile's prefix itself)
+    // every later tile of the chunk: its inclusive prefix follows from the chunk's start
+    int64_t inc = mysum;
+#pragma unroll
+    for (int o = 1; o < kPackChunkMax; o <<= 1) { const int64_t up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+    if (lane > 0 && lane < ntile) __hip_atomic_store(word(tile_first + lane), x + inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) s_base = x;
+  }
+  __syncthreads();
+  int64_t chunk_base = s_base;
+  // ---- phase 2: tile by tile - row offsets, row_ptr, the copy
+  for (int i = 0; i < ntile; ++i) {
+  const int tile = tile_first + i;
+  const int64_t r = (int64_t)tile * kPackTile + tid;
+  const bool mine = tid < kPackTile && r < rows;
+  const int n = tid < kPackTile ? s_len[i][tid] : 0;
+  const int64_t cost = mine ? (int64_t)((n + a.align_mask) & ~a.align_mask) : 0;
+  int64_t inc = cost;
+  if (w < kScanWaves) {
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) { const int64_t up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+  }
+  int64_t start = chunk_base + inc - cost;
+  for (int k = 0; k < w && k < kScanWaves; ++k) start += s_part[i][k];
+  if (tid < kPackTile) { s_start[tid] = start; s_n[tid] = n; }
+  // row_ptr[r + 1] = the end of row r; the slot that closes the tile is its status word (it holds the same value)
+  if (mine && tid != kPackTile - 1 && r + 1 < rows) a.row_ptr[r + 1] = start + cost;
+  const int64_t tbase_tile = chunk_base;
+  const int64_t tile_sum = s_tsum[i];
+  chunk_base += tile_sum;
+  uint32_t wide = 0;
+  bool over = false;
+  if (a.fast) {
+    // 8-id pieces, flat over the tile: with 8-id alignment the tile's packed region is ONE run of whole 16-byte (E = 2 bytes)
+    // pieces, piece j of the tile landing at tile_start + 8 j.  A thread takes pieces tid, tid + 256, ... - kPackU of them per
+    // pass, their loads in flight together (a row-per-thread-group loop had one load in flight per thread: 61 us for ZINC-full's
+    // 44 MB in + 44 MB out, slower than the four launches it replaced) - and finds a piece's row by bisection over the rows'
+    // piece offsets in LDS.  Tail pieces are loaded whole (a slab row is a multiple of 8 ids wide) and masked to zeros.
+    const int64_t tbase = tbase_tile;
+    if (tid < kPackTile) s_p[tid] = (int)((start - tbase) >> 3);
+    __syncthreads();
+    const int total_p = (int)(tile_sum >> 3);
+    const int64_t row0 = (int64_t)tile * kPackTile;
+    const int nrows = (int)min((int64_t)kPackTile, a.rows - row0);
+    for (int j0 = tid; j0 < total_p; j0 += 256 * kPackU) {
+      uint4 lo[kPackU], hi[kPackU];
+      int cnt[kPackU];
+#pragma unroll
+      for (int u = 0; u < kPackU; ++u) {
+        const int j = j0 + u * 256;
+        cnt[u] = 0;
+        if (j < total_p) {
+          int b0 = 0, b1 = nrows - 1;                    // the last row whose pieces start at or before j (empty rows share a start)
+          while (b0 < b1) { const int mid = (b0 + b1 + 1) >> 1; if (s_p[mid] <= j) b0 = mid; else b1 = mid - 1; }
+          const int q = j - s_p[b0];
+          const int64_t st = s_start[b0];
+          if (st + s_n[b0] > a.capacity) { over = true; }
+          else {
+            cnt[u] = min(8, s_n[b0] - 8 * q);
+            const S *src = reinterpret_cast<const S *>(a.ids) + (row0 + b0) * (int64_t)a.ld + 8 * q;
+            lo[u] = *reinterpret_cast<const uint4 *>(src);
+            if (sizeof(S) == 4) hi[u] = *reinterpret_cast<const uint4 *>(src + 4);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kPackU; ++u) {
+        if (cnt[u] <= 0) continue;
+        const int c = cnt[u];
+        uint32_t t[8];
+        if (sizeof(S) == 4) {
+          t[0] = lo[u].x; t[1] = lo[u].y; t[2] = lo[u].z; t[3] = lo[u].w; t[4] = hi[u].x; t[5] = hi[u].y; t[6] = hi[u].z; t[7] = hi[u].w;
+        } else {
+          t[0] = lo[u].x & 0xFFFFu; t[1] = lo[u].x >> 16; t[2] = lo[u].y & 0xFFFFu; t[3] = lo[u].y >> 16;
+          t[4] = lo[u].z & 0xFFFFu; t[5] = lo[u].z >> 16; t[6] = lo[u].w & 0xFFFFu; t[7] = lo[u].w >> 16;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = k < c ? t[k] : 0u;
+        if (sizeof(S) == 4) wide |= t[0] | t[1] | t[2] | t[3] | t[4] | t[5] | t[6] | t[7];
+        E *dst = reinterpret_cast<E *>(a.packed) + tbase + 8 * (int64_t)(j0 + u * 256);
+        if (sizeof(E) == 2) {
+          *reinterpret_cast<uint4 *>(dst) = make_uint4((t[0] & 0xFFFFu) | (t[1] << 16), (t[2] & 0xFFFFu) | (t[3] << 16),
+                                                       (t[4] & 0xFFFFu) | (t[5] << 16), (t[6] & 0xFFFFu) | (t[7] << 16));
+        } else if (sizeof(E) == 4) {
+          *reinterpret_cast<uint4 *>(dst) = make_uint4(t[0], t[1], t[2], t[3]);
+          *reinterpret_cast<uint4 *>(dst + 4) = make_uint4(t[4], t[5], t[6], t[7]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) {
+            const int64_t a0 = sizeof(S) == 4 ? (int64_t)(int32_t)t[k] : (int64_t)t[k], a1 = sizeof(S) == 4 ? (int64_t)(int32_t)t[k + 1] : (int64_t)t[k + 1];
+            *reinterpret_cast<longlong2 *>(dst + k) = longlong2{a0, a1};
+          }
+        }
+      }
+    }
+    if (over) atomicOr(a.status, 2);
+  } else {
+    __syncthreads();
+    const int tpr = 1 << a.tpr_shift, sub = tid & (tpr - 1), rpp = 256 >> a.tpr_shift;
+    for (int p = tid >> a.tpr_shift; p < kPackTile; p += rpp) {
+      const int64_t rr = (int64_t)tile * kPackTile + p;
+      if (rr >= a.rows) break;
+      const int nn = s_n[p];
+      const int64_t st = s_start[p];
+      if (st + nn > a.capacity) { over = true; continue; }
+      wide |= copy_row_pieces<S, E>(reinterpret_cast<const S *>(a.ids) + rr * (int64_t)a.ld, reinterpret_cast<E *>(a.packed) + st, nn, sub, tpr);
+    }
+    if (over && sub == 0) atomicOr(a.status, 2);
+  }
+  if (sizeof(E) == 2 && sizeof(S) == 4 && (wide & 0xFFFF0000u)) atomicOr(a.status, 1);
+  __syncthreads();      // the tile's LDS tables are free again
+  }
 }
 
 // Never reads beyond what the row's owner wrote: a row whose ids would end past its segment (segment_stride: a rank
 // whose rows did not fit the caller-given capacity skipped them, gtok_pack_rows status bit 1, while the gathered lengths
 // still carry them) or past the buffer (`capacity` elements, 0 = unknown) comes out as all pad and raises status bit 1.
-template <typename E>
+// O: the slab's id type - int32_t (the documented slab) or uint16_t (gtok_unpack_rows_u16: the 16-bit slab GTOK_SENT_U16 writes,
+// half the bytes of the re-padding pass that ends every compact all-gather)
+template <typename E, typename O>
 __global__ void __launch_bounds__(256) unpack_rows_kernel(const RowsArgs a) {
   const int tpr = 1 << a.tpr_shift, sub = (int)threadIdx.x & (tpr - 1);
   const int64_t r = (int64_t)blockIdx.x * (256 >> a.tpr_shift) + ((int)threadIdx.x >> a.tpr_shift);
@@ -206,32 +394,37 @@ __global__ void __launch_bounds__(256) unpack_rows_kernel(const RowsArgs a) {
     if (sub == 0 && n > 0 && a.status) atomicOr(a.status, 2);
     n = 0;
   }
-  int32_t *__restrict__ row = a.out_ids + r * (int64_t)a.ld;
+  O *__restrict__ row = reinterpret_cast<O *>(a.out_ids) + r * (int64_t)a.ld;
   const E *__restrict__ src = reinterpret_cast<const E *>(a.packed) + (fits ? start : 0);
   const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
   const int pad = a.pad_id;
   for (int i = sub * 8; i < a.ld; i += tpr * 8) {
     if (vec && i + 8 <= a.ld) {
-      int4 lo = make_int4(pad, pad, pad, pad), hi = lo;
+      int32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = pad;
       if (i + 8 <= n) {
         if (sizeof(E) == 2) {
           const uint4 p = *reinterpret_cast<const uint4 *>(src + i);
-          lo = make_int4((int)(p.x & 0xFFFFu), (int)(p.x >> 16), (int)(p.y & 0xFFFFu), (int)(p.y >> 16));
-          hi = make_int4((int)(p.z & 0xFFFFu), (int)(p.z >> 16), (int)(p.w & 0xFFFFu), (int)(p.w >> 16));
+          v[0] = (int)(p.x & 0xFFFFu); v[1] = (int)(p.x >> 16); v[2] = (int)(p.y & 0xFFFFu); v[3] = (int)(p.y >> 16);
+          v[4] = (int)(p.z & 0xFFFFu); v[5] = (int)(p.z >> 16); v[6] = (int)(p.w & 0xFFFFu); v[7] = (int)(p.w >> 16);
         } else {
-          lo = *reinterpret_cast<const int4 *>(src + i);
-          hi = *reinterpret_cast<const int4 *>(src + i + 4);
+          const int4 lo = *reinterpret_cast<const int4 *>(src + i), hi = *reinterpret_cast<const int4 *>(src + i + 4);
+          v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
         }
       } else if (i < n) {
-        int32_t v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = i + k < n ? (int32_t)src[i + k] : pad;
-        lo = make_int4(v[0], v[1], v[2], v[3]); hi = make_int4(v[4], v[5], v[6], v[7]);
       }
-      *reinterpret_cast<int4 *>(row + i) = lo;
-      *reinterpret_cast<int4 *>(row + i + 4) = hi;
+      if (sizeof(O) == 4) {
+        *reinterpret_cast<int4 *>(row + i) = make_int4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<int4 *>(row + i + 4) = make_int4(v[4], v[5], v[6], v[7]);
+      } else {
+        auto pk = [](int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); };
+        *reinterpret_cast<uint4 *>(row + i) = make_uint4(pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7]));
+      }
     } else {
-      for (int k = i; k < a.ld && k < i + 8; ++k) row[k] = k < n ? (int32_t)src[k] : pad;
+      for (int k = i; k < a.ld && k < i + 8; ++k) row[k] = (O)(k < n ? (int32_t)src[k] : pad);
     }
   }
 }
@@ -405,7 +598,7 @@ extern "C" int gtok_row_offsets(const int32_t *len, int64_t num_rows, int32_t ld
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 
-static int rows_launch(bool pack, const void *ids, int src_bytes, int32_t *out_ids, int32_t ld, const int32_t *len, int64_t num_rows,
+static int rows_launch(bool pack, const void *ids, int src_bytes, void *out_ids, int out_bytes, int32_t ld, const int32_t *len, int64_t num_rows,
                        const int64_t *row_ptr, int32_t segment_rows, int64_t segment_stride, int32_t elem_bytes,
                        void *packed, int64_t capacity, int32_t pad_id, int32_t *status, void *stream) {
   DeviceScope device_scope((hipStream_t)stream);
@@ -431,33 +624,97 @@ static int rows_launch(bool pack, const void *ids, int src_bytes, int32_t *out_i
     if (elem_bytes == 2) hipLaunchKernelGGL((pack_rows_kernel<int32_t, uint16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((pack_rows_kernel<int32_t, int32_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
   } else {
-    if (elem_bytes == 2) hipLaunchKernelGGL(unpack_rows_kernel<uint16_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(unpack_rows_kernel<int32_t>, dim3((unsigned)nb), dim3(256), 0, s, a);
+    if (out_bytes == 2) {
+      if (elem_bytes == 2) hipLaunchKernelGGL((unpack_rows_kernel<uint16_t, uint16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((unpack_rows_kernel<int32_t, uint16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    } else {
+      if (elem_bytes == 2) hipLaunchKernelGGL((unpack_rows_kernel<uint16_t, int32_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((unpack_rows_kernel<int32_t, int32_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    }
   }
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_pack_rows_scan(const void *ids, int32_t src_bytes, int32_t ld, const int32_t *len, int64_t num_rows, int32_t align,
+                                   int32_t elem_bytes, void *packed, int64_t capacity, int64_t *row_ptr, int32_t *status, void *stream) {
+  DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  const bool eb_ok = elem_bytes == 2 || elem_bytes == 4 || (src_bytes == 2 && elem_bytes == 8);
+  if (num_rows < 0 || ld <= 0 || (src_bytes != 2 && src_bytes != 4) || !eb_ok || align < 1 || (align & (align - 1)) || capacity < 0 || !row_ptr)
+    return GTOK_E_INVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (!status || (num_rows > 0 && (!ids || !len || !packed))) return GTOK_E_INVAL;
+  const int ncu = device_cu_count(device_scope.dev);
+  int tile_rows = 256;      // (smaller tiles were measured slower at every size: more tickets, more look-back)
+  if (const char *cs = std::getenv("GTOK_PACK_TILE")) { const int c = std::atoi(cs); if (c == 64 || c == 128 || c == 256) tile_rows = c; }   // tuning knob
+  const int64_t tiles = (num_rows + tile_rows - 1) / tile_rows;
+  if (tiles > 0x7FFFFFFF) return GTOK_E_TOO_LARGE;
+  hipLaunchKernelGGL(pack_scan_init_kernel, dim3((unsigned)(tiles > 0 ? (tiles + 255) / 256 : 1)), dim3(256), 0, s, row_ptr, num_rows, (int)tiles, tile_rows, status);
+  if (num_rows == 0) return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+  QueueSlot slot = take_queue_slot(device_scope.dev, s);       // the tile ticket: a counter of this launch's own (zero between launches)
+  if (!slot.counters) return slot.graph_pool_empty ? GTOK_E_GRAPH_SLOTS : GTOK_E_LAUNCH;
+  PackScanArgs a;
+  a.ids = ids; a.len = len; a.row_ptr = row_ptr; a.packed = packed; a.status = status; a.ticket = slot.counters;
+  a.rows = num_rows; a.capacity = capacity; a.ld = ld; a.align_mask = align - 1; a.tiles = (int)tiles;
+  // (general path) threads per row: enough for half the widest row's 8-id pieces in one pass (rows are ~half as long as the slab is wide)
+  int sh = tpr_shift_for(ld);
+  if (sh > 0) --sh;
+  a.tpr_shift = sh;
+  a.fast = align == 8 && ((int64_t)ld * src_bytes) % 16 == 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(ids) & 15u) == 0 &&
+           (reinterpret_cast<uintptr_t>(packed) & 15u) == 0;
+  a.chunk = (int)((tiles + 8ll * ncu - 1) / (8ll * ncu));
+  if (a.chunk < 1) a.chunk = 1;
+  if (a.chunk > kPackChunkMax) a.chunk = kPackChunkMax;
+  if (const char *cs = std::getenv("GTOK_PACK_CHUNK")) { const int c = std::atoi(cs); if (c >= 1 && c <= kPackChunkMax) a.chunk = c; }   // tuning knob
+  const dim3 grid((unsigned)((tiles + a.chunk - 1) / a.chunk)), block(256);
+#define GTOK_PACK_SCAN(S_, E_)                                                                              \
+  do {                                                                                                      \
+    if (tile_rows == 256) hipLaunchKernelGGL((pack_scan_kernel<S_, E_, 256>), grid, block, 0, s, a);        \
+    else if (tile_rows == 128) hipLaunchKernelGGL((pack_scan_kernel<S_, E_, 128>), grid, block, 0, s, a);   \
+    else hipLaunchKernelGGL((pack_scan_kernel<S_, E_, 64>), grid, block, 0, s, a);                          \
+  } while (0)
+  if (src_bytes == 2) {
+    if (elem_bytes == 2) GTOK_PACK_SCAN(uint16_t, uint16_t);
+    else if (elem_bytes == 4) GTOK_PACK_SCAN(uint16_t, int32_t);
+    else GTOK_PACK_SCAN(uint16_t, int64_t);
+  } else {
+    if (elem_bytes == 2) GTOK_PACK_SCAN(int32_t, uint16_t);
+    else GTOK_PACK_SCAN(int32_t, int32_t);
+  }
+#undef GTOK_PACK_SCAN
+  mark_queue_slot(slot, s);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 
 extern "C" int gtok_pack_rows(const int32_t *ids, int32_t ld, const int32_t *len, int64_t num_rows, const int64_t *row_ptr,
                               int32_t elem_bytes, void *packed, int64_t capacity, int32_t *status, void *stream) {
-  return rows_launch(true, ids, 4, nullptr, ld, len, num_rows, row_ptr, 0, 0, elem_bytes, packed, capacity, 0, status, stream);
+  return rows_launch(true, ids, 4, nullptr, 4, ld, len, num_rows, row_ptr, 0, 0, elem_bytes, packed, capacity, 0, status, stream);
 }
 
 extern "C" int gtok_pack_rows_u16(const uint16_t *ids16, int32_t ld, const int32_t *len, int64_t num_rows, const int64_t *row_ptr,
                                   int32_t elem_bytes, void *packed, int64_t capacity, int32_t *status, void *stream) {
-  return rows_launch(true, ids16, 2, nullptr, ld, len, num_rows, row_ptr, 0, 0, elem_bytes, packed, capacity, 0, status, stream);
+  return rows_launch(true, ids16, 2, nullptr, 4, ld, len, num_rows, row_ptr, 0, 0, elem_bytes, packed, capacity, 0, status, stream);
 }
 
 extern "C" int gtok_unpack_rows(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
                                 int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int32_t pad_id,
                                 int32_t *out_ids, int32_t ld, void *stream) {
-  return rows_launch(false, nullptr, 4, out_ids, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
+  return rows_launch(false, nullptr, 4, out_ids, 4, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
                      const_cast<void *>(packed), 0, pad_id, nullptr, stream);
 }
 
 extern "C" int gtok_unpack_rows_checked(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
                                         int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int64_t packed_elems,
                                         int32_t pad_id, int32_t *out_ids, int32_t ld, int32_t *status, void *stream) {
-  return rows_launch(false, nullptr, 4, out_ids, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
+  return rows_launch(false, nullptr, 4, out_ids, 4, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
+                     const_cast<void *>(packed), packed_elems, pad_id, status, stream);
+}
+
+extern "C" int gtok_unpack_rows_u16(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
+                                    int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int64_t packed_elems,
+                                    int32_t pad_id, uint16_t *out_ids16, int32_t ld, int32_t *status, void *stream) {
+  if (pad_id < 0 || pad_id > 65535) return GTOK_E_INVAL;
+  return rows_launch(false, nullptr, 4, out_ids16, 2, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
                      const_cast<void *>(packed), packed_elems, pad_id, status, stream);
 }
 

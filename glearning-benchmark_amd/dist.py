@@ -44,8 +44,8 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     Ranks hold blocks from block_bounds(); the last blocks may be short, so every rank pads its
     block to ceil(G/P) rows first (one fixed-size all_gather_into_tensor, no size exchange).
     force: issue the collective even in a one-rank group (rehearsal of the N>1 path on a one-GPU box).
-    ids: the int32 slab, or the 16-bit slab of ops.sent(..., u16=True) (int16 storage; the padded exchange then moves half
-    the bytes and returns the 16-bit slab, the compact one packs it directly and returns the int32 slab as always).
+    ids: the int32 slab, or the 16-bit slab of ops.sent(..., u16=True) (int16 storage; both exchanges then return the 16-bit
+    slab: the padded one moves half the bytes, the compact one packs the rows as they are and re-pads at 16 bits).
 
     compact=True moves the PACKED form over the links instead of the padded slab (include/gtok.h, "packed rows"): every
     rank packs its rows back to back at `elem_bytes` (2: every SENT / IBTT id fits 16 bits; 4 otherwise) per id
@@ -81,12 +81,14 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     if rows_impl is None:
         from . import ops as rows_impl
     pack = rows_impl.pack_rows_u16 if ids.dtype == torch.int16 else rows_impl.pack_rows
-    row_ptr = rows_impl.row_offsets(ln, ld)
     caller_bound = capacity is not None
+    row_ptr = None
     if not caller_bound:
+        row_ptr = rows_impl.row_offsets(ln, ld)
         capacity = all_reduce_max_int(int(row_ptr[-1]), ids.device)
     capacity = max(8, -(-int(capacity) // 8) * 8)           # keeps every rank's segment 16-byte aligned
-    # (a caller-given bound - e.g. last epoch's size plus a margin - means no size exchange and no host round trip at all)
+    # (a caller-given bound - e.g. last epoch's size plus a margin - means no size exchange, no host round trip at all, and
+    # offsets + packing in ONE pass: gtok_pack_rows_scan)
     packed, _, status = pack(ids, ln, row_ptr, elem_bytes, capacity=capacity, check_status=False)
     all_packed = torch.empty(world * capacity, dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(all_packed.view(torch.uint8), packed[:capacity].contiguous().view(torch.uint8))
@@ -97,7 +99,10 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     all_ln = all_ext[:, :per].reshape(-1).contiguous()
     all_ptr = rows_impl.row_offsets(all_ln, ld)
     ustatus = torch.zeros(1, dtype=torch.int32, device=ln.device)
-    all_ids = rows_impl.unpack_rows(all_packed, all_ptr, all_ln, ld, pad_id, segment_rows=per, segment_stride=capacity, status=ustatus)
+    # 16-bit rows in, 16-bit slab out (as the padded exchange does): the re-padding pass writes half the bytes
+    u16 = ids.dtype == torch.int16
+    all_ids = rows_impl.unpack_rows(all_packed, all_ptr, all_ln, ld, pad_id, segment_rows=per, segment_stride=capacity, status=ustatus,
+                                    **({"u16": True} if u16 else {}))
     verdict = torch.maximum(all_ext[:, per].max().to(torch.int32).reshape(1), ustatus)
     if not caller_bound:
         st = int(verdict.item())

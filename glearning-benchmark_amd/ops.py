@@ -424,6 +424,37 @@ def row_offsets(ln: torch.Tensor, ld: int, align: int = ROW_ALIGN) -> torch.Tens
     return ptr
 
 
+def _pack_verdict(packed, row_ptr, status, cap, what):
+    st = int(status.item())
+    if st & 1:
+        raise _lib.GtokError(f"{what}: an id does not fit 16 bits; pack with elem_bytes=4")
+    if st & 2:
+        raise _lib.GtokError(f"{what}: capacity {cap} is too small for these rows")
+    return packed, row_ptr
+
+
+def pack_rows_scan(ids: torch.Tensor, ln: torch.Tensor, elem_bytes: int, capacity: int, align: int = ROW_ALIGN):
+    """row_offsets + pack_rows / pack_rows_u16 in ONE pass (gtok_pack_rows_scan): for callers that know a capacity before
+    they know the sizes.  ids: the int32 slab or the 16-bit slab (int16 storage).  Returns (packed, row_ptr, status) - nothing
+    waits for the host (status bit 0: an id needs more than 16 bits, bit 1: rows that did not fit `capacity` were skipped)."""
+    _need_gpu(ids, "pack_rows_scan")
+    if ids.dtype not in (torch.int32, torch.int16) or ids.dim() != 2 or not ids.is_contiguous() or ln.dtype != torch.int32 or not ln.is_contiguous():
+        raise ValueError("pack_rows_scan expects a contiguous int32 / int16 [rows, ld] slab and contiguous int32 lengths")
+    src_bytes = ids.element_size()
+    if elem_bytes not in ((2, 4, 8) if src_bytes == 2 else (2, 4)):
+        raise ValueError("elem_bytes must be 2 or 4 (8 also from a 16-bit slab)")
+    dev, (rows, ld) = ids.device, ids.shape
+    if int(ln.numel()) != rows:
+        raise ValueError("pack_rows_scan: one length per row")
+    cap = int(capacity)
+    packed = torch.empty(max(cap, 1), dtype={2: torch.int16, 4: torch.int32, 8: torch.int64}[elem_bytes], device=dev)
+    row_ptr = torch.empty(rows + 1, dtype=torch.int64, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)          # (set by the call)
+    check(lib().gtok_pack_rows_scan(ids.data_ptr(), src_bytes, ld, ln.data_ptr(), rows, int(align), elem_bytes, packed.data_ptr(), cap,
+                                    row_ptr.data_ptr(), status.data_ptr(), _stream(dev)), "gtok_pack_rows_scan")
+    return packed, row_ptr, status
+
+
 def pack_rows(ids: torch.Tensor, ln: torch.Tensor, row_ptr: Optional[torch.Tensor] = None, elem_bytes: int = 2,
               capacity: Optional[int] = None, align: int = ROW_ALIGN, check_status: bool = True):
     """[rows, ld] int32 slab + lengths -> (packed, row_ptr): row r's ids back to back from packed[row_ptr[r]], int16
@@ -437,6 +468,9 @@ def pack_rows(ids: torch.Tensor, ln: torch.Tensor, row_ptr: Optional[torch.Tenso
     dev, (rows, ld) = ids.device, ids.shape
     if int(ln.numel()) != rows:
         raise ValueError("pack_rows: one length per row")
+    if row_ptr is None and capacity is not None and _lib.library_version() >= 5:       # sizes not needed first: one pass
+        packed, row_ptr, status = pack_rows_scan(ids, ln.contiguous(), elem_bytes, capacity, align)
+        return (packed, row_ptr, status) if not check_status else _pack_verdict(packed, row_ptr, status, int(capacity), "pack_rows")
     if row_ptr is None:
         row_ptr = row_offsets(ln, ld, align)
     cap = int(row_ptr[-1]) if capacity is None else int(capacity)
@@ -467,6 +501,9 @@ def pack_rows_u16(ids16: torch.Tensor, ln: torch.Tensor, row_ptr: Optional[torch
     dev, (rows, ld) = ids16.device, ids16.shape
     if int(ln.numel()) != rows:
         raise ValueError("pack_rows_u16: one length per row")
+    if row_ptr is None and capacity is not None and _lib.library_version() >= 5:       # sizes not needed first: one pass
+        packed, row_ptr, status = pack_rows_scan(ids16, ln.contiguous(), elem_bytes, capacity, align)
+        return (packed, row_ptr, status) if not check_status else _pack_verdict(packed, row_ptr, status, int(capacity), "pack_rows_u16")
     if row_ptr is None:
         row_ptr = row_offsets(ln, ld, align)
     cap = int(row_ptr[-1]) if capacity is None else int(capacity)
@@ -483,21 +520,26 @@ def pack_rows_u16(ids16: torch.Tensor, ln: torch.Tensor, row_ptr: Optional[torch
 
 def unpack_rows(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: torch.Tensor, ld: int, pad_id: int,
                 segment_rows: int = 0, segment_stride: int = 0, out: Optional[torch.Tensor] = None,
-                status: Optional[torch.Tensor] = None) -> torch.Tensor:
+                status: Optional[torch.Tensor] = None, u16: bool = False) -> torch.Tensor:
     """packed rows -> [rows, ld] int32 slab with pad_id behind every row (gtok_unpack_rows_checked).  segment_rows /
     segment_stride: the packed buffer is the concatenation of per-rank buffers (see include/gtok.h).  row_ptr=None: the
     strided form - `packed` is itself a [rows, ld] slab of 16- or 32-bit ids (ops.sent(..., u16=True)), widened in place.
     Rows that would end beyond their segment or the buffer come out as all pad; `status` (int32 [1], zeroed by the
-    caller) gets bit 1 then."""
+    caller) gets bit 1 then.  u16=True (gtok_unpack_rows_u16): the slab holds 16-bit ids (int16 storage, as ops.sent(...,
+    u16=True) writes it) - half the bytes of the pass."""
     _need_gpu(packed, "unpack_rows")
     dev, rows = packed.device, int(ln.numel())
     eb = packed.element_size()
     if eb not in (2, 4):
         raise ValueError("unpack_rows expects int16 or int32 storage")
-    ids = torch.empty((rows, ld), dtype=torch.int32, device=dev) if out is None else out
-    check(lib().gtok_unpack_rows_checked(packed.data_ptr(), eb, None if row_ptr is None else row_ptr.data_ptr(), ln.data_ptr(), rows,
-                                         int(segment_rows), int(segment_stride), int(packed.numel()), int(pad_id), ids.data_ptr(), int(ld),
-                                         None if status is None else status.data_ptr(), _stream(dev)), "gtok_unpack_rows")
+    want = torch.int16 if u16 else torch.int32
+    ids = torch.empty((rows, ld), dtype=want, device=dev) if out is None else out
+    if ids.dtype != want:
+        raise ValueError(f"out must be {want}")
+    fn = lib().gtok_unpack_rows_u16 if u16 else lib().gtok_unpack_rows_checked
+    check(fn(packed.data_ptr(), eb, None if row_ptr is None else row_ptr.data_ptr(), ln.data_ptr(), rows,
+             int(segment_rows), int(segment_stride), int(packed.numel()), int(pad_id), ids.data_ptr(), int(ld),
+             None if status is None else status.data_ptr(), _stream(dev)), "gtok_unpack_rows")
     return ids
 
 

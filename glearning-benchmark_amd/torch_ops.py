@@ -394,6 +394,18 @@ def _(ids16, lens, row_ptr, elem_bytes, capacity):
             ids16.new_empty((1,), dtype=torch.int32))
 
 
+@torch.library.custom_op("gtok::pack_rows_scan", mutates_args=(), device_types="cuda")
+def pack_rows_scan(ids: Tensor, lens: Tensor, elem_bytes: int, capacity: int, align: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """gtok_pack_rows_scan: (packed [capacity], row_ptr int64 [rows + 1], status int32 [1]) from an int32 or 16-bit slab in one pass."""
+    return _ops.pack_rows_scan(ids, lens, elem_bytes, capacity, align)
+
+
+@pack_rows_scan.register_fake
+def _(ids, lens, elem_bytes, capacity, align):
+    return (ids.new_empty((max(capacity, 1),), dtype={2: torch.int16, 4: torch.int32, 8: torch.int64}[elem_bytes]),
+            ids.new_empty((lens.shape[0] + 1,), dtype=torch.int64), ids.new_empty((1,), dtype=torch.int32))
+
+
 @torch.library.custom_op("gtok::unpack_rows", mutates_args=(), device_types="cuda")
 def unpack_rows(packed: Tensor, row_ptr: Optional[Tensor], lens: Tensor, ld: int, pad_id: int, segment_rows: int,
                 segment_stride: int) -> Tensor:

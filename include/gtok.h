@@ -23,7 +23,7 @@
  *                      (gather rows of a batch, pad to the batch max, bool mask)
  *   gtok_parse_graph_text  graph_token_dataset_autograph.py:14-158 (text -> edges, query, label)
  *   gtok_find_token    the `<q>` search of trainer/train_ibtt.py:88-103 on a collated batch
- *   gtok_row_offsets / gtok_pack_rows / gtok_pack_rows_u16 / gtok_unpack_rows / gtok_unpack_rows_checked / gtok_collate_packed
+ *   gtok_row_offsets / gtok_pack_rows / gtok_pack_rows_u16 / gtok_pack_rows_scan / gtok_unpack_rows / gtok_unpack_rows_checked / gtok_unpack_rows_u16 / gtok_collate_packed
  *                      (no reference counterpart) the packed form of a token slab - rows back to back, 16 or 32
  *                      bits per id - for the copies that leave the GPU: the all-gather that reassembles the rows of
  *                      every rank in dataset order (val/test loaders, trainer/train_agtt.py:602-607) and the D2H
@@ -398,6 +398,21 @@ int gtok_unpack_rows_checked(const void *packed, int32_t elem_bytes, const int64
                              int32_t pad_id, int32_t *out_ids, int32_t ld, int32_t *status, void *stream);
 int gtok_pack_rows_u16(const uint16_t *ids16, int32_t ld, const int32_t *len, int64_t num_rows, const int64_t *row_ptr,
                        int32_t elem_bytes, void *packed, int64_t capacity, int32_t *status, void *stream);
+/* gtok_unpack_rows_checked into a slab of 16-BIT ids (ABI v5; what GTOK_SENT_U16 writes and gtok_collate_packed reads in
+ * place): the re-padding pass that ends a compact all-gather of 16-bit rows writes half the bytes.  ids keep their low 16
+ * bits; 0 <= pad_id <= 65535.                                                                                             */
+int gtok_unpack_rows_u16(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
+                         int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int64_t packed_elems,
+                         int32_t pad_id, uint16_t *out_ids16, int32_t ld, int32_t *status, void *stream);
+/* gtok_row_offsets + gtok_pack_rows (src_bytes 4: an int32 slab) / gtok_pack_rows_u16 (src_bytes 2: a GTOK_SENT_U16 slab) in
+ * ONE pass (ABI v5): row_ptr (int64 [num_rows + 1], OUT) and the packed rows are written by the same kernel - tiles of 256
+ * rows, each tile learning its start from the tiles before it (single-pass prefix sum, the tile's closing row_ptr slot is its
+ * status word) - for callers that know a capacity before they know the sizes (the compact all-gather with a caller-given
+ * bound, a per-epoch D2H staging buffer): the lengths are read once, the ids once, and two launches replace four.  Same
+ * results, same status bits - except that status is SET by this call, not accumulated into (bit 1 = rows that did not
+ * fit `capacity` were skipped).                                                                                              */
+int gtok_pack_rows_scan(const void *ids, int32_t src_bytes, int32_t ld, const int32_t *len, int64_t num_rows, int32_t align,
+                        int32_t elem_bytes, void *packed, int64_t capacity, int64_t *row_ptr, int32_t *status, void *stream);
 
 /* Rows of ids -> TEXT: the strings ZINCTokenizationDataset.__getitem__ returns (zinc_dataset_indexbase.py:143-227: the
  * trainer builds its vocab from them, trainer/train_ibtt.py:229-235, :361-372) rendered for a whole split at once.  Row

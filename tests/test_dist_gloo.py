@@ -27,6 +27,8 @@ class _OracleRows:
     @staticmethod
     def pack_rows(ids, ln, row_ptr, elem_bytes=2, capacity=None, check_status=True):
         packed, ptr, st = orc.pack_rows(ids.numpy(), ln.numpy(), ids.shape[1], elem_bytes, capacity=capacity, fill=0x7ABC, with_status=True)
+        if row_ptr is None:               # a caller-given capacity: offsets and packing are one pass (gtok_pack_rows_scan)
+            row_ptr = torch.from_numpy(ptr)
         assert np.array_equal(ptr, row_ptr.numpy())
         if check_status and st:
             raise ValueError(f"pack status {st}")
@@ -36,13 +38,13 @@ class _OracleRows:
     pack_rows_u16 = pack_rows           # (the oracle's statement takes either slab)
 
     @staticmethod
-    def unpack_rows(packed, row_ptr, ln, ld, pad_id, segment_rows=0, segment_stride=0, status=None):
+    def unpack_rows(packed, row_ptr, ln, ld, pad_id, segment_rows=0, segment_stride=0, status=None, u16=False):
         p = packed.numpy()
         p = p.view(np.uint16) if p.dtype == np.int16 else p
         out, st = orc.unpack_rows(p, None if row_ptr is None else row_ptr.numpy(), ln.numpy(), ld, pad_id, segment_rows, segment_stride, with_status=True)
         if status is not None:
             status |= st
-        return torch.from_numpy(out)
+        return torch.from_numpy(out.astype(np.uint16).view(np.int16)) if u16 else torch.from_numpy(out)     # (gtok_unpack_rows_u16: a 16-bit slab)
 
 
 def _worker(rank, world, port, G, q):
@@ -74,7 +76,7 @@ def _worker(rank, world, port, G, q):
             i16 = torch.from_numpy(ids.astype(np.uint16).view(np.int16))
             u_ids, u_ln = gtok.dist.gather_tokens(i16, torch.from_numpy(ln), G, 5, compact=True, elem_bytes=eb, rows_impl=_OracleRows)
             p_ids, p_ln = gtok.dist.gather_tokens(i16, torch.from_numpy(ln), G, 5)
-            ok = ok and torch.equal(u_ids, full_ids) and p_ids.dtype == torch.int16 \
+            ok = ok and u_ids.dtype == torch.int16 and p_ids.dtype == torch.int16 and torch.equal(u_ids, p_ids) and torch.equal(u_ln, full_ln) \
                 and np.array_equal(p_ids.numpy().view(np.uint16).astype(np.int32), full_ids.numpy()) and torch.equal(p_ln, full_ln)
         # a caller-given capacity that turns out too small: no rank reads beyond a segment, every rank sees the same verdict,
         # the rows that did not fit come out as pad, the others are right

@@ -63,6 +63,71 @@ def test_pack_rows_flags_wide_ids_and_small_buffers():
     assert q.tolist() == [0] and gtok.ops.unpack_rows(p, q, e_ln, 16, 5).shape == (0, 16)
 
 
+@pytest.mark.parametrize("rows,ld", [(1, 16), (255, 24), (256, 24), (257, 24), (4097, 48), (100003, 176), (513, 1024), (300, 13), (70000, 8)])
+@pytest.mark.parametrize("align", [8, 1])
+def test_pack_rows_scan_is_row_offsets_plus_pack_in_one_pass(rows, ld, align):
+    """gtok_pack_rows_scan (ABI v5): same row_ptr and same packed rows as gtok_row_offsets + gtok_pack_rows(_u16), from the
+    int32 slab and from the 16-bit one, at every packed width; tile boundaries (256 rows), lengths outside [0, ld]."""
+    ids, ln = _slab(rows, ld, seed=rows * 3 + ld, long_rows=True)
+    ln[::11] = -3                                                   # negative lengths count as empty rows
+    d_ids, d_ln = torch.from_numpy(ids).to(DEV), torch.from_numpy(ln).to(DEV)
+    d_ids16 = d_ids.to(torch.int16)
+    ptr = gtok.ops.row_offsets(d_ln, ld, align)
+    want_ptr = orc.row_offsets(ln, ld, align)
+    assert np.array_equal(ptr.cpu().numpy(), want_ptr)
+    total, n = int(want_ptr[-1]), np.clip(ln, 0, ld)
+    for src, ebs in ((d_ids, (2, 4)), (d_ids16, (2, 4, 8))):
+        for eb in ebs:
+            cap = total + 64
+            packed, p2, st = gtok.ops.pack_rows_scan(src, d_ln, eb, cap, align)
+            assert int(st.item()) == 0 and np.array_equal(p2.cpu().numpy(), want_ptr), (src.dtype, eb)
+            two = (gtok.ops.pack_rows_u16 if src.dtype == torch.int16 else gtok.ops.pack_rows)(src, d_ln, ptr, elem_bytes=eb, capacity=cap, check_status=False)[0]
+            a, b = packed.cpu().numpy(), two.cpu().numpy()
+            a, b = (a.view(np.uint16), b.view(np.uint16)) if eb == 2 else (a, b)
+            idx = np.concatenate([np.arange(want_ptr[r], want_ptr[r] + n[r]) for r in range(0, rows, max(1, rows // 4000))] + [np.zeros(0, np.int64)]).astype(np.int64)
+            assert np.array_equal(a[idx], b[idx]), (src.dtype, eb)
+            if rows <= 5000:                                        # every row, against the slab itself
+                for r in range(rows):
+                    assert np.array_equal(a[want_ptr[r]:want_ptr[r] + n[r]].astype(np.int64), ids[r, :n[r]]), (r, eb)
+    # through the public wrappers: row_ptr=None + a capacity = the one-pass route
+    packed, p3 = gtok.ops.pack_rows_u16(d_ids16, d_ln, None, elem_bytes=2, capacity=total + 8, align=align)
+    assert np.array_equal(p3.cpu().numpy(), want_ptr)
+    back = gtok.ops.unpack_rows(packed, p3, d_ln, ld, pad_id=5)
+    assert np.array_equal(back.cpu().numpy(), np.where(np.arange(ld)[None, :] < n[:, None], ids, 5))
+
+
+def test_pack_rows_scan_status_bits_and_repeated_launches():
+    ids, ln = _slab(3000, 64, seed=3)
+    ids[1234, 0] = 70000
+    ln[1234] = max(ln[1234], 1)
+    d_ids, d_ln = torch.from_numpy(ids).to(DEV), torch.from_numpy(ln).to(DEV)
+    total = int(orc.row_offsets(ln, 64, 8)[-1])
+    assert int(gtok.ops.pack_rows_scan(d_ids, d_ln, 2, total, 8)[2].item()) == 1          # an id beyond 16 bits
+    assert int(gtok.ops.pack_rows_scan(d_ids, d_ln, 4, total, 8)[2].item()) == 0
+    packed, ptr, st = gtok.ops.pack_rows_scan(d_ids, d_ln, 4, total - 8, 8)                # the last rows do not fit: skipped, flagged
+    assert int(st.item()) == 2 and np.array_equal(ptr.cpu().numpy(), orc.row_offsets(ln, 64, 8))
+    with pytest.raises(gtok.GtokError, match="capacity"):
+        gtok.ops.pack_rows(d_ids, d_ln, None, elem_bytes=4, capacity=total - 8)
+    # the tile ticket is re-armed by every launch: 300 launches back to back (beyond the ring of 256 counter blocks), two streams
+    want = orc.row_offsets(ln, 64, 8)
+    side = torch.cuda.Stream(device=DEV)
+    outs = []
+    for k in range(300):
+        if k % 3 == 0:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                outs.append(gtok.ops.pack_rows_scan(d_ids, d_ln, 4, total, 8))
+        else:
+            outs.append(gtok.ops.pack_rows_scan(d_ids, d_ln, 4, total, 8))
+    torch.cuda.synchronize()
+    ref = outs[0][0].cpu().numpy()
+    for packed, ptr, st in outs[::17]:
+        assert np.array_equal(ptr.cpu().numpy(), want) and int(st.item()) == 0
+    e_ids, e_ln = torch.empty((0, 16), dtype=torch.int32, device=DEV), torch.empty(0, dtype=torch.int32, device=DEV)
+    p, q, st = gtok.ops.pack_rows_scan(e_ids, e_ln, 2, 0, 8)
+    assert q.tolist() == [0] and int(st.item()) == 0
+
+
 def test_collate_packed_equals_collate_on_the_slab():
     d = gtok.synth.zinc_like(3000, seed=12)
     batch, coo = both(d)
@@ -127,6 +192,13 @@ def test_compact_gather_over_rccl_equals_padded_gather():
         # a caller-given capacity skips the size exchange
         k_ids, _ = gtok.dist.gather_tokens(ids, ln, 30001, 5, force=True, compact=True, capacity=sc["capacity"] + 64)
         assert torch.equal(k_ids, p_ids)
+        # 16-bit rows in (two epochs in one launch), 16-bit slab out of both exchanges: packed in one pass, re-padded at 16 bits
+        i16, l16 = gtok.ops.sent(batch.to(DEV), 37, 1024, 21, 3, ld=ld, u16=True, epochs=2, **kw)
+        i16, l16 = i16.reshape(-1, ld), l16.reshape(-1)
+        u_ids, u_ln = gtok.dist.gather_tokens(i16, l16, 2 * 30001, 5, force=True, compact=True, capacity=int(2.05 * sc["capacity"]))
+        q_ids, q_ln = gtok.dist.gather_tokens(i16, l16, 2 * 30001, 5, force=True)
+        assert u_ids.dtype == torch.int16 and torch.equal(u_ids, q_ids) and torch.equal(u_ln, q_ln) and u_ids.data_ptr() != i16.data_ptr()
+        assert np.array_equal(u_ids[:30001].cpu().numpy().view(np.uint16).astype(np.int32), ref)
     finally:
         tdist.destroy_process_group()
 
