@@ -124,21 +124,25 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
             : (p4 ? (KF)sent_blane_kernel<4, 4, U> : (KF)sent_blane_kernel<4, 8, U>))
     KF kern = u16 ? GTOK_BLANE_K(true) : GTOK_BLANE_K(false);
 #undef GTOK_BLANE_K
-    const size_t lds = (size_t)4608 * W;   // 18 W dwords per lane (gtok_sent_blane.hpp)
-    int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) != hipSuccess) return GTOK_E_NO_DEVICE;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    // one workgroup per CU: 8 waves at W = 4 (144 KB of LDS, 2 per SIMD: the register file holds no more), else 16
+    const size_t lds = (size_t)5120 * W;   // 20 W dwords per lane (gtok_sent_blane.hpp)
+    const int dev = device_scope.dev, ncu = device_cu_count(dev);
+    // one workgroup per CU: 8 waves at W = 4 (160 KB of LDS, 2 per SIMD: the register file holds no more), else 16
     int nw = W == 4 ? 8 : 16;
     if (const char *cs = std::getenv("GTOK_BLANE_WAVES")) { const int c = std::atoi(cs); if (c == 4 || c == 8 || c == 16) nw = c < nw ? c : nw; }   // tuning knob
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!raise_lds_limit(reinterpret_cast<const void *>(kern), dev)) return GTOK_E_LAUNCH;
     const int vun = a.units * K;
     const int nb = vun < ncu ? vun : ncu;   // every CU, also when some of its waves stay without a unit
+    if (2 * nb > kSlotInts) return GTOK_E_TOO_LARGE;      // (two ticket words per workgroup in one counter block: 528 CUs)
     // unit-major always: the K walks of a unit fetch the same adjacency rows at about the same time (L2 hits on the one HBM read
     // of a step) - 125 k ER graphs x 8 epochs: 0.356 ms per epoch against 0.404 epoch-major (0.49 for one epoch per launch)
     a.epoch_major = 0;
     if (const char *cs = std::getenv("GTOK_LANE_PAIR_ORDER")) a.epoch_major = cs[0] == 'e';   // tuning knob: unit | epoch
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * nw), lds * nw + 16, (hipStream_t)stream, a);   // (+ the workgroup's ticket counter)
+    // the ticket counters of the pairs beyond the first round: a block of this launch's own, in device memory, zero between launches
+    QueueSlot slot = take_queue_slot(dev, (hipStream_t)stream);
+    if (!slot.counters) return slot.graph_pool_empty ? GTOK_E_GRAPH_SLOTS : GTOK_E_LAUNCH;
+    a.tickets = slot.counters;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * nw), lds * nw, (hipStream_t)stream, a);
+    mark_queue_slot(slot, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
   }
   if (lane_path) {

@@ -33,9 +33,16 @@ struct SentBLaneArgs {
   int prio;    // long units at a higher issue priority than the short ones they share a SIMD with
   int pad_nt;  // padding leaves with non-temporal stores (slabs larger than the memory-side cache: gtok_sent_lane.hpp)
   int epoch_major;   // order of the (unit, epoch) pairs (gtok_sent_lane.hpp)
+  int *tickets;      // 2 ints per workgroup in device memory, zero between launches: [2 b] the ticket of the pairs beyond the first
+                     // round, [2 b + 1] the waves of workgroup b that are through (the last one re-arms both).  Round 5: the LDS is
+                     // full to the last byte (8 x 20 KB at W = 4), the counter moved out; a draw costs ~1 us once per ~400 us unit
 };
 
 struct __attribute__((aligned(16))) U64x2 { uint64_t a, b; };
+#ifndef GTOK_BLANE_CONV
+#define GTOK_BLANE_CONV 4
+#endif
+constexpr int kBlaneConv = GTOK_BLANE_CONV;   // bracket members taken to visit-index space per loop iteration
 
 // U16: the GTOK_SENT_U16 slab - rows of 16-bit ids, the token windows stored as they stand
 template <int W, int P, bool U16>
@@ -44,16 +51,20 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
   constexpr int EV = U16 ? 8 : 4;            // ids per 16-byte store
   out_t *const out_base = reinterpret_cast<out_t *>(a.out);
   // LDS, all of it lane-private and laid out [dword][lane] (bank = lane): 16 W dwords node -> visit index (u8 each),
-  // 2 W dwords bracket members in visit-index space (zero between brackets)
-  // one workgroup per CU (8 waves at W = 4, else 16), each wave with its own 18 W x 256 bytes of the workgroup's LDS;
+  // 2 W dwords bracket members in visit-index space (zero between brackets), 2 W dwords the bracket's members in node space
+  // (staged there so that a lane can fetch ITS next non-empty sub-word with one indexed LDS read: see the bracket loops)
+  // one workgroup per CU (8 waves at W = 4, else 16), each wave with its own 20 W x 256 bytes of the workgroup's LDS;
   // waves never cooperate
   extern __shared__ __align__(16) unsigned char smem_all[];
   const int lane = lane_id(), wave = wave_id();
-  unsigned char *smem = smem_all + (size_t)wave * (18 * W * 256);
-  uint8_t *vx = smem + lane * 4;
-  auto vx_at = [&](int u) __attribute__((always_inline)) -> uint8_t & { return vx[((u & ~3) << 6) + (u & 3)]; };
+  unsigned char *smem = smem_all + (size_t)wave * (20 * W * 256);
+  // (the visit-index table is [node][lane] BYTES: one shift-add per address - the [dword][lane] form of rounds 2-4 was free of bank
+  // conflicts but cost four instructions per look-up, and this kernel's time is its instruction count, not its LDS passes)
+  uint8_t *vx = smem + lane;
+  auto vx_at = [&](int u) __attribute__((always_inline)) -> uint8_t & { return vx[u << 6]; };
   uint32_t *lw = reinterpret_cast<uint32_t *>(smem) + lane;
   constexpr int TW0 = 16 * W * 64;   // dword offset of the visit-index set
+  constexpr int MW0 = TW0 + 2 * W * 64;   // ... of the staged member set (node space)
 
   const int lim = a.p.max_len, ld = a.ld, cap = min(lim, ld);
   const int idx_off = GTOK_SENT_IDX_OFFSET;
@@ -85,9 +96,7 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
   // longest first), at priority 0: a wave that has finished takes the longest pair left instead of leaving its SIMD one wave
   // short (125 k ER graphs x 2 epochs: 0.44 ms per epoch with the static deal already, against 0.51 for one epoch per launch).
   const int K = a.epochs, vunits = a.units * K, nslots = (int)gridDim.x * nwaves;
-  int *wg_ticket = reinterpret_cast<int *>(smem_all + (size_t)nwaves * (18 * W * 256));
-  if (threadIdx.x == 0) *wg_ticket = 0;
-  __syncthreads();
+  int *const wg_ticket = a.tickets + 2 * (int)blockIdx.x;
   for (int vu = grp * qsize + ((grp & 1) ? qsize - 1 - jq : jq); vu < vunits;) {
     int unit = vu, ep = 0;
     if (K > 1) {
@@ -217,44 +226,52 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
       for (int w = 0; w < W; ++w) t += __popcll(s[w]);
       return t;
     };
-    // ---- a set of 64 W bits (W registers) consumed in ascending order, 32 bits at a time: `nz` = its sub-words that still
-    // hold members beyond the current one.  Every lane moves through ITS non-empty sub-words, so a wave runs as many
-    // iterations as its largest set has members, whatever words they fall in.  The sub-word is picked out of the
-    // registers by a tree of bit-field inserts under masks made from the bits of its index (the masks go through inline
-    // asm: left to itself the compiler turns the tree into a chain of 2 W compares and selects).
-    struct Stream { uint32_t cur, nz; int base; };
-    auto bit_mask = [](int k, int bit) __attribute__((always_inline)) -> uint32_t {   // all ones if bit `bit` of k is set
-      uint32_t m;
-      if (bit == 0) asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(k));
-      else if (bit == 1) asm("v_bfe_i32 %0, %1, 1, 1" : "=v"(m) : "v"(k));
-      else if (bit == 2) asm("v_bfe_i32 %0, %1, 2, 1" : "=v"(m) : "v"(k));
-      else asm("v_bfe_i32 %0, %1, 3, 1" : "=v"(m) : "v"(k));
-      return m;
+    // ---- a set of 64 W bits consumed in ascending order OUT OF THE LANE'S LDS (2 W dwords at dword offset `off`, [dword][lane]),
+    // four members per loop iteration and NO BRANCH inside an iteration.  A lane holds two 32-bit sub-words of its set in
+    // registers (`cur`, then `nxt`); `nz` = the non-empty sub-words beyond those.  An iteration
+    //   top     asks LDS for the sub-word after `nxt` (the index differs from lane to lane, the bank does not) - always, used or not;
+    //   middle  pops up to four members from cur / nxt with selects (a pop from an empty pair is harmless and masked by the
+    //           caller's count), as many as the pair holds: stream_take() says how many;
+    //   bottom  shifts the pair along when `cur` is used up - selects again - and only there waits for the read of the top.
+    // Every lane moves through ITS non-empty sub-words, so a wave runs as many iterations as its largest set needs, whatever
+    // words the members fall in.  (Rounds 2-4 kept the set in W registers and picked sub-words with a tree of bit-field inserts
+    // under masks; an LDS stream with a refill branch behind every pop waited for its read inside the branch - the compiler
+    // has to finish the register shuffle before the join.  Both cost ~130 vector instructions per four members, and since
+    // SOME lane of the wave needed the slow path at nearly every pop, every iteration paid all of them.)
+    struct Stream { uint32_t cur, nxt, nz, pre; int base, nbase, pk; };
+    auto sub_slot = [&](int off, uint32_t nz, int &k) __attribute__((always_inline)) -> uint32_t * {
+      k = max(__ffs((int)nz) - 1, 0);          // (nz == 0: sub-word 0 - a valid address, a value nobody uses)
+      return lw + off + k * 64;
     };
-    auto sub_word = [&](const uint64_t (&sw)[W], int k) __attribute__((always_inline)) -> uint32_t {   // k = -1 (none left): 0
-      uint32_t h[2 * W];
-#pragma unroll
-      for (int w = 0; w < W; ++w) { h[2 * w] = (uint32_t)sw[w]; h[2 * w + 1] = (uint32_t)(sw[w] >> 32); }
-      int level = 0;
-#pragma unroll
-      for (int span = 1; span < 2 * W; span <<= 1, ++level) {
-        const uint32_t m = bit_mask(k, level);
-#pragma unroll
-        for (int j = 0; j + span < 2 * W; j += 2 * span) h[j] = (h[j] & ~m) | (h[j + span] & m);
-      }
-      return h[0] & ~bit_mask(k, level);
+    auto stream_open = [&](Stream &st, int off, uint32_t nz) __attribute__((always_inline)) {   // nz != 0
+      int k0, k1;
+      const uint32_t c = *sub_slot(off, nz, k0);
+      nz &= nz - 1;
+      const uint32_t n = *sub_slot(off, nz, k1);
+      st.cur = c; st.base = k0 << 5;
+      st.nxt = nz ? n : 0u; st.nbase = k1 << 5;
+      st.nz = nz & (nz - 1);
     };
-    auto stream_next = [&](Stream &st, const uint64_t (&sw)[W]) __attribute__((always_inline)) {   // (current sub-word used up)
-      const int k = __ffs((int)st.nz) - 1;   // -1 when nz == 0
-      st.nz &= st.nz - 1;
-      st.cur = sub_word(sw, k);
-      st.base = k << 5;
+    auto stream_top = [&](Stream &st, int off) __attribute__((always_inline)) { st.pre = *sub_slot(off, st.nz, st.pk); };
+    auto stream_take = [&](const Stream &st, int left) __attribute__((always_inline)) -> int {   // members this iteration can pop
+      return min(min(left, 4), __popc(st.cur) + __popc(st.nxt));
     };
-    auto stream_pop = [&](Stream &st, const uint64_t (&sw)[W]) __attribute__((always_inline)) -> int {   // st.cur != 0
-      const int u = st.base + __builtin_ctz(st.cur);
-      st.cur &= st.cur - 1;
-      if (st.cur == 0) stream_next(st, sw);
+    auto stream_pop = [&](Stream &st) __attribute__((always_inline)) -> int {
+      const bool fc = st.cur != 0;
+      const uint32_t src = fc ? st.cur : st.nxt;
+      int low;                                 // lowest set bit; -1 for an empty pair (v_ffbl_b32: defined, unlike __builtin_ctz(0))
+      asm("v_ffbl_b32 %0, %1" : "=v"(low) : "v"(src));
+      const int u = (fc ? st.base : st.nbase) + low;
+      st.cur &= st.cur - 1;                    // (0 stays 0)
+      st.nxt = fc ? st.nxt : (src & (src - 1));
       return u;
+    };
+    auto stream_bottom = [&](Stream &st) __attribute__((always_inline)) {
+      const bool adopt = st.cur == 0;
+      const uint32_t fresh = st.nz ? st.pre : 0u;
+      st.cur = adopt ? st.nxt : st.cur; st.base = adopt ? st.nbase : st.base;
+      st.nxt = adopt ? fresh : st.nxt; st.nbase = adopt ? (st.pk << 5) : st.nbase;
+      st.nz = adopt ? (st.nz & (st.nz - 1)) : st.nz;
     };
 
 #ifdef GTOK_PHASE_TIMING   // profiling build only: cycles per phase, left in the last 8 columns of the row of the unit's lane 0
@@ -276,7 +293,7 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
         bool have = false;                      // false in the first pass only (same in every lane: nothing to write yet)
         for (;;) {
           uint64_t M[W], tokv = 0;
-          int tokc = 0;
+          int tokc = 0, nm = 0;      // nm: members of this step's bracket
           bool anym = false;
 #pragma unroll
           for (int w = 0; w < W; ++w) M[w] = 0;
@@ -295,7 +312,6 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
             }
             // first visit: the node's neighbours lose an unvisited neighbour; visited neighbours (itself included: self
             // loop) other than the trail's predecessor form its bracket
-            int nm = 0;
             uint64_t bw[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) bw[w] = first ? rowc[w] : 0ull;
@@ -365,47 +381,61 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
             if (anym && pos < lim) {
               // LADJ, members by ascending visit index, RADJ: each member (node space, any order) sets its visit index's
               // bit in the lane's LDS set (two per iteration: two independent LDS reads in flight) ...
-              Stream sm;
-              sm.nz = 0;
+              uint32_t nzm = 0;
 #pragma unroll
-              for (int w = 0; w < W; ++w)
-                sm.nz |= ((uint32_t)M[w] ? 1u << (2 * w) : 0u) | ((uint32_t)(M[w] >> 32) ? 2u << (2 * w) : 0u);
-              stream_next(sm, M);
+              for (int w = 0; w < W; ++w) {
+                const uint32_t lo = (uint32_t)M[w], hi = (uint32_t)(M[w] >> 32);
+                lw[MW0 + (2 * w) * 64] = lo; lw[MW0 + (2 * w + 1) * 64] = hi;
+                nzm |= (lo ? 1u << (2 * w) : 0u) | (hi ? 2u << (2 * w) : 0u);
+              }
+              Stream sm;
+              stream_open(sm, MW0, nzm);
               uint32_t nzt = 0;
-              while (sm.cur != 0) {
-                const int u1 = stream_pop(sm, M);
-                const int u2 = sm.cur != 0 ? stream_pop(sm, M) : u1;
-                const uint32_t t1 = vx_at(u1), t2 = vx_at(u2);
-                __hip_atomic_fetch_or(&lw[TW0 + (t1 >> 5) * 64], 1u << (t1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_or(&lw[TW0 + (t2 >> 5) * 64], 1u << (t2 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                nzt |= (1u << (t1 >> 5)) | (1u << (t2 >> 5));
+              for (int left = nm; left > 0;) {
+                stream_top(sm, MW0);
+                const int c4 = stream_take(sm, left);
+                int u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int x = stream_pop(sm); u[j] = (j == 0 || j < c4) ? x : u[0]; }   // (a lane with fewer repeats its first)
+                uint32_t t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = vx_at(u[j]);
+                left -= c4;
+                stream_bottom(sm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  __hip_atomic_fetch_or(&lw[TW0 + (t[j] >> 5) * 64], 1u << (t[j] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                  nzt |= 1u << (t[j] >> 5);
+                }
 #ifdef GTOK_PHASE_TIMING
                 ++pt_it1;
 #endif
               }
               GTOK_PT(2)
-              // ... which is then read back whole, zeroed, and listed in ascending order, two tokens per iteration, RADJ
-              // with the last
-              uint64_t T[W];
-#pragma unroll
-              for (int w = 0; w < W; ++w) {
-                const uint32_t lo = lw[TW0 + (2 * w) * 64], hi = lw[TW0 + (2 * w + 1) * 64];
-                T[w] = ((uint64_t)hi << 32) | lo;
-                lw[TW0 + (2 * w) * 64] = 0; lw[TW0 + (2 * w + 1) * 64] = 0;
-              }
+              // ... which is then streamed back and listed in ascending order, up to a whole 4-token window per iteration, RADJ
+              // behind the last; then the set is zeroed for the next bracket
               Stream stt;
-              stt.nz = nzt;
-              stream_next(stt, T);
-              while (stt.cur != 0 && pos < lim) {
-                uint64_t val = (uint64_t)(uint32_t)(idx_off + stream_pop(stt, T));
-                int cntt = 1;
-                if (stt.cur != 0) { val |= (uint64_t)(uint32_t)(idx_off + stream_pop(stt, T)) << 16; cntt = 2; }
-                if (stt.cur == 0) { val |= T_RADJ << (cntt << 4); ++cntt; }
+              stream_open(stt, TW0, nzt);
+              for (int left = nm; left > 0 && pos < lim;) {
+                stream_top(stt, TW0);
+                const int c4 = stream_take(stt, left);
+                uint32_t tk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const uint32_t x = (uint32_t)(idx_off + stream_pop(stt)); tk[j] = j < c4 ? x : 0u; }
+                left -= c4;
+                uint64_t val = ((uint64_t)(tk[2] | (tk[3] << 16)) << 32) | (tk[0] | (tk[1] << 16));
+                int cntt = c4;
+                const bool last = left == 0;
+                if (last && c4 < 4) { val |= T_RADJ << (c4 << 4); ++cntt; }
                 append(val, cntt);
+                if (last && c4 == 4) append(T_RADJ, 1);
+                stream_bottom(stt);
 #ifdef GTOK_PHASE_TIMING
                 ++pt_it2;
 #endif
               }
+#pragma unroll
+              for (int k = 0; k < 2 * W; ++k) lw[TW0 + k * 64] = 0;
               GTOK_PT(3)
             }
           }
@@ -491,9 +521,14 @@ __global__ void __launch_bounds__(W == 4 ? 512 : 1024) sent_blane_kernel(const S
 #endif
     // ---- the next pair
     int t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(wg_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) t = __hip_atomic_fetch_add(wg_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     vu = nslots + uni(t) * (int)gridDim.x + (int)blockIdx.x;
     __builtin_amdgcn_s_setprio(0);
+  }
+  // every wave passes here exactly once; the workgroup's last one leaves both counters zero for the launch that gets them next
+  if (lane == 0 && __hip_atomic_fetch_add(wg_ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwaves - 1) {
+    __hip_atomic_store(wg_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(wg_ticket + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
