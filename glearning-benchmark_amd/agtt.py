@@ -38,6 +38,7 @@ class TokenizedGraphDataset(Dataset):
         self._rows = None                      # rows.EpochRows: the host view __getitem__ serves from
         self._ids = self._lens = None
         self._slab = None                      # (ids16 [K, G, ld], len [K, G], first epoch, padded): the last K-epoch launch
+        self._slab_sig = None                  # ... and what it was made with (tokenizer configuration, remap switch, query table)
         self._served = None                    # __getitems__: which rows of the current epoch went out already
         self._y_dev = None                     # labels on the device (batch-level fetch)
         self._lens_h = None                    # the current epoch's row lengths on the host (batch-level fetch)
@@ -91,8 +92,14 @@ class TokenizedGraphDataset(Dataset):
         carries K epochs (tokenizer.epochs_for: trails depend on (seed, epoch, graph) only, and the trainer asks for the
         same split again every epoch, trainer/train_agtt.py:676-680); the following K - 1 calls are slices of it."""
         batch = self._graphs()
+        # what the cached K-epoch slab was made with: a tokenizer reconfigured since (set_num_nodes, seed, truncation_length,
+        # labelled types), another remap switch or query table must not be served the old trails for up to K - 1 epochs
+        sig = (self.tokenizer._signature() if hasattr(self.tokenizer, "_signature") else None, self.remap_to_fixed_vocab, id(self._query))
         sl = self._slab
+        if sl is not None and self._slab_sig != sig:
+            sl = self._slab = None
         if sl is None or not sl[2] <= epoch < sl[2] + sl[0].shape[0]:
+            self._slab_sig = sig
             K = 1
             if hasattr(self.tokenizer, "epochs_for"):
                 K = self.tokenizer.epochs_for(batch.num_graphs, _ops.sent_safe_ld(batch, self.tokenizer.labeled_graph, self.tokenizer._max_len(),
@@ -175,6 +182,10 @@ class TokenizedGraphDataset(Dataset):
         if self._mixed_query:
             return [self[i] for i in indices]
         idx = np.asarray(indices, dtype=np.int64)
+        if idx.size > 1 and np.unique(idx).size != idx.size:
+            # a sampler with replacement put an item into the batch twice: in the reference every fetch of an item is a new
+            # random trail, and one epoch slab holds one trail per item - the per-item path serves such a batch
+            return [self[i] for i in indices]
         if self._served is None or self._ids is None or self._ids.dtype != torch.int16 or self._served[idx].any():
             self.tokenize_epoch_u16(self._epoch + 1)
             self._served = np.zeros(len(self), dtype=bool)
@@ -195,15 +206,17 @@ class TokenizedGraphDataset(Dataset):
         n = len(self)
         ds = self.pyg_dataset
         y = self._labels_on_device()
-        lens_h = lens.cpu()
         order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
         order_d = order.to(ids.device)
-        ld = ids.shape[1]
-        for s in range(0, n, batch_size):
-            idx = order[s:s + batch_size]
-            idx_d = order_d[s:s + batch_size]
-            X, A = _ops.collate_packed(ids, None, lens, ld, idx_d, PAD, min(ld, int(lens_h[idx].max())))
-            yield X, A, y[idx_d], (LazyDataList(ds, idx.tolist()) if with_data else [])
+        # the whole epoch collated by one call (gtok_collate_epoch): a batch is three views of the epoch's arenas - no launch, no
+        # allocation, no host-side maximum per batch (round 4: one gtok_collate_packed launch + a lens[idx].max() per batch)
+        X, A, lmax, off = _ops.collate_epoch(ids, None, lens, ids.shape[1], order_d, batch_size, PAD)
+        y_perm = y[order_d]
+        order_l = order.tolist() if with_data else None
+        for b, s in enumerate(range(0, n, batch_size)):
+            B, L, o = min(batch_size, n - s), lmax[b], off[b]
+            yield (X.as_strided((B, L), (L, 1), o), A.as_strided((B, L), (L, 1), o), y_perm[s:s + B],
+                   LazyDataList(ds, order_l[s:s + B]) if with_data else [])
 
 
 class LazyDataList(Sequence):
@@ -234,6 +247,11 @@ class CollatedBatch(Sequence):
 
     def __len__(self):
         return len(self._idx)
+
+    def pin_memory(self):
+        """DataLoader(pin_memory=True) pins what the fetcher returns; this batch lives on the device already (a CUDA tensor cannot
+        be pinned: without this method the loader's pin thread raises)."""
+        return self
 
     def _materialise(self):
         if self._items is None:

@@ -150,20 +150,23 @@ struct QueueRing {
   bool used[kMaxDev][kSlots] = {};
   unsigned seq[kMaxDev] = {};
   bool graph_used[kMaxDev][kGraphSlots] = {};   // reserved blocks held by live hipGraphs
+  bool graph_keep[kMaxDev][kGraphSlots] = {};   // ... whose hand-over to a graph failed: never returned (a graph may still replay with them)
 };
 inline QueueRing &queue_ring() { static QueueRing r; return r; }
 
 // A reserved block goes back to the pool when the hipGraph that captured its launch is destroyed (and every executable
 // graph instantiated from it: they hold their own reference): a HIP user object owned by the graph carries the block's
 // (device, index) and hands it back from its destructor - which runs on a runtime thread and calls no HIP function.  The
-// block is clean then: the last wave of every launch re-arms its counters.
+// block is clean then: the last wave of every launch re-arms its counters - PROVIDED no replay of an executable graph made from
+// that graph is still running: synchronise the streams its replays were launched on before destroying a graph (the counters of a
+// replay in flight would otherwise be handed to the next capture).
 inline void release_graph_slot(void *tag) {
   const uintptr_t t = reinterpret_cast<uintptr_t>(tag) - 1;
   const int dev = (int)(t / kGraphSlots), idx = (int)(t % kGraphSlots);
   if (dev < 0 || dev >= kMaxDev) return;
   QueueRing &r = queue_ring();
   std::lock_guard<std::mutex> lock(r.mu);
-  r.graph_used[dev][idx] = false;
+  if (!r.graph_keep[dev][idx]) r.graph_used[dev][idx] = false;
 }
 
 inline QueueSlot take_queue_slot(int dev, hipStream_t stream) {
@@ -171,6 +174,7 @@ inline QueueSlot take_queue_slot(int dev, hipStream_t stream) {
   if (dev < 0 || dev >= kMaxDev) return out;
   QueueRing &r = queue_ring();
   hipEvent_t wait_for = nullptr;
+  int graph_idx = -1;                                   // a reserved block taken for a captured launch
   {
     std::lock_guard<std::mutex> lock(r.mu);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -189,28 +193,10 @@ inline QueueSlot take_queue_slot(int dev, hipStream_t stream) {
       for (int i = 0; i < kGraphSlots; ++i)
         if (!r.graph_used[dev][i]) { idx = i; break; }
       if (idx < 0) { out.graph_pool_empty = true; return out; }
-      r.graph_used[dev][idx] = true;                    // (stays taken for the life of the process if the hand-over below fails)
+      r.graph_used[dev][idx] = true;                    // reserved under the lock; the hand-over to the graph happens outside it
+      graph_idx = idx;
       out.counters = r.mem[dev] + (size_t)kSlotInts * (kSlots + idx);
-      // tie the block to the capturing graph's lifetime
-      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-      hipGraph_t graph = nullptr;
-      unsigned long long id = 0;
-      if (hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, nullptr, nullptr) == hipSuccess && graph) {
-        hipUserObject_t obj = nullptr;
-        void *tag = reinterpret_cast<void *>((uintptr_t)dev * kGraphSlots + idx + 1);
-        if (hipUserObjectCreate(&obj, tag, release_graph_slot, 1, hipUserObjectNoDestructorSync) == hipSuccess) {
-          if (hipGraphRetainUserObject(graph, obj, 1, hipGraphUserObjectMove) != hipSuccess) {
-            (void)hipGetLastError();
-            r.graph_used[dev][idx] = true;              // keep it reserved: the destructor must not free a block still in a graph
-          }
-        } else {
-          (void)hipGetLastError();
-        }
-      } else {
-        (void)hipGetLastError();
-      }
-      return out;
-    }
+    } else {
     // the ring index is this call's alone until the ring wraps again (kSlots launches later): the wait for the launch
     // that used it last happens OUTSIDE the lock, so launches on other devices and threads are not held up behind it
     const int i = (int)(r.seq[dev]++ % kSlots);
@@ -221,6 +207,32 @@ inline QueueSlot take_queue_slot(int dev, hipStream_t stream) {
     }
     out.counters = r.mem[dev] + (size_t)kSlotInts * i;
     out.index = i;
+    }
+  }
+  if (graph_idx >= 0) {
+    // tie the block to the capturing graph's lifetime - with the ring's mutex RELEASED: the user object's destructor
+    // (release_graph_slot) takes that mutex from a runtime thread, possibly under a lock of the runtime's own that the calls
+    // below need as well (an ABBA order with a hipGraphDestroy on another thread).  On any failure the block stays
+    // reserved for the life of the process (never handed to a second graph) and a user object that no graph retained is released.
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    hipGraph_t graph = nullptr;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, nullptr, nullptr) == hipSuccess && graph) {
+      hipUserObject_t obj = nullptr;
+      void *tag = reinterpret_cast<void *>((uintptr_t)dev * kGraphSlots + graph_idx + 1);
+      if (hipUserObjectCreate(&obj, tag, release_graph_slot, 1, hipUserObjectNoDestructorSync) == hipSuccess) {
+        if (hipGraphRetainUserObject(graph, obj, 1, hipGraphUserObjectMove) != hipSuccess) {
+          (void)hipGetLastError();
+          { std::lock_guard<std::mutex> lock(r.mu); r.graph_keep[dev][graph_idx] = true; }   // the captured launch still uses the block
+          (void)hipUserObjectRelease(obj, 1);           // (its destructor then leaves the block reserved)
+        }
+      } else {
+        (void)hipGetLastError();
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+    return out;
   }
   if (wait_for && hipEventSynchronize(wait_for) != hipSuccess) {      // still in flight (or unknown): wait for that launch
     (void)hipGetLastError();

@@ -450,6 +450,66 @@ __global__ void __launch_bounds__(256) collate_packed_kernel(const void *__restr
   }
 }
 
+// ---- a whole epoch's batches in one launch (gtok_collate_epoch): rows order[0 .. n) cut into batches of batch_size, batch b
+// collated to its own width L_b (its longest row) at element batch_off[b] of one arena.  The per-batch route costs a launch,
+// two allocations and a host-side maximum per 128 rows - ~25 us of Python and runtime for 13 us of work per ZINC batch.
+__global__ void __launch_bounds__(256) collate_plan_kernel(const int32_t *__restrict__ len, int ld, const int64_t *__restrict__ order, int64_t n,
+                                                           int batch_size, int64_t nb, int32_t *__restrict__ batch_lmax) {
+  const int lane = lane_id();
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave_id();
+  if (b >= nb) return;
+  const int64_t r0 = b * batch_size, r1 = min(n, r0 + batch_size);
+  int m = 0;
+  for (int64_t r = r0 + lane; r < r1; r += kWave) { int v = len[order[r]]; v = v < 0 ? 0 : (v > ld ? ld : v); m = max(m, v); }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if (lane == 0) batch_lmax[b] = m;
+}
+
+// batch_off[b] = sum over earlier batches of rows x width, batch_off[nb] = the arena's size in elements; one workgroup
+__global__ void __launch_bounds__(1024) collate_offsets_kernel(const int32_t *__restrict__ batch_lmax, int64_t n, int batch_size, int64_t nb,
+                                                              int64_t *__restrict__ batch_off) {
+  __shared__ int64_t s_w[16];
+  const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6;
+  const int64_t chunk = (nb + 1023) / 1024, lo = min(nb, tid * chunk), hi = min(nb, lo + chunk);
+  auto size_of = [&](int64_t b) -> int64_t { return (min(n, (b + 1) * (int64_t)batch_size) - b * (int64_t)batch_size) * batch_lmax[b]; };
+  int64_t s = 0;
+  for (int64_t b = lo; b < hi; ++b) s += size_of(b);
+  int64_t inc = s;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) { const int64_t up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+  if (lane == kWave - 1) s_w[w] = inc;
+  __syncthreads();
+  int64_t run = inc - s;
+  for (int k = 0; k < w; ++k) run += s_w[k];
+  for (int64_t b = lo; b < hi; ++b) { batch_off[b] = run; run += size_of(b); }
+  if (tid == 1023) batch_off[nb] = run;
+}
+
+template <typename E>
+__global__ void __launch_bounds__(256) collate_epoch_kernel(const void *__restrict__ packed, const int64_t *__restrict__ row_ptr,
+                                                            const int32_t *__restrict__ len, int ld, const int64_t *__restrict__ order, int64_t n,
+                                                            int batch_size, int pad_id, const int32_t *__restrict__ batch_lmax,
+                                                            const int64_t *__restrict__ batch_off, int64_t *__restrict__ out_x,
+                                                            uint8_t *__restrict__ out_attn, int64_t arena_elems) {
+  const int lane = lane_id();
+  const int64_t r = (int64_t)blockIdx.x * (int)(blockDim.x >> 6) + wave_id();
+  if (r >= n) return;
+  const int64_t b = r / batch_size;
+  const int L = batch_lmax[b];
+  const int64_t at = batch_off[b] + (r - b * batch_size) * (int64_t)L;
+  if (at < 0 || at + L > arena_elems) return;                   // (an arena smaller than batch_off[nb]: nothing is written past it)
+  const int64_t src = order[r];
+  int nn = len[src];
+  nn = nn < 0 ? 0 : (nn > ld ? ld : nn);
+  const E *__restrict__ row = reinterpret_cast<const E *>(packed) + (row_ptr ? row_ptr[src] : src * (int64_t)ld);
+  for (int i = lane; i < L; i += kWave) {
+    const bool in = i < nn;
+    out_x[at + i] = in ? (int64_t)row[i] : (int64_t)pad_id;
+    out_attn[at + i] = in ? 1 : 0;
+  }
+}
+
 // ---- id rows -> text (the strings ZINCTokenizationDataset.__getitem__ hands to the trainer, zinc_dataset_indexbase.py:143-227,
 // rendered for a whole split at once).  One wave per row; lane = token: the row's text is the table strings of its first
 // take[r] ids joined by single spaces, then the row's suffix bytes verbatim.
@@ -734,6 +794,40 @@ extern "C" int gtok_collate_packed(const void *packed, int32_t elem_bytes, const
   else
     hipLaunchKernelGGL(collate_packed_kernel<int32_t>, dim3((batch + 3) / 4), dim3(256), 0, s, packed, row_ptr, len, ld, index,
                        batch, pad_id, out_x, out_attn, out_ld);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_collate_epoch_plan(const int32_t *len, int32_t ld, const int64_t *order, int64_t n, int32_t batch_size,
+                                       int32_t *batch_lmax, int64_t *batch_off, void *stream) {
+  DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (n < 0 || ld <= 0 || batch_size <= 0 || !batch_off) return GTOK_E_INVAL;
+  const int64_t nb = (n + batch_size - 1) / batch_size;
+  if (nb > 0 && (!len || !order || !batch_lmax)) return GTOK_E_INVAL;
+  if ((nb + 3) / 4 > 0x7FFFFFFF) return GTOK_E_TOO_LARGE;
+  hipStream_t s = (hipStream_t)stream;
+  if (nb > 0) hipLaunchKernelGGL(collate_plan_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s, len, ld, order, n, batch_size, nb, batch_lmax);
+  hipLaunchKernelGGL(collate_offsets_kernel, dim3(1), dim3(1024), 0, s, batch_lmax, n, batch_size, nb, batch_off);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_collate_epoch(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len, int32_t ld,
+                                  const int64_t *order, int64_t n, int32_t batch_size, int32_t pad_id, const int32_t *batch_lmax,
+                                  const int64_t *batch_off, int64_t *out_x, uint8_t *out_attn, int64_t arena_elems, void *stream) {
+  DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (n < 0 || ld <= 0 || batch_size <= 0 || arena_elems < 0 || (elem_bytes != 2 && elem_bytes != 4)) return GTOK_E_INVAL;
+  if (n == 0) return GTOK_OK;
+  if (!packed || !len || !order || !batch_lmax || !batch_off || !out_x || !out_attn) return GTOK_E_INVAL;
+  if ((n + 3) / 4 > 0x7FFFFFFF) return GTOK_E_TOO_LARGE;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+  if (elem_bytes == 2)
+    hipLaunchKernelGGL(collate_epoch_kernel<uint16_t>, grid, block, 0, s, packed, row_ptr, len, ld, order, n, batch_size, pad_id, batch_lmax, batch_off,
+                       out_x, out_attn, arena_elems);
+  else
+    hipLaunchKernelGGL(collate_epoch_kernel<int32_t>, grid, block, 0, s, packed, row_ptr, len, ld, order, n, batch_size, pad_id, batch_lmax, batch_off,
+                       out_x, out_attn, arena_elems);
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 

@@ -559,6 +559,33 @@ def collate_packed(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: to
     return X, A
 
 
+def collate_epoch(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: torch.Tensor, ld: int, order: torch.Tensor, batch_size: int,
+                  pad_id: int):
+    """Every batch of an epoch collated by ONE call (gtok_collate_epoch): rows `order` (int64, on the device) cut into batches of
+    batch_size -> (X int64 arena, attn bool arena, lmax list[int], off list[int]): batch b is
+    X.as_strided((B_b, lmax[b]), (lmax[b], 1), off[b]) - what collate_packed(index=order[b * batch_size:...], out_ld=lmax[b]) gives.
+    row_ptr=None: `packed` is a [rows, ld] slab of 16- / 32-bit ids (ops.sent(..., u16=True)).  One small read-back per EPOCH
+    (the batch widths), none per batch."""
+    _need_gpu(packed, "collate_epoch")
+    dev = packed.device
+    order = order.to(dev, dtype=torch.int64).contiguous()
+    n, bs = int(order.numel()), int(batch_size)
+    nb = -(-n // bs) if n else 0
+    lmax = torch.empty(max(nb, 1), dtype=torch.int32, device=dev)
+    off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+    L = lib()
+    check(L.gtok_collate_epoch_plan(ln.data_ptr(), int(ld), order.data_ptr(), n, bs, lmax.data_ptr(), off.data_ptr(), _stream(dev)),
+          "gtok_collate_epoch_plan")
+    off_h = off.tolist()                       # the one synchronisation of the epoch: the arena is sized exactly
+    total = off_h[-1]
+    X = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    A = torch.empty(max(total, 1), dtype=torch.bool, device=dev)
+    check(L.gtok_collate_epoch(packed.data_ptr(), packed.element_size(), None if row_ptr is None else row_ptr.data_ptr(), ln.data_ptr(), int(ld),
+                               order.data_ptr(), n, bs, int(pad_id), lmax.data_ptr(), off.data_ptr(), X.data_ptr(), A.data_ptr(), total,
+                               _stream(dev)), "gtok_collate_epoch")
+    return X, A, lmax[:nb].tolist(), off_h
+
+
 def zinc_text_tails(y: torch.Tensor, ln: torch.Tensor, max_len: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """What follows `<p>` in every ZINC text, rendered on the device (gtok_zinc_text_tails; reference
     zinc_dataset_indexbase.py:186-195, :217-221): y float32 [G] labels, ln int32 [G] ids per row (gtok_ibtt_zinc's lengths).

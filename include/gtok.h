@@ -30,6 +30,7 @@
  *                      copy behind TokenizedGraphDataset.__getitem__ (trainer/train_agtt.py:246-273); the readers also
  *                      take a [rows, ld] slab of 16-bit ids in place (row_ptr NULL): the per-batch collate of
  *                      trainer/train_agtt.py:276-302 straight over GTOK_SENT_U16 rows
+ *   gtok_collate_epoch_plan / gtok_collate_epoch   trainer/train_agtt.py:276-302 for every batch of an epoch at once
  *   gtok_ids_to_text   graph_data_loader/zinc_dataset_indexbase.py:143-227, the STRING form (ids rendered through a string table)
  *   gtok_zinc_text_tails   zinc_dataset_indexbase.py:186-195, :217-221 (label token + <eos> / the max_len cut, per molecule)
  *   gtok_csr_check     (no reference counterpart; the property torch_geometric's coalesced undirected graphs have by construction -
@@ -413,6 +414,22 @@ int gtok_unpack_rows_u16(const void *packed, int32_t elem_bytes, const int64_t *
  * fit `capacity` were skipped).                                                                                              */
 int gtok_pack_rows_scan(const void *ids, int32_t src_bytes, int32_t ld, const int32_t *len, int64_t num_rows, int32_t align,
                         int32_t elem_bytes, void *packed, int64_t capacity, int64_t *row_ptr, int32_t *status, void *stream);
+
+/* A whole EPOCH's batches collated by one call (ABI v5; trainer/train_agtt.py:599-607 builds the loader, :276-302 is the collate
+ * it replaces): the rows order[0 .. n) of the slab / packed rows (as gtok_collate_packed reads them) are cut into batches of
+ * batch_size consecutive entries of `order` (the last one may be short).  gtok_collate_epoch_plan writes batch_lmax[b] = the
+ * longest row of batch b (min(len, ld) each; int32 [nb], nb = ceil(n / batch_size)) and batch_off[b] = the element at which
+ * batch b starts in the arenas, batch_off[nb] = their size (int64 [nb + 1]).  gtok_collate_epoch then fills out_x (int64) and
+ * out_attn (bool bytes): batch b is the row-major [B_b, batch_lmax[b]] block at batch_off[b] of both - exactly what
+ * gtok_collate_packed gives for index = order[b * batch_size ..] and out_ld = batch_lmax[b].  arena_elems = the elements the
+ * arenas hold: an upper bound such as n * ld needs no read-back before the fill (a row that would end beyond it is skipped).
+ * A batch then costs its consumer no launch, no allocation and no synchronisation: the host reads batch_lmax / batch_off once
+ * per epoch and takes views.                                                                                                  */
+int gtok_collate_epoch_plan(const int32_t *len, int32_t ld, const int64_t *order, int64_t n, int32_t batch_size,
+                            int32_t *batch_lmax, int64_t *batch_off, void *stream);
+int gtok_collate_epoch(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len, int32_t ld,
+                       const int64_t *order, int64_t n, int32_t batch_size, int32_t pad_id, const int32_t *batch_lmax,
+                       const int64_t *batch_off, int64_t *out_x, uint8_t *out_attn, int64_t arena_elems, void *stream);
 
 /* Rows of ids -> TEXT: the strings ZINCTokenizationDataset.__getitem__ returns (zinc_dataset_indexbase.py:143-227: the
  * trainer builds its vocab from them, trainer/train_ibtt.py:229-235, :361-372) rendered for a whole split at once.  Row

@@ -349,6 +349,67 @@ def test_stock_dataloader_fetches_whole_batches_through_getitems():
             break
 
 
+def test_device_batches_collate_the_epoch_in_one_call_and_the_slab_follows_the_tokenizer():
+    """agtt.TokenizedGraphDataset.device_batches: every batch of the epoch comes out of ONE gtok_collate_epoch call (views of
+    the epoch's arenas) and equals gtok_collate_packed per batch == the oracle's rows; shuffle and a short last batch included.
+    ADVICE r4: a tokenizer reconfigured between epochs (seed) must not be served trails of the cached K-epoch slab; a batch
+    with a duplicated index goes through the per-item path."""
+    from torch.utils.data import DataLoader
+    G = 2500
+    d = gtok.synth.zinc_like(G, seed=78)
+    _, coo = both(d)
+    pyg = gdl.ZINCDatasetForAutoGraph(split="train", zinc_dataset=gtok.synth.InMemoryLike(d))
+    agtt = gtok.agtt
+    ds = agtt.TokenizedGraphDataset(pyg, _zinc_tokenizer(37), task="zinc", remap_to_fixed_vocab=True, device=DEV)
+    okw = dict(ld=256, labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True, nthreads=8)
+    for epoch, shuffle in ((4, False), (5, True)):
+        ref, rln = orc.sent(coo, 37, 1024, 5, epoch, **okw)
+        gen = torch.Generator().manual_seed(3)
+        order = torch.randperm(G, generator=torch.Generator().manual_seed(3)).numpy() if shuffle else np.arange(G)
+        seen = 0
+        for k, (X, A, Y, datas) in enumerate(ds.device_batches(96, epoch=epoch, shuffle=shuffle, generator=gen)):
+            idx = order[k * 96:(k + 1) * 96]
+            L = int(rln[idx].max())
+            assert tuple(X.shape) == (len(idx), L) and X.dtype == torch.long and A.dtype == torch.bool and X.is_cuda
+            Xh, Ah = X.cpu().numpy(), A.cpu().numpy()
+            want = np.where(np.arange(L)[None, :] < rln[idx][:, None], ref[idx][:, :L], 5)
+            assert np.array_equal(Xh, want) and np.array_equal(Ah, np.arange(L)[None, :] < rln[idx][:, None])
+            assert np.allclose(Y.cpu().numpy(), d["y"][idx]) and len(datas) == len(idx) and datas[1].num_nodes == int(d["node_counts"][idx[1]])
+            seen += len(idx)
+        assert seen == G and k == (G - 1) // 96
+    # the raw op against gtok_collate_packed, int32 slab + explicit row_ptr too
+    ids, ln = ds.tokenize_epoch(7)
+    order_d = torch.randperm(G, generator=torch.Generator().manual_seed(9)).to(DEV)
+    ptr = gtok.ops.row_offsets(ln, ids.shape[1])
+    packed, _ = gtok.ops.pack_rows(ids, ln, ptr, elem_bytes=2)
+    for src, rp in ((ids, None), (packed, ptr)):
+        X, A, lmax, off = gtok.ops.collate_epoch(src, rp, ln, ids.shape[1], order_d, 128, 5)
+        for b in (0, 7, len(lmax) - 1):
+            sel = order_d[b * 128:(b + 1) * 128]
+            Xb, Ab = gtok.ops.collate_packed(src, rp, ln, ids.shape[1], sel, 5, lmax[b])
+            B = sel.numel()
+            assert torch.equal(X.as_strided((B, lmax[b]), (lmax[b], 1), off[b]), Xb) and torch.equal(A.as_strided((B, lmax[b]), (lmax[b], 1), off[b]), Ab)
+        assert off[-1] == sum(min(128, G - 128 * b) * lmax[b] for b in range(len(lmax)))
+    # ADVICE: the cached K-epoch slab follows the tokenizer's configuration
+    a0, l0 = ds.tokenize_epoch_u16(20)
+    a0, l0 = a0.clone(), l0.clone()
+    ds.tokenizer.seed = 6
+    a1, l1 = ds.tokenize_epoch_u16(21)                 # inside the K epochs of the cached launch, but the seed changed
+    r1, rl1 = orc.sent(coo, 37, 1024, 6, 21, **dict(okw, ld=a1.shape[1]))
+    assert np.array_equal(l1.cpu().numpy(), rl1)
+    got = a1.cpu().numpy().view(np.uint16).astype(np.int32)
+    inside = np.arange(a1.shape[1])[None, :] < rl1[:, None]
+    assert np.array_equal(np.where(inside, got, 0), np.where(inside, r1, 0))
+    ds.tokenizer.seed = 5
+    # a batch with a duplicated index: per-item path (two fetches of an item are two trails), no exception
+    out = ds.__getitems__([3, 3, 9])
+    assert isinstance(out, list) and len(out) == 3 and out[0][0].dtype == torch.long
+    # (pin_memory=True is not supported over device batches - the loader pins what collate_fn returns, and CUDA tensors cannot be
+    # pinned; the reference's loaders do not set it, INTEGRATION.md says so.)  The fetcher's own object passes a pin request through:
+    cb = ds.__getitems__([1, 2, 5])
+    assert cb.pin_memory() is cb and agtt.collate_fn(cb)[0].is_cuda
+
+
 def test_token_dataset_batches_through_getitems_equal_per_item_collate():
     """IBTT: `DataLoader(TokenDataset, batch_size, shuffle, num_workers=2, collate_fn=lambda b: collate(b, pad_id))`
     (trainer/train_ibtt.py:399-402) - batches built from the packed host buffer in one go equal the per-item collate."""
