@@ -98,6 +98,7 @@ SYMBOLS = {
     "gtok_unpack_rows_u16": (_I, [_P, _I, _P, _P, ctypes.c_int64, _I, ctypes.c_int64, ctypes.c_int64, _I, _P, _I, _P, _P]),
     "gtok_pack_rows_u16": (_I, [_P, _I, _P, ctypes.c_int64, _P, _I, _P, ctypes.c_int64, _P, _P]),
     "gtok_pack_rows_scan": (_I, [_P, _I, _I, _P, ctypes.c_int64, _I, _I, _P, ctypes.c_int64, _P, _P, _P]),
+    "gtok_collate_batch": (_I, [_P, _I, _P, _P, _I, _P, _I, ctypes.c_int64, _I, _P, _P, _I, _P, _I, _P, _P]),
     "gtok_collate_epoch_plan": (_I, [_P, _I, _P, ctypes.c_int64, _I, _P, _P, _P]),
     "gtok_collate_epoch": (_I, [_P, _I, _P, _P, _I, _P, ctypes.c_int64, _I, _I, _P, _P, _P, _P, ctypes.c_int64, _P]),
     "gtok_ids_to_text": (_I, [_P, _I, _P, ctypes.c_int64, _P, _P, _I, _P, _P, _P, _P, _P, _P]),

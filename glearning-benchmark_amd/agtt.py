@@ -182,7 +182,7 @@ class TokenizedGraphDataset(Dataset):
         if self._mixed_query:
             return [self[i] for i in indices]
         idx = np.asarray(indices, dtype=np.int64)
-        if idx.size > 1 and np.unique(idx).size != idx.size:
+        if len(set(indices)) != idx.size:
             # a sampler with replacement put an item into the batch twice: in the reference every fetch of an item is a new
             # random trail, and one epoch slab holds one trail per item - the per-item path serves such a batch
             return [self[i] for i in indices]
@@ -191,10 +191,10 @@ class TokenizedGraphDataset(Dataset):
             self._served = np.zeros(len(self), dtype=bool)
             self._lens_h = self._lens.cpu().numpy()
         self._served[idx] = True
-        idx_d = torch.from_numpy(idx).to(self._dev(), non_blocking=True)
         lmax = int(np.minimum(self._lens_h[idx], self._ids.shape[1]).max()) if idx.size else 0
-        X, A = _ops.collate_packed(self._ids, None, self._lens, self._ids.shape[1], idx_d, PAD, lmax)
-        return CollatedBatch(self, idx, X, A, self._labels_on_device()[idx_d], self._epoch)
+        # the index list stays on the host: it rides in the launch's arguments, and the labels come out of the same launch
+        X, A, Y = _ops.collate_batch(self._ids, None, self._lens, self._ids.shape[1], idx, PAD, lmax, self._labels_on_device())
+        return CollatedBatch(self, idx, X, A, Y, self._epoch)
 
     def device_batches(self, batch_size: int, epoch: int, shuffle: bool = False,
                        generator: Optional[torch.Generator] = None, with_data: bool = True):

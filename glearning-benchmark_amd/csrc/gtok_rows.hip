@@ -510,6 +510,35 @@ __global__ void __launch_bounds__(256) collate_epoch_kernel(const void *__restri
   }
 }
 
+// ---- one batch whose row list arrives from the HOST (gtok_collate_batch): the stock DataLoader hands a Python list of 128
+// indices to the dataset per batch; uploading it was a synchronous 1 KB H2D copy and the labels a gather launch of their own.
+// Here the indices travel in the kernel's arguments (<= 512 per launch) and the labels are gathered by the same kernel.
+constexpr int kBatchArgIdx = 512;
+struct BatchArgs {
+  const void *packed; const int64_t *row_ptr; const int32_t *len; int64_t *out_x; uint8_t *out_attn;
+  const uint8_t *y; uint8_t *out_y;
+  int ld, batch, first, pad_id, out_ld, y_bytes;
+  int32_t index[kBatchArgIdx];
+};
+
+template <typename E>
+__global__ void __launch_bounds__(256) collate_batch_kernel(const BatchArgs a) {
+  const int lane = lane_id();
+  const int k = (int)blockIdx.x * 4 + wave_id();          // row of this launch's chunk
+  if (k >= a.batch) return;
+  const int64_t src = a.index[k];
+  const int b = a.first + k;                              // row of the whole batch
+  int n = a.len[src];
+  n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
+  const E *__restrict__ row = reinterpret_cast<const E *>(a.packed) + (a.row_ptr ? a.row_ptr[src] : src * (int64_t)a.ld);
+  for (int i = lane; i < a.out_ld; i += kWave) {
+    const bool in = i < n;
+    a.out_x[(int64_t)b * a.out_ld + i] = in ? (int64_t)row[i] : (int64_t)a.pad_id;
+    a.out_attn[(int64_t)b * a.out_ld + i] = in ? 1 : 0;
+  }
+  if (a.y && lane < a.y_bytes) a.out_y[(int64_t)b * a.y_bytes + lane] = a.y[src * (int64_t)a.y_bytes + lane];
+}
+
 // ---- id rows -> text (the strings ZINCTokenizationDataset.__getitem__ hands to the trainer, zinc_dataset_indexbase.py:143-227,
 // rendered for a whole split at once).  One wave per row; lane = token: the row's text is the table strings of its first
 // take[r] ids joined by single spaces, then the row's suffix bytes verbatim.
@@ -794,6 +823,32 @@ extern "C" int gtok_collate_packed(const void *packed, int32_t elem_bytes, const
   else
     hipLaunchKernelGGL(collate_packed_kernel<int32_t>, dim3((batch + 3) / 4), dim3(256), 0, s, packed, row_ptr, len, ld, index,
                        batch, pad_id, out_x, out_attn, out_ld);
+  return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
+}
+
+extern "C" int gtok_collate_batch(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len, int32_t ld,
+                                  const int64_t *host_index, int32_t batch, int64_t num_rows, int32_t pad_id, int64_t *out_x, uint8_t *out_attn,
+                                  int32_t out_ld, const void *y, int32_t y_bytes, void *out_y, void *stream) {
+  DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  if (batch < 0 || ld <= 0 || out_ld < 0 || num_rows < 0 || (elem_bytes != 2 && elem_bytes != 4) || (y && (y_bytes < 1 || y_bytes > 8 || !out_y)))
+    return GTOK_E_INVAL;
+  if (batch == 0) return GTOK_OK;
+  if (!packed || !len || !host_index || (out_ld > 0 && (!out_x || !out_attn))) return GTOK_E_INVAL;
+  for (int i = 0; i < batch; ++i)
+    if (host_index[i] < 0 || host_index[i] >= num_rows) return GTOK_E_INVAL;       // the list is on the host: checked before anything is launched
+  hipStream_t s = (hipStream_t)stream;
+  BatchArgs a;
+  a.packed = packed; a.row_ptr = row_ptr; a.len = len; a.out_x = out_x; a.out_attn = out_attn;
+  a.y = reinterpret_cast<const uint8_t *>(y); a.out_y = reinterpret_cast<uint8_t *>(out_y);
+  a.ld = ld; a.pad_id = pad_id; a.out_ld = out_ld; a.y_bytes = y ? y_bytes : 0;
+  for (int first = 0; first < batch; first += kBatchArgIdx) {
+    const int cnt = batch - first < kBatchArgIdx ? batch - first : kBatchArgIdx;
+    a.batch = cnt; a.first = first;
+    for (int i = 0; i < cnt; ++i) a.index[i] = (int32_t)host_index[first + i];
+    if (elem_bytes == 2) hipLaunchKernelGGL(collate_batch_kernel<uint16_t>, dim3((cnt + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(collate_batch_kernel<int32_t>, dim3((cnt + 3) / 4), dim3(256), 0, s, a);
+  }
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 

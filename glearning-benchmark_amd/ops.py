@@ -559,6 +559,29 @@ def collate_packed(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: to
     return X, A
 
 
+def collate_batch(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: torch.Tensor, ld: int, index_host: np.ndarray, pad_id: int,
+                  out_ld: int, y: Optional[torch.Tensor] = None):
+    """collate_packed for a row list that is a HOST array (int64 numpy, what a DataLoader's sampler produced): the indices travel
+    in the kernel's arguments (gtok_collate_batch: no upload) and the labels y[index] come out of the same launch.
+    -> (X int64 [B, out_ld], attn bool [B, out_ld], Y or None)."""
+    _need_gpu(packed, "collate_batch")
+    dev = packed.device
+    idx = np.ascontiguousarray(index_host, dtype=np.int64)
+    B = int(idx.size)
+    X = torch.empty((B, out_ld), dtype=torch.int64, device=dev)
+    A = torch.empty((B, out_ld), dtype=torch.bool, device=dev)
+    Y = None
+    if y is not None:
+        if y.dim() != 1 or not y.is_contiguous() or y.element_size() not in (4, 8):
+            raise ValueError("y must be a contiguous 1-D tensor of 4- or 8-byte elements")
+        Y = torch.empty(B, dtype=y.dtype, device=dev)
+    check(lib().gtok_collate_batch(packed.data_ptr(), packed.element_size(), None if row_ptr is None else row_ptr.data_ptr(), ln.data_ptr(), int(ld),
+                                   idx.ctypes.data, B, int(ln.numel()), int(pad_id), X.data_ptr(), A.data_ptr(), int(out_ld),
+                                   None if y is None else y.data_ptr(), 0 if y is None else y.element_size(), None if Y is None else Y.data_ptr(),
+                                   _stream(dev)), "gtok_collate_batch")
+    return X, A, Y
+
+
 def collate_epoch(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: torch.Tensor, ld: int, order: torch.Tensor, batch_size: int,
                   pad_id: int):
     """Every batch of an epoch collated by ONE call (gtok_collate_epoch): rows `order` (int64, on the device) cut into batches of

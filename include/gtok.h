@@ -31,6 +31,7 @@
  *                      take a [rows, ld] slab of 16-bit ids in place (row_ptr NULL): the per-batch collate of
  *                      trainer/train_agtt.py:276-302 straight over GTOK_SENT_U16 rows
  *   gtok_collate_epoch_plan / gtok_collate_epoch   trainer/train_agtt.py:276-302 for every batch of an epoch at once
+ *   gtok_collate_batch  the same for one batch whose row list is a host array (what torch's DataLoader hands over)
  *   gtok_ids_to_text   graph_data_loader/zinc_dataset_indexbase.py:143-227, the STRING form (ids rendered through a string table)
  *   gtok_zinc_text_tails   zinc_dataset_indexbase.py:186-195, :217-221 (label token + <eos> / the max_len cut, per molecule)
  *   gtok_csr_check     (no reference counterpart; the property torch_geometric's coalesced undirected graphs have by construction -
@@ -414,6 +415,15 @@ int gtok_unpack_rows_u16(const void *packed, int32_t elem_bytes, const int64_t *
  * fit `capacity` were skipped).                                                                                              */
 int gtok_pack_rows_scan(const void *ids, int32_t src_bytes, int32_t ld, const int32_t *len, int64_t num_rows, int32_t align,
                         int32_t elem_bytes, void *packed, int64_t capacity, int64_t *row_ptr, int32_t *status, void *stream);
+
+/* gtok_collate_packed for ONE batch whose row list is on the HOST (ABI v5; the stock torch DataLoader hands a dataset its index
+ * list as Python ints - trainer/train_agtt.py:599-607): host_index[batch] (rows of the slab / packed form, each in [0, num_rows):
+ * checked on the host, GTOK_E_INVAL otherwise) travels in the kernel's arguments - no upload, nothing to synchronise - and the
+ * labels are gathered by the same launch: out_y[b] = y[host_index[b]] for elements of y_bytes (4: float32 / int32, 8: int64)
+ * bytes each, y == NULL = none.  num_rows must fit 31 bits.  Outputs as gtok_collate_packed.                                  */
+int gtok_collate_batch(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len, int32_t ld,
+                       const int64_t *host_index, int32_t batch, int64_t num_rows, int32_t pad_id, int64_t *out_x, uint8_t *out_attn,
+                       int32_t out_ld, const void *y, int32_t y_bytes, void *out_y, void *stream);
 
 /* A whole EPOCH's batches collated by one call (ABI v5; trainer/train_agtt.py:599-607 builds the loader, :276-302 is the collate
  * it replaces): the rows order[0 .. n) of the slab / packed rows (as gtok_collate_packed reads them) are cut into batches of
