@@ -288,3 +288,47 @@ def test_zinc_text_tails_format_labels_as_python_does():
         assert [b[p[r]:p[r + 1]] for r in range(4000)] == want
     with pytest.raises(gtok.GtokError):
         gtok.ops.zinc_text_tails(d_y, d_ln, 0)
+
+
+def test_c_abi_error_codes_of_the_round_5_row_entry_points():
+    """gtok_pack_rows_scan / gtok_unpack_rows_u16 / gtok_collate_batch / gtok_collate_epoch*: bad arguments come back as GTOK_E_*
+    codes before anything is launched; a host index outside the slab never reaches the kernel."""
+    import ctypes
+    L = gtok.lib()
+    ids, ln = _slab(300, 32, seed=5)
+    d_ids, d_ln = torch.from_numpy(ids).to(DEV), torch.from_numpy(ln).to(DEV)
+    d16 = d_ids.to(torch.int16)
+    z = lambda n, dt: torch.empty(n, dtype=dt, device=DEV)
+    packed, ptr, st = z(300 * 32, torch.int16), z(301, torch.int64), z(1, torch.int32)
+    ok = lambda *a: L.gtok_pack_rows_scan(*a, None)
+    assert ok(d16.data_ptr(), 2, 32, d_ln.data_ptr(), 300, 8, 2, packed.data_ptr(), 300 * 32, ptr.data_ptr(), st.data_ptr()) == 0
+    assert ok(d16.data_ptr(), 3, 32, d_ln.data_ptr(), 300, 8, 2, packed.data_ptr(), 300 * 32, ptr.data_ptr(), st.data_ptr()) == -1    # source width
+    assert ok(d16.data_ptr(), 2, 32, d_ln.data_ptr(), 300, 6, 2, packed.data_ptr(), 300 * 32, ptr.data_ptr(), st.data_ptr()) == -1    # align not a power of two
+    assert ok(d_ids.data_ptr(), 4, 32, d_ln.data_ptr(), 300, 8, 8, packed.data_ptr(), 300 * 32, ptr.data_ptr(), st.data_ptr()) == -1  # int64 only from 16-bit rows
+    assert ok(d16.data_ptr(), 2, 32, d_ln.data_ptr(), 300, 8, 2, packed.data_ptr(), 300 * 32, None, st.data_ptr()) == -1
+    assert ok(None, 2, 32, d_ln.data_ptr(), 300, 8, 2, packed.data_ptr(), 300 * 32, ptr.data_ptr(), st.data_ptr()) == -1
+    out16 = z((300, 32), torch.int16)
+    un = lambda pad: L.gtok_unpack_rows_u16(packed.data_ptr(), 2, ptr.data_ptr(), d_ln.data_ptr(), 300, 0, 0, 300 * 32, pad, out16.data_ptr(), 32, None, None)
+    assert un(5) == 0 and un(70000) == -1 and un(-1) == -1
+    assert np.array_equal(out16.cpu().numpy().view(np.uint16).astype(np.int32), np.where(np.arange(32)[None, :] < np.clip(ln, 0, 32)[:, None], ids, 5))
+    X, A = z((4, 32), torch.int64), z((4, 32), torch.bool)
+    idx = (ctypes.c_int64 * 4)(0, 299, 7, 7)
+    cb = lambda ix, rows: L.gtok_collate_batch(d16.data_ptr(), 2, None, d_ln.data_ptr(), 32, ix, 4, rows, 5, X.data_ptr(), A.data_ptr(), 32, None, 0, None, None)
+    assert cb(idx, 300) == 0
+    bad = (ctypes.c_int64 * 4)(0, 300, 7, 7)
+    assert cb(bad, 300) == -1 and cb((ctypes.c_int64 * 4)(0, -1, 7, 7), 300) == -1 and cb(None, 300) == -1
+    lmax, off = z(3, torch.int32), z(4, torch.int64)
+    order = torch.arange(300, device=DEV)
+    assert L.gtok_collate_epoch_plan(d_ln.data_ptr(), 32, order.data_ptr(), 300, 128, lmax.data_ptr(), off.data_ptr(), None) == 0
+    assert L.gtok_collate_epoch_plan(d_ln.data_ptr(), 32, order.data_ptr(), 300, 0, lmax.data_ptr(), off.data_ptr(), None) == -1
+    assert L.gtok_collate_epoch_plan(d_ln.data_ptr(), 32, order.data_ptr(), 300, 128, lmax.data_ptr(), None, None) == -1
+    total = int(off[-1])
+    Xa, Aa = z(total, torch.int64), z(total, torch.bool)
+    ce = lambda eb, arena: L.gtok_collate_epoch(d16.data_ptr(), eb, None, d_ln.data_ptr(), 32, order.data_ptr(), 300, 128, 5, lmax.data_ptr(), off.data_ptr(),
+                                                Xa.data_ptr(), Aa.data_ptr(), arena, None)
+    assert ce(2, total) == 0 and ce(3, total) == -1 and ce(2, -1) == -1
+    # an arena smaller than the plan says: rows that would end beyond it are skipped, nothing is written past it
+    Xa.fill_(-7)
+    assert ce(2, total // 2) == 0
+    torch.cuda.synchronize()
+    assert bool((Xa[total // 2:] == -7).all())
