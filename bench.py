@@ -185,6 +185,14 @@ def boundary_section(d, G, dev, max_nodes, max_len):
                 note="for X, A, Y, data_list in DataLoader(agtt.TokenizedGraphDataset, batch_size=128, shuffle, num_workers=0, collate_fn=agtt.collate_fn): "
                      "batch-level fetch (__getitems__ -> gtok_collate_packed on the 16-bit slab), data_list is a lazy sequence")
 
+        # the same loader with this package's batch sampler in place of `shuffle=True` (one permutation per epoch, cut into lists): the
+        # stock RandomSampler -> BatchSampler chain costs ~38 us per batch of 128 on this host before the dataset is asked for anything
+        dl = DataLoader(ds, batch_sampler=gtok.agtt.EpochBatchSampler(len(ds), 128, shuffle=True), num_workers=0, collate_fn=gtok.agtt.collate_fn)
+        clock(lambda: loader_epoch(dl))
+        t, n = clock(lambda: loader_epoch(dl))
+        out["agtt_dataloader_batch_sampler"] = dict(items_per_sec=round(n / t, 1), batch_size=128, items=n, shuffle=True,
+                                                    note="DataLoader(ds, batch_sampler=agtt.EpochBatchSampler(len(ds), 128, shuffle=True), num_workers=0, collate_fn=agtt.collate_fn)")
+
         def batches(with_data, bs=128):
             n = 0
             for X, A, Y, dl in ds.device_batches(bs, epoch=7, with_data=with_data):

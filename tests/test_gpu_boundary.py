@@ -404,6 +404,16 @@ def test_device_batches_collate_the_epoch_in_one_call_and_the_slab_follows_the_t
     # a batch with a duplicated index: per-item path (two fetches of an item are two trails), no exception
     out = ds.__getitems__([3, 3, 9])
     assert isinstance(out, list) and len(out) == 3 and out[0][0].dtype == torch.long
+    # the package's batch sampler: one permutation per epoch cut into index lists - every item once, short last batch, drop_last
+    bsamp = agtt.EpochBatchSampler(G, 96, shuffle=True, generator=torch.Generator().manual_seed(4))
+    lists = list(bsamp)
+    assert len(lists) == len(bsamp) == -(-G // 96) and sorted(i for l in lists for i in l) == list(range(G)) and len(lists[-1]) == G % 96
+    assert len(list(agtt.EpochBatchSampler(G, 96, drop_last=True))) == G // 96 and list(agtt.EpochBatchSampler(5, 2))[-1] == [4]
+    seen = 0
+    for X, A, Y, datas in DataLoader(ds, batch_sampler=agtt.EpochBatchSampler(G, 96, shuffle=True), num_workers=0, collate_fn=agtt.collate_fn):
+        assert X.is_cuda and X.shape[0] == len(datas) == Y.shape[0] and abs(float(Y[0]) - float(datas[0].y)) < 1e-6
+        seen += X.shape[0]
+    assert seen == G
     # (pin_memory=True is not supported over device batches - the loader pins what collate_fn returns, and CUDA tensors cannot be
     # pinned; the reference's loaders do not set it, INTEGRATION.md says so.)  The fetcher's own object passes a pin request through:
     cb = ds.__getitems__([1, 2, 5])
