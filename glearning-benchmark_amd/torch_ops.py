@@ -5,6 +5,7 @@ The ops take the batched-CSR arrays as plain tensors (layout: include/gtok.h); `
 GraphBatch-level wrappers, both end in the same C-ABI calls.  Fake (meta) implementations give output shapes,
 so the ops trace under torch.compile / FakeTensor without touching the GPU.
 """
+import sys
 import weakref
 from typing import List, Optional, Tuple
 
@@ -22,7 +23,7 @@ from .csr import GraphBatch
 # that have died or were written to in place do not.  (Round 4 built a fresh flags=0 batch per call: the op then ran
 # sent_reg_kernel on ZINC - 8 x the time of the benchmarked sent_lane_kernel - and rebuilt the bit-matrix mirror every call.)
 _BATCHES: "dict[tuple, tuple]" = {}
-_BATCHES_MAX = 16
+_BATCHES_MAX = 8
 _PREPARED: "dict[tuple, tuple]" = {}      # the same for batches the caller prepared (csr_prepare outputs passed back in)
 
 
@@ -41,10 +42,38 @@ def _batch(node_ptr, edge_ptr, rowptr, col, eorder, nattr, eattr, max_nodes, max
     b = GraphBatch(int(node_ptr.numel()) - 1, max_nodes, max_edges, node_ptr, edge_ptr, rowptr, col, eorder, nattr, eattr)
     if verify:
         _verify(b)
+    _purge(_BATCHES)
     if len(_BATCHES) >= _BATCHES_MAX:
         _BATCHES.pop(next(iter(_BATCHES)))
     _BATCHES[key] = (tuple(None if t is None else weakref.ref(t) for t in ts), tuple(None if t is None else t._version for t in ts), b)
     return b
+
+
+def _purge(cache: dict) -> None:
+    """Drop the entries nobody else can use any more.  A cached batch holds its input tensors (its C struct points into them), so a
+    weak reference alone never dies; what tells a dead entry is that the batch object is the ONLY holder left of every one of its
+    tensors (reference count: the cached batches' fields + this loop's variable + getrefcount's argument).  Without this a caller that
+    tokenizes corpus after corpus through the raw-tensor ops would keep up to _BATCHES_MAX dead corpora resident."""
+    names = ("node_ptr", "edge_ptr", "rowptr", "col", "eorder", "nattr", "eattr", "graph_ids", "unit_ptr")
+    in_cache: dict = {}                       # tensor -> how many cached batches hold it (two entries may share their tensors)
+    for entry in cache.values():
+        for n in names:
+            t = getattr(entry[-1], n)
+            if t is not None:
+                in_cache[id(t)] = in_cache.get(id(t), 0) + 1
+            del t
+    for key in list(cache):
+        b = cache[key][-1]
+        fields = [getattr(b, n) for n in names]
+        held = False
+        while fields:
+            t = fields.pop()
+            if t is not None and sys.getrefcount(t) > 2 + in_cache[id(t)]:
+                held = True
+                break
+            del t
+        if not held:
+            del cache[key]
 
 
 def _verify(b: GraphBatch) -> None:
@@ -85,6 +114,7 @@ def _prepared_batch(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes, ma
     if adj_rows is not None:
         b.adj_rows, b.adj_planes, b.lane_order = adj_rows, adj_planes, lane_order
         b.adj_words, b.adj_max_degree = L["adj_words"], L["adj_max_degree"]
+    _purge(_PREPARED)
     if len(_PREPARED) >= _BATCHES_MAX:
         _PREPARED.pop(next(iter(_PREPARED)))
     _PREPARED[key] = (tuple(None if t is None else weakref.ref(t) for t in ts), b)

@@ -346,3 +346,27 @@ def test_bench_ends_every_rank_when_one_fails_while_rank_0_would_wait(tmp_path):
                 break
             _time.sleep(0.1)
         assert gone, "rank 0 is still running after the parent returned"
+
+
+def test_raw_tensor_op_cache_finds_live_batches_and_drops_dead_ones():
+    """torch.ops.gtok.sent without prepared arrays keeps the batch it prepares per set of tensor objects (identity + version
+    counters).  The cache must find a live batch again, miss after an in-place write, and not keep a corpus alive that only the
+    cache itself still references (host logic: no GPU needed)."""
+    import gc
+    to = gtok.torch_ops
+    to._BATCHES.clear()
+    mk = lambda n: (torch.zeros(n + 1, dtype=torch.int32), torch.zeros(n + 1, dtype=torch.int64), torch.zeros(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int32))
+    a, c = mk(5), mk(6)
+    b1 = to._batch(*a, None, None, None, 3, 3)
+    assert to._batch(*a, None, None, None, 3, 3) is b1 and len(to._BATCHES) == 1
+    assert to._batch(*a, None, None, None, 4, 3) is not b1            # other maxima: another batch
+    b2 = to._batch(*c, None, None, None, 3, 3)
+    n_before = len(to._BATCHES)
+    del b1, a
+    gc.collect()
+    d = mk(7)
+    to._batch(*d, None, None, None, 3, 3)                              # a miss purges what nobody else holds
+    assert len(to._BATCHES) == n_before - 2 + 1                        # both entries of `a` gone, `d` added
+    c[3].add_(1)                                                       # written in place: not the batch that was prepared
+    assert to._batch(*c, None, None, None, 3, 3) is not b2
+    to._BATCHES.clear()
