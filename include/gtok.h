@@ -93,7 +93,7 @@ extern "C" {
 #define GTOK_E_NO_DEVICE (-4) /* no gfx950 device visible                       */
 #define GTOK_E_GRAPH_SLOTS (-5) /* a launch captured into a hipGraph needed a reserved block of work-queue counters and all 64
                                    per device are held by LIVE graphs: the ticket-scheduled kernels ("sent_lds_kernel",
-                                   "ibtt_zinc_lane_kernel") keep one per captured launch for as long as the capturing graph
+                                   "sent_blane_kernel", "ibtt_zinc_lane_kernel", gtok_pack_rows_scan) keep one per captured launch for as long as the capturing graph
                                    (and the executable graphs made from it) exist - destroying a graph returns its blocks   */
 
 #define GTOK_MAX_NODES 512 /* SENT adjacency bit-matrix rows per wave (LDS)  */
