@@ -332,3 +332,30 @@ def test_c_abi_error_codes_of_the_round_5_row_entry_points():
     assert ce(2, total // 2) == 0
     torch.cuda.synchronize()
     assert bool((Xa[total // 2:] == -7).all())
+
+
+def test_pack_rows_scan_with_several_tiles_per_ticket_and_large_host_batches(monkeypatch):
+    """The chunked-ticket path of gtok_pack_rows_scan (several tiles per workgroup: what slabs beyond ~500 k rows get) forced on a
+    small slab, and gtok_collate_batch with more indices than one launch's arguments hold (512)."""
+    ids, ln = _slab(5000, 40, seed=77, long_rows=True)
+    d_ln = torch.from_numpy(ln).to(DEV)
+    d16 = torch.from_numpy(ids).to(DEV).to(torch.int16)
+    want_ptr = orc.row_offsets(ln, 40, 8)
+    n = np.clip(ln, 0, 40)
+    for chunk in ("3", "8"):
+        monkeypatch.setenv("GTOK_PACK_CHUNK", chunk)
+        for tile in ("64", "256"):
+            monkeypatch.setenv("GTOK_PACK_TILE", tile)
+            packed, ptr, st = gtok.ops.pack_rows_scan(d16, d_ln, 2, int(want_ptr[-1]) + 8)
+            assert int(st.item()) == 0 and np.array_equal(ptr.cpu().numpy(), want_ptr), (chunk, tile)
+            got = packed.cpu().numpy().view(np.uint16)
+            for r in range(0, 5000, 7):
+                assert np.array_equal(got[want_ptr[r]:want_ptr[r] + n[r]].astype(np.int64), ids[r, :n[r]]), (chunk, tile, r)
+    monkeypatch.delenv("GTOK_PACK_CHUNK"); monkeypatch.delenv("GTOK_PACK_TILE")
+    idx = np.random.default_rng(1).integers(0, 5000, 1300).astype(np.int64)
+    y = torch.arange(5000, dtype=torch.float32, device=DEV) * 0.5
+    X, A, Y = gtok.ops.collate_batch(d16, None, d_ln, 40, idx, 5, 40, y)
+    Xr, Ar = gtok.ops.collate_packed(d16, None, d_ln, 40, torch.from_numpy(idx).to(DEV), 5, 40)
+    assert torch.equal(X, Xr) and torch.equal(A, Ar) and torch.equal(Y, y[torch.from_numpy(idx).to(DEV)])
+    yl = torch.arange(5000, dtype=torch.int64, device=DEV) * 3
+    assert torch.equal(gtok.ops.collate_batch(d16, None, d_ln, 40, idx[:5], 5, 16, yl)[2], yl[torch.from_numpy(idx[:5]).to(DEV)])
