@@ -804,101 +804,114 @@ def main():
                                                 frac=round(tbytes / tk / 1e9 / HBM_PEAK_GBS, 5), traffic=None,
                                                 algorithmic_bytes_per_launch=int(tbytes)))
 
-    # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
-    if multi:
-        log("[bench] all-gather legs")
-        gtok.dist.gather_tokens(ids[:G], lens[-1], world * G, 5, force=True)
-        torch.cuda.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
+    # The two exchange legs run last among the multi-rank work and must never cost the run its headline line: an error that every
+    # rank hits alike (a Python-level failure) is recorded in the line instead of raised.  (A rank that fails ALONE inside a
+    # collective still ends the run - the others wait until the process group's timeout.)
+    def exchange_legs():
+        # reassembling the padded slab on every rank: one RCCL all-gather over xGMI, timed on its own
+        if multi:
+            log("[bench] all-gather legs")
             gtok.dist.gather_tokens(ids[:G], lens[-1], world * G, 5, force=True)
-        torch.cuda.synchronize(); dist.barrier()
-        ag = (time.perf_counter() - t0) / reps
-        agt = torch.tensor([ag], dtype=torch.float64, device=dev)
-        dist.all_reduce(agt, op=dist.ReduceOp.MAX)
-        recv = (world - 1) * G * (ld + 1) * 4
-        out["allgather"] = dict(ms=round(float(agt.item()) * 1e3, 3), bytes_received_per_gpu=recv,
-                                bytes_gathered_per_gpu=world * G * (ld + 1) * 4,
-                                GBps_per_gpu=round(world * G * (ld + 1) * 4 / float(agt.item()) / 1e9, 2))
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                gtok.dist.gather_tokens(ids[:G], lens[-1], world * G, 5, force=True)
+            torch.cuda.synchronize(); dist.barrier()
+            ag = (time.perf_counter() - t0) / reps
+            agt = torch.tensor([ag], dtype=torch.float64, device=dev)
+            dist.all_reduce(agt, op=dist.ReduceOp.MAX)
+            recv = (world - 1) * G * (ld + 1) * 4
+            out["allgather"] = dict(ms=round(float(agt.item()) * 1e3, 3), bytes_received_per_gpu=recv,
+                                    bytes_gathered_per_gpu=world * G * (ld + 1) * 4,
+                                    GBps_per_gpu=round(world * G * (ld + 1) * 4 / float(agt.item()) / 1e9, 2))
 
-    # BASELINE config 4 as configured: ONE ZINC-full corpus block-sharded over the ranks (strong scaling), each rank
-    # tokenizes its block with graph_base = the block's first global index, one all-gather reassembles the padded slab
-    # on every rank.  Reported beside the weak-scaling line above (the driver computes efficiency from `value`).
-    if multi and zinc and (args.scaling == "strong" or os.environ.get("GTOK_BENCH_STRONG", "1") == "1"):
-        Gt = args.graphs or wl["graphs"]
-        dc = gtok.synth.zinc_like(Gt, seed=1000)                      # the same corpus on every rank
-        whole = gtok.GraphBatch.from_coo_device(dc["node_counts"], dc["edge_counts"], dc["src"], dc["dst"], dc["x"], dc["edge_attr"], device=dev)
-        mine, lo, hi = gtok.dist.shard_of(whole, rank, world)
-        del whole
-        gtok.ops.pack8(mine)
-        kws = dict(kw, graph_base=lo)
-        # K epochs per launch (round 4): a rank's 31 k-molecule share cannot fill the chip for one epoch (0.065 ms against
-        # 0.076 ms for the whole corpus on one GPU), Es epochs of it can - and ONE exchange then carries Es epochs of rows.
-        # Rows leave the walk as 16-bit ids without padding; the compact exchange packs them as they are.  Each rank's
-        # buffer is [Es, per, ld] (epoch-major); the gathered slab is rank-major: epoch e of graph g sits at row
-        # ((g // per) * Es + e) * per + g % per - consumers index it (gtok_collate takes any row list).
-        Gs, per = hi - lo, -(-Gt // world)
-        Es = gtok.Graph2TrailTokenizer.epochs_for_shape(Gs, ld) if Gt % world == 0 else 1
-        if os.environ.get("GTOK_BENCH_STRONG_EPOCHS"):
-            Es = max(1, int(os.environ["GTOK_BENCH_STRONG_EPOCHS"]))
-        sids = torch.empty((Es * Gs, ld), dtype=torch.int16, device=dev)
-        sln = torch.empty((Es * Gs,), dtype=torch.int32, device=dev)
-        gstats = {}
+        # BASELINE config 4 as configured: ONE ZINC-full corpus block-sharded over the ranks (strong scaling), each rank
+        # tokenizes its block with graph_base = the block's first global index, one all-gather reassembles the padded slab
+        # on every rank.  Reported beside the weak-scaling line above (the driver computes efficiency from `value`).
+        if multi and zinc and (args.scaling == "strong" or os.environ.get("GTOK_BENCH_STRONG", "1") == "1"):
+            Gt = args.graphs or wl["graphs"]
+            dc = gtok.synth.zinc_like(Gt, seed=1000)                      # the same corpus on every rank
+            whole = gtok.GraphBatch.from_coo_device(dc["node_counts"], dc["edge_counts"], dc["src"], dc["dst"], dc["x"], dc["edge_attr"], device=dev)
+            mine, lo, hi = gtok.dist.shard_of(whole, rank, world)
+            del whole
+            gtok.ops.pack8(mine)
+            kws = dict(kw, graph_base=lo)
+            # K epochs per launch (round 4): a rank's 31 k-molecule share cannot fill the chip for one epoch (0.065 ms against
+            # 0.076 ms for the whole corpus on one GPU), Es epochs of it can - and ONE exchange then carries Es epochs of rows.
+            # Rows leave the walk as 16-bit ids without padding; the compact exchange packs them as they are.  Each rank's
+            # buffer is [Es, per, ld] (epoch-major); the gathered slab is rank-major: epoch e of graph g sits at row
+            # ((g // per) * Es + e) * per + g % per - consumers index it (gtok_collate takes any row list).
+            Gs, per = hi - lo, -(-Gt // world)
+            Es = gtok.Graph2TrailTokenizer.epochs_for_shape(Gs, ld) if Gt % world == 0 else 1
+            if os.environ.get("GTOK_BENCH_STRONG_EPOCHS"):
+                Es = max(1, int(os.environ["GTOK_BENCH_STRONG_EPOCHS"]))
+            sids = torch.empty((Es * Gs, ld), dtype=torch.int16, device=dev)
+            sln = torch.empty((Es * Gs,), dtype=torch.int32, device=dev)
+            gstats = {}
 
-        def sstep(k, gather):
-            gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k * Es, ld=ld, out=(sids, sln), pad=False, epochs=Es, u16=True, **kws)
-            if gather == "padded":      # the 16-bit slab as it is (pad tails and all: they are not written, the bytes still travel)
-                return gtok.dist.gather_tokens(sids, sln, Gt * Es, 5, force=True, stats=gstats.setdefault("padded", {}))
-            if gather == "compact":    # capacity = the first launch's largest rank + 2 %: no size exchange, no host round trip
-                return gtok.dist.gather_tokens(sids, sln, Gt * Es, 5, force=True, compact=True, capacity=gstats.get("cap"),
-                                               stats=gstats.setdefault("compact", {}))
-        res = {}
-        n_sl = max(2, -(-args.steps // Es))
-        for gather in (None, "padded", "compact"):
-            if gather == "compact":
-                sstep(0, gather)                              # sized by an all-reduce once ...
-                gstats["cap"] = int(gstats["compact"]["capacity"] * 1.02) + 64      # ... then a fixed bound
-            for w in range(max(1, args.warmup // Es)):
-                sstep(w, gather)
-            swall, _ = timed_loop(lambda k: sstep(args.warmup + k, gather), n_sl, True)
-            tm = torch.tensor([swall], dtype=torch.float64, device=dev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            res[gather] = float(tm.item())
-        if int(sln.max().item()) > ld:
-            raise SystemExit("strong-scaling leg: slab too narrow")
-        # the compact exchange must give the padded one's rows (checked on the last launch's buffers, inside the row lengths:
-        # the 16-bit slab travels without its pad tails written)
-        p_ids, p_ln = sstep(args.warmup, "padded")
-        c_ids, c_ln = sstep(args.warmup, "compact")
-        inside = torch.arange(ld, device=dev)[None, :] < c_ln[:, None]
-        same = bool(c_ids.dtype == p_ids.dtype and torch.equal(p_ln, c_ln) and torch.equal(torch.where(inside, p_ids, 0), torch.where(inside, c_ids, 0))
-                    and bool((c_ids[~inside] == 5).all())) and int(gstats["compact"]["status"].item()) == 0
-        epochs_timed = n_sl * Es
-        per_epoch = lambda t: round(t / epochs_timed * 1e3, 5)
-        out["strong_scaling"] = dict(
-            workload=f"one {Gt}-graph corpus block-sharded x{world} (graphs_per_gpu {Gs}), {Es} epochs per launch and per exchange, kernel "
-                     f"{gtok.ops.sent_kernel_name(mine, max_nodes, max_len, labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True, epochs=Es)}",
-            epochs_per_launch=Es, launches_timed=n_sl,
-            tokenize_graphs_per_sec=round(Gt * epochs_timed / res[None], 1), tokenize_ms_per_epoch=per_epoch(res[None]),
-            tokenize_and_allgather_graphs_per_sec=round(Gt * epochs_timed / res["compact"], 1),
-            tokenize_and_allgather_ms_per_epoch=per_epoch(res["compact"]),
-            exchange="compact: 16-bit rows straight from the walk, packed in one pass (gtok_pack_rows_scan) + lengths over RCCL, re-padded locally "
-                     "into a 16-bit slab (gtok_unpack_rows_u16; dist.gather_tokens(compact=True)); one exchange per launch = per Es epochs",
-            compact=dict(ms_per_epoch=per_epoch(res["compact"]), exchange_ms_per_epoch=per_epoch(res["compact"] - res[None]),
-                         bytes_sent_per_rank_per_epoch=gstats["compact"]["bytes_sent_per_rank"] // Es,
-                         bytes_gathered_per_rank_per_epoch=world * gstats["compact"]["bytes_sent_per_rank"] // Es),
-            padded=dict(ms_per_epoch=per_epoch(res["padded"]), exchange_ms_per_epoch=per_epoch(res["padded"] - res[None]),
-                        bytes_sent_per_rank_per_epoch=gstats["padded"]["bytes_sent_per_rank"] // Es,
-                        bytes_gathered_per_rank_per_epoch=world * gstats["padded"]["bytes_sent_per_rank"] // Es,
-                        note="the 16-bit slab [Es, per, ld] as it is (half the bytes of round 3's int32 slab)"),
-            compact_equals_padded=same, gathered_slab_bytes_per_epoch=int(Gt) * (ld * 2 + 4),
-            note="no N > 1 run exists until a SCALE record does: with one rank (GTOK_BENCH_FORCE_DIST=1) the collective is a device-local copy")
-        if args.scaling == "strong":      # make the configured workload the headline of this run
-            out.update(value=out["strong_scaling"]["tokenize_and_allgather_graphs_per_sec"], scaling="strong",
-                       ms_per_step=out["strong_scaling"]["tokenize_and_allgather_ms_per_epoch"])
-            out["config"]["parallelism"] = f"one corpus block-sharded x{world} + RCCL all-gather of the padded slab"
-            out["config"]["graphs_per_gpu"] = hi - lo
+            def sstep(k, gather):
+                gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k * Es, ld=ld, out=(sids, sln), pad=False, epochs=Es, u16=True, **kws)
+                if gather == "padded":      # the 16-bit slab as it is (pad tails and all: they are not written, the bytes still travel)
+                    return gtok.dist.gather_tokens(sids, sln, Gt * Es, 5, force=True, stats=gstats.setdefault("padded", {}))
+                if gather == "compact":    # capacity = the first launch's largest rank + 2 %: no size exchange, no host round trip
+                    return gtok.dist.gather_tokens(sids, sln, Gt * Es, 5, force=True, compact=True, capacity=gstats.get("cap"),
+                                                   stats=gstats.setdefault("compact", {}))
+            res = {}
+            n_sl = max(2, -(-args.steps // Es))
+            for gather in (None, "padded", "compact"):
+                if gather == "compact":
+                    sstep(0, gather)                              # sized by an all-reduce once ...
+                    gstats["cap"] = int(gstats["compact"]["capacity"] * 1.02) + 64      # ... then a fixed bound
+                for w in range(max(1, args.warmup // Es)):
+                    sstep(w, gather)
+                swall, _ = timed_loop(lambda k: sstep(args.warmup + k, gather), n_sl, True)
+                tm = torch.tensor([swall], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                res[gather] = float(tm.item())
+            if int(sln.max().item()) > ld:
+                raise SystemExit("strong-scaling leg: slab too narrow")
+            # the compact exchange must give the padded one's rows (checked on the last launch's buffers, inside the row lengths:
+            # the 16-bit slab travels without its pad tails written)
+            p_ids, p_ln = sstep(args.warmup, "padded")
+            c_ids, c_ln = sstep(args.warmup, "compact")
+            inside = torch.arange(ld, device=dev)[None, :] < c_ln[:, None]
+            same = bool(c_ids.dtype == p_ids.dtype and torch.equal(p_ln, c_ln) and torch.equal(torch.where(inside, p_ids, 0), torch.where(inside, c_ids, 0))
+                        and bool((c_ids[~inside] == 5).all())) and int(gstats["compact"]["status"].item()) == 0
+            epochs_timed = n_sl * Es
+            per_epoch = lambda t: round(t / epochs_timed * 1e3, 5)
+            out["strong_scaling"] = dict(
+                workload=f"one {Gt}-graph corpus block-sharded x{world} (graphs_per_gpu {Gs}), {Es} epochs per launch and per exchange, kernel "
+                         f"{gtok.ops.sent_kernel_name(mine, max_nodes, max_len, labeled=True, num_node_types=ntypes, num_edge_types=etypes, remap_zinc=True, epochs=Es)}",
+                epochs_per_launch=Es, launches_timed=n_sl,
+                tokenize_graphs_per_sec=round(Gt * epochs_timed / res[None], 1), tokenize_ms_per_epoch=per_epoch(res[None]),
+                tokenize_and_allgather_graphs_per_sec=round(Gt * epochs_timed / res["compact"], 1),
+                tokenize_and_allgather_ms_per_epoch=per_epoch(res["compact"]),
+                exchange="compact: 16-bit rows straight from the walk, packed in one pass (gtok_pack_rows_scan) + lengths over RCCL, re-padded locally "
+                         "into a 16-bit slab (gtok_unpack_rows_u16; dist.gather_tokens(compact=True)); one exchange per launch = per Es epochs",
+                compact=dict(ms_per_epoch=per_epoch(res["compact"]), exchange_ms_per_epoch=per_epoch(res["compact"] - res[None]),
+                             bytes_sent_per_rank_per_epoch=gstats["compact"]["bytes_sent_per_rank"] // Es,
+                             bytes_gathered_per_rank_per_epoch=world * gstats["compact"]["bytes_sent_per_rank"] // Es),
+                padded=dict(ms_per_epoch=per_epoch(res["padded"]), exchange_ms_per_epoch=per_epoch(res["padded"] - res[None]),
+                            bytes_sent_per_rank_per_epoch=gstats["padded"]["bytes_sent_per_rank"] // Es,
+                            bytes_gathered_per_rank_per_epoch=world * gstats["padded"]["bytes_sent_per_rank"] // Es,
+                            note="the 16-bit slab [Es, per, ld] as it is (half the bytes of round 3's int32 slab)"),
+                compact_equals_padded=same, gathered_slab_bytes_per_epoch=int(Gt) * (ld * 2 + 4),
+                note="no N > 1 run exists until a SCALE record does: with one rank (GTOK_BENCH_FORCE_DIST=1) the collective is a device-local copy")
+            if args.scaling == "strong":      # make the configured workload the headline of this run
+                out.update(value=out["strong_scaling"]["tokenize_and_allgather_graphs_per_sec"], scaling="strong",
+                           ms_per_step=out["strong_scaling"]["tokenize_and_allgather_ms_per_epoch"])
+                out["config"]["parallelism"] = f"one corpus block-sharded x{world} + RCCL all-gather of the padded slab"
+                out["config"]["graphs_per_gpu"] = hi - lo
+
+    try:
+        exchange_legs()
+    except SystemExit:
+        raise
+    except Exception as ex:
+        import traceback
+        traceback.print_exc()
+        out["exchange_legs_error"] = f"{type(ex).__name__}: {ex}"
 
     # throughput through the Dataset classes the trainers call (not the kernels): rank 0, N=1, ZINC-shaped workloads
     if rank == 0 and world == 1 and zinc and not args.no_boundary:
