@@ -387,12 +387,12 @@ def main():
     def step(k, ln):          # ONE epoch in one launch (secondary legs and the end-of-run parity check)
         gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=k, ld=ld, out=(ids[:G], ln.view(-1)[:G]), pad=rows_pad, u16=rows_u16, **kw)
 
-    def launch(j, ln, count=E, first=None, pad=None, u16=None, out_ids=None):
+    def launch(j, ln, count=E, first=None, pad=None, u16=None, out_ids=None, packed=None, slab=True):
         """epochs first .. first + count - 1 (default: launch j of the timed region) in one gtok_sent call"""
         o = ids if out_ids is None else out_ids
-        gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=j * E if first is None else first, ld=ld,
-                      out=(o[:count * G], ln.view(-1)[:count * G]), pad=rows_pad if pad is None else pad, epochs=count,
-                      u16=(rows_u16 if out_ids is None else True) if u16 is None else u16, **kw)
+        return gtok.ops.sent(batch, max_nodes, max_len, seed=0, epoch=j * E if first is None else first, ld=ld,
+                             out=(o[:count * G], ln.view(-1)[:count * G]) if slab else None, pad=rows_pad if pad is None else pad, epochs=count,
+                             u16=(rows_u16 if out_ids is None else True) if u16 is None else u16, packed=packed, slab=slab, **kw)
 
     def timed_launches(first_epoch):
         """the K steps: n_launch calls, epochs first_epoch .. first_epoch + K - 1, lengths of step k in lens_all[k]"""
@@ -438,7 +438,7 @@ def main():
     wall = float(tmax.item())
     # beside the headline: the same steps with GTOK_SENT_NO_PAD (rows written up to their length only - what
     # TokenizedGraphDataset uses, its readers go through `len`); not the headline because the C ABI's documented output is the padded slab
-    nopad_ms = ragged = u16_ms = u16p_ms = ragged16 = ragged16_two = epoch_loop = None
+    nopad_ms = ragged = u16_ms = u16p_ms = ragged16 = ragged16_two = ragged16_scan = ragged16_slab = epoch_loop = None
     if zinc and not args.no_unpadded and not rows_u16:
         per_step = lambda ms: float(np.sum(ms)) / (n_launch * E)
         _, npm = timed_loop(lambda j: launch(j, scratch_len, pad=False), n_launch, multi, per_launch_events=False)
@@ -461,12 +461,34 @@ def main():
         _, rgm = timed_loop(ragged_step, n_launch, multi, per_launch_events=False)
         ragged = per_step(rgm)
 
-        def ragged16_step(k):        # offsets + packing in one pass (gtok_pack_rows_scan: the capacity is known before the sizes are)
+        def ragged16_scan_step(k):   # offsets + packing in one pass (gtok_pack_rows_scan: the capacity is known before the sizes are)
             launch(k, scratch_len, pad=False, u16=True, out_ids=ids16)
             return gtok.ops.pack_rows_u16(ids16, scratch_len, None, elem_bytes=2, capacity=E * G * ld, check_status=False)
+        ragged16_scan_step(0)
+        _, rgm = timed_loop(ragged16_scan_step, n_launch, multi, per_launch_events=False)
+        ragged16_scan = per_step(rgm)
+
+        # the walk packs its rows itself (gtok_sent_packed, ABI v6): no second pass; the buffer is sized from the first launch + 4 %
+        launch(0, scratch_len, pad=False, u16=True, out_ids=ids16)
+        need = int(((scratch_len.view(-1)[:E * G].clamp(0, ld) + 7) // 8 * 8).sum().item())
+        pk = gtok.ops.PackedRows(E * G, int(need * 1.04) + 4096, True, dev)
+
+        def ragged16_slab_step(k):   # ... beside the 16-bit slab
+            launch(k, scratch_len, pad=False, u16=True, out_ids=ids16, packed=pk)
+        ragged16_slab_step(0)
+        if not pk.fused or int(pk.status().item()):
+            raise SystemExit(f"packed rows leg: fused {pk.fused}, status {int(pk.status().item())}")
+        _, rgm = timed_loop(ragged16_slab_step, n_launch, multi, per_launch_events=False)
+        ragged16_slab = per_step(rgm)
+
+        def ragged16_step(k):        # ... alone (GTOK_SENT_PACK_ONLY: no slab, the rows are staged in 64 rows per resident wave)
+            launch(k, scratch_len, u16=True, packed=pk, slab=False)
         ragged16_step(0)
+        if not pk.fused or int(pk.status().item()):
+            raise SystemExit(f"packed rows leg: fused {pk.fused}, status {int(pk.status().item())}")
         _, rgm = timed_loop(ragged16_step, n_launch, multi, per_launch_events=False)
         ragged16 = per_step(rgm)
+        del pk
 
         def ragged16_two_step(k):    # round 4's route: gtok_row_offsets (three launches) + gtok_pack_rows_u16
             launch(k, scratch_len, pad=False, u16=True, out_ids=ids16)
@@ -692,10 +714,15 @@ def main():
                                        "(the round-3 route to gtok_collate_packed / the compact exchange)")
         out["u16_rows"] = dict(unpadded_ms_per_step=round(u16_ms, 4), unpadded_graphs_per_sec=round(G / u16_ms * 1e3, 1),
                                padded_ms_per_step=round(u16p_ms, 4), padded_graphs_per_sec=round(G / u16p_ms * 1e3, 1),
-                               packed_ms_per_step=round(ragged16, 4), packed_two_pass_ms_per_step=round(ragged16_two, 4),
+                               packed_ms_per_step=round(ragged16, 4), packed_beside_slab_ms_per_step=round(ragged16_slab, 4),
+                               packed_scan_ms_per_step=round(ragged16_scan, 4),
+                               packed_two_pass_ms_per_step=round(ragged16_two, 4),
                                note="GTOK_SENT_U16: rows of 16-bit ids straight from the walk's token windows (no unpacking, half the bytes); "
                                     "unpadded = + GTOK_SENT_NO_PAD: what TokenizedGraphDataset / gtok_collate_packed(row_ptr NULL) / EpochRows read in place, "
-                                    "no second pass; packed = + gtok_pack_rows_scan (offsets + 16-bit rows back to back in one pass: the compact all-gather's payload); "
+                                    "no second pass; packed = gtok_sent_packed + GTOK_SENT_PACK_ONLY: the walk appends every finished unit's rows to a packed buffer (row starts "
+                                    "beside the lengths: the compact all-gather's payload, no second pass, no slab - rows are staged in 64 rows per resident wave; "
+                                    "zeroing the 8 KB of fill marks is inside the figure); packed_beside_slab = gtok_sent_packed writing the unpadded 16-bit slab as well; "
+                                    "packed_scan = unpadded + gtok_pack_rows_scan (offsets + rows back to back in dataset order in one pass); "
                                     "packed_two_pass = + gtok_row_offsets + gtok_pack_rows_u16 (round 4's route, four launches)")
     if epoch_loop is not None:
         out["epoch_loop"] = epoch_loop
@@ -849,20 +876,26 @@ def main():
             sids = torch.empty((Es * Gs, ld), dtype=torch.int16, device=dev)
             sln = torch.empty((Es * Gs,), dtype=torch.int32, device=dev)
             gstats = {}
+            spk = {}
 
             def sstep(k, gather):
+                if gather == "compact":    # the walk packs the rows itself and writes no slab (gtok_sent_packed, GTOK_SENT_PACK_ONLY); capacity = the first launch's largest rank + 4 %
+                    _, cln = gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k * Es, ld=ld, epochs=Es, u16=True, packed=spk["pk"], slab=False, **kws)
+                    return gtok.dist.gather_tokens(None, cln.reshape(-1), Gt * Es, 5, force=True, compact=True, packed=spk["pk"], ld=ld,
+                                                   stats=gstats.setdefault("compact", {}))
                 gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k * Es, ld=ld, out=(sids, sln), pad=False, epochs=Es, u16=True, **kws)
                 if gather == "padded":      # the 16-bit slab as it is (pad tails and all: they are not written, the bytes still travel)
                     return gtok.dist.gather_tokens(sids, sln, Gt * Es, 5, force=True, stats=gstats.setdefault("padded", {}))
-                if gather == "compact":    # capacity = the first launch's largest rank + 2 %: no size exchange, no host round trip
+                if gather == "compact_scan":    # round 5's first route: pack in a second pass (gtok_pack_rows_scan), capacity as below
                     return gtok.dist.gather_tokens(sids, sln, Gt * Es, 5, force=True, compact=True, capacity=gstats.get("cap"),
-                                                   stats=gstats.setdefault("compact", {}))
+                                                   stats=gstats.setdefault("compact_scan", {}))
             res = {}
             n_sl = max(2, -(-args.steps // Es))
-            for gather in (None, "padded", "compact"):
-                if gather == "compact":
+            for gather in (None, "padded", "compact_scan", "compact"):
+                if gather == "compact_scan":
                     sstep(0, gather)                              # sized by an all-reduce once ...
-                    gstats["cap"] = int(gstats["compact"]["capacity"] * 1.02) + 64      # ... then a fixed bound
+                    gstats["cap"] = int(gstats["compact_scan"]["capacity"] * 1.04) + 4096      # ... then a fixed bound, the same on every rank
+                    spk["pk"] = gtok.ops.PackedRows(Es * Gs, gstats["cap"], True, dev)
                 for w in range(max(1, args.warmup // Es)):
                     sstep(w, gather)
                 swall, _ = timed_loop(lambda k: sstep(args.warmup + k, gather), n_sl, True)
@@ -878,6 +911,8 @@ def main():
             inside = torch.arange(ld, device=dev)[None, :] < c_ln[:, None]
             same = bool(c_ids.dtype == p_ids.dtype and torch.equal(p_ln, c_ln) and torch.equal(torch.where(inside, p_ids, 0), torch.where(inside, c_ids, 0))
                         and bool((c_ids[~inside] == 5).all())) and int(gstats["compact"]["status"].item()) == 0
+            s_ids, s_ln = sstep(args.warmup, "compact_scan")
+            same = same and torch.equal(s_ln, c_ln) and torch.equal(s_ids, c_ids) and int(gstats["compact_scan"]["status"].item()) == 0
             epochs_timed = n_sl * Es
             per_epoch = lambda t: round(t / epochs_timed * 1e3, 5)
             out["strong_scaling"] = dict(
@@ -887,11 +922,15 @@ def main():
                 tokenize_graphs_per_sec=round(Gt * epochs_timed / res[None], 1), tokenize_ms_per_epoch=per_epoch(res[None]),
                 tokenize_and_allgather_graphs_per_sec=round(Gt * epochs_timed / res["compact"], 1),
                 tokenize_and_allgather_ms_per_epoch=per_epoch(res["compact"]),
-                exchange="compact: 16-bit rows straight from the walk, packed in one pass (gtok_pack_rows_scan) + lengths over RCCL, re-padded locally "
-                         "into a 16-bit slab (gtok_unpack_rows_u16; dist.gather_tokens(compact=True)); one exchange per launch = per Es epochs",
+                exchange="compact: 16-bit rows packed by the walk itself, no slab on the sending side (gtok_sent_packed + GTOK_SENT_PACK_ONLY: " + ("fused" if spk["pk"].fused else "NOT fused: gtok_pack_rows_scan behind the walk")
+                         + ") + row starts and lengths over RCCL, re-padded locally into a 16-bit slab (gtok_unpack_rows_at; dist.gather_tokens(compact=True, packed=)); "
+                         "one exchange per launch = per Es epochs",
                 compact=dict(ms_per_epoch=per_epoch(res["compact"]), exchange_ms_per_epoch=per_epoch(res["compact"] - res[None]),
                              bytes_sent_per_rank_per_epoch=gstats["compact"]["bytes_sent_per_rank"] // Es,
                              bytes_gathered_per_rank_per_epoch=world * gstats["compact"]["bytes_sent_per_rank"] // Es),
+                compact_scan=dict(ms_per_epoch=per_epoch(res["compact_scan"]), exchange_ms_per_epoch=per_epoch(res["compact_scan"] - res[None]),
+                                  bytes_sent_per_rank_per_epoch=gstats["compact_scan"]["bytes_sent_per_rank"] // Es,
+                                  note="the rows packed in a second pass (gtok_pack_rows_scan), lengths only beside them"),
                 padded=dict(ms_per_epoch=per_epoch(res["padded"]), exchange_ms_per_epoch=per_epoch(res["padded"] - res[None]),
                             bytes_sent_per_rank_per_epoch=gstats["padded"]["bytes_sent_per_rank"] // Es,
                             bytes_gathered_per_rank_per_epoch=world * gstats["padded"]["bytes_sent_per_rank"] // Es,

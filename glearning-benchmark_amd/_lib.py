@@ -42,6 +42,7 @@ class GtokCsr(ctypes.Structure):
 CSR_SIMPLE_SYMMETRIC = 1
 SENT_NO_PAD = 1
 SENT_U16 = 2
+SENT_PACK_ONLY = 4
 
 
 class GtokCsrSorted(ctypes.Structure):
@@ -77,6 +78,9 @@ SYMBOLS = {
     "gtok_ibtt_synth": (_I, [ctypes.POINTER(GtokCsr), _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     "gtok_text_to_ids": (_I, [_P, _P, _I, ctypes.POINTER(GtokVocabTable), _I, _I, _P, _I, _P, _P]),
     "gtok_sent": (_I, [ctypes.POINTER(GtokCsr), ctypes.POINTER(GtokSentParams), _P, _I, _P, _P]),
+    "gtok_sent_packed": (_I, [ctypes.POINTER(GtokCsr), ctypes.POINTER(GtokSentParams), _P, _I, _P, _P, ctypes.c_int64, _P, _P, _P]),
+    "gtok_sent_pack_scratch_rows": (ctypes.c_int64, [_P]),
+    "gtok_unpack_rows_at": (_I, [_P, _I, _P, _P, ctypes.c_int64, _I, ctypes.c_int64, ctypes.c_int64, _I, _P, _I, _I, _P, _P]),
     "gtok_sent_decode": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "gtok_remap_zinc": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "gtok_collate": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P]),
@@ -109,7 +113,8 @@ SYMBOLS = {
     "gtok_target": (ctypes.c_char_p, []),
 }
 
-ERRORS = {-1: "GTOK_E_INVAL", -2: "GTOK_E_TOO_LARGE", -3: "GTOK_E_LAUNCH", -4: "GTOK_E_NO_DEVICE", -5: "GTOK_E_GRAPH_SLOTS"}
+ERRORS = {-1: "GTOK_E_INVAL", -2: "GTOK_E_TOO_LARGE", -3: "GTOK_E_LAUNCH", -4: "GTOK_E_NO_DEVICE", -5: "GTOK_E_GRAPH_SLOTS", -6: "GTOK_E_UNSUPPORTED"}
+E_UNSUPPORTED = -6
 
 
 class GtokError(RuntimeError):
@@ -166,7 +171,7 @@ _lib = None
 _lib_version = 0
 
 
-ABI_VERSION = 5     # include/gtok.h: GTOK_ABI_VERSION
+ABI_VERSION = 6     # include/gtok.h: GTOK_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:

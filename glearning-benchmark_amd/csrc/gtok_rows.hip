@@ -105,8 +105,12 @@ __global__ void __launch_bounds__(kScanBlock) row_tile_fill_kernel(const int32_t
 // a row's start in the packed buffer: segments (the blocks the ranks of an all-gather contributed) restart at
 // multiples of segment_stride elements
 __device__ __forceinline__ int64_t packed_start(const int64_t *__restrict__ row_ptr, int64_t r, int segment_rows,
-                                                int64_t segment_stride, int ld) {
+                                                int64_t segment_stride, int ld, int at = 0) {
   if (!row_ptr) return r * (int64_t)ld;            // the strided form: a [rows, ld] slab (GTOK_SENT_U16) read in place
+  if (at) {                                        // explicit starts, relative to the row's segment (gtok_unpack_rows_at)
+    const int64_t st = row_ptr[r];
+    return st < 0 ? (int64_t)-1 : (segment_rows > 0 ? (r / segment_rows) * segment_stride : (int64_t)0) + st;
+  }
   if (segment_rows <= 0) return row_ptr[r];
   const int64_t seg = r / segment_rows;
   return seg * segment_stride + (row_ptr[r] - row_ptr[seg * (int64_t)segment_rows]);
@@ -121,6 +125,7 @@ struct RowsArgs {
   int32_t *status;
   int64_t rows;
   int ld, pad_id, segment_rows, tpr_shift;   // threads per row = 1 << tpr_shift
+  int at;                                    // unpack: row_ptr holds explicit row starts relative to the row's segment
   int64_t segment_stride, capacity;   // pack: elements `packed` can hold; unpack: elements it holds (0 = unknown)
 };
 
@@ -384,7 +389,7 @@ __global__ void __launch_bounds__(256) unpack_rows_kernel(const RowsArgs a) {
   if (r >= a.rows) return;
   int n = a.len[r];
   n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
-  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride, a.ld);
+  const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride, a.ld, a.at);
   bool fits = start >= 0 && (a.capacity <= 0 || start + n <= a.capacity);
   if (a.row_ptr && a.segment_rows > 0) {
     const int64_t seg = r / a.segment_rows;
@@ -689,7 +694,7 @@ extern "C" int gtok_row_offsets(const int32_t *len, int64_t num_rows, int32_t ld
 
 static int rows_launch(bool pack, const void *ids, int src_bytes, void *out_ids, int out_bytes, int32_t ld, const int32_t *len, int64_t num_rows,
                        const int64_t *row_ptr, int32_t segment_rows, int64_t segment_stride, int32_t elem_bytes,
-                       void *packed, int64_t capacity, int32_t pad_id, int32_t *status, void *stream) {
+                       void *packed, int64_t capacity, int32_t pad_id, int32_t *status, void *stream, int at = 0) {
   DeviceScope device_scope((hipStream_t)stream);
   if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   const bool eb_ok = elem_bytes == 2 || elem_bytes == 4 || (pack && src_bytes == 2 && elem_bytes == 8);
@@ -701,6 +706,7 @@ static int rows_launch(bool pack, const void *ids, int src_bytes, void *out_ids,
   a.ids = ids; a.out_ids = out_ids; a.len = len; a.row_ptr = row_ptr; a.packed = packed; a.status = status;
   a.rows = num_rows; a.ld = ld; a.pad_id = pad_id; a.segment_rows = segment_rows; a.segment_stride = segment_stride; a.capacity = capacity;
   a.tpr_shift = tpr_shift_for(ld);
+  a.at = at;
   const int rpb = 256 >> a.tpr_shift;
   const int64_t nb = (num_rows + rpb - 1) / rpb;
   if (nb > 0x7FFFFFFF) return GTOK_E_TOO_LARGE;
@@ -805,6 +811,14 @@ extern "C" int gtok_unpack_rows_u16(const void *packed, int32_t elem_bytes, cons
   if (pad_id < 0 || pad_id > 65535) return GTOK_E_INVAL;
   return rows_launch(false, nullptr, 4, out_ids16, 2, ld, len, num_rows, row_ptr, segment_rows, segment_stride, elem_bytes,
                      const_cast<void *>(packed), packed_elems, pad_id, status, stream);
+}
+
+extern "C" int gtok_unpack_rows_at(const void *packed, int32_t elem_bytes, const int64_t *row_start, const int32_t *len, int64_t num_rows,
+                                   int32_t segment_rows, int64_t segment_stride, int64_t packed_elems, int32_t pad_id, void *out_ids,
+                                   int32_t out_bytes, int32_t ld, int32_t *status, void *stream) {
+  if ((out_bytes != 2 && out_bytes != 4) || !row_start || (out_bytes == 2 && (pad_id < 0 || pad_id > 65535))) return GTOK_E_INVAL;
+  return rows_launch(false, nullptr, 4, out_ids, out_bytes, ld, len, num_rows, row_start, segment_rows, segment_stride, elem_bytes,
+                     const_cast<void *>(packed), packed_elems, pad_id, status, stream, 1);
 }
 
 extern "C" int gtok_collate_packed(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,

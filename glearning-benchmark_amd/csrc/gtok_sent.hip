@@ -76,8 +76,12 @@ static int choose_sent_kernel(const gtok_csr *g, const gtok_sent_params *p) {
 
 using namespace gtok;
 
-extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids,
-                         int32_t ld, int32_t *out_len, void *stream) {
+namespace {
+struct PackDest { void *packed; int64_t capacity; int64_t *row_start; int64_t *state; };   // gtok_sent_packed
+}
+
+static int sent_impl(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids, int32_t ld, int32_t *out_len,
+                     const PackDest *pd, void *stream) {
   gtok::DeviceScope device_scope((hipStream_t)stream);   // the stream's device, not the thread's current one
   if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
   if (!g || !p || ld <= 0 || g->num_graphs < 0) return GTOK_E_INVAL;
@@ -85,7 +89,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   if (!out_ids || !out_len) return GTOK_E_INVAL;
   if (!g->node_ptr || !g->edge_ptr || !g->rowptr || (g->max_edges > 0 && !g->col)) return GTOK_E_INVAL;
   if (p->max_len < 0 || p->max_num_nodes < 0 || p->epoch_count < 0 || p->reserved != 0) return GTOK_E_INVAL;
-  if (p->flags & ~(GTOK_SENT_NO_PAD | GTOK_SENT_U16)) return GTOK_E_INVAL;
+  if (p->flags & ~(GTOK_SENT_NO_PAD | GTOK_SENT_U16 | (pd ? GTOK_SENT_PACK_ONLY : 0))) return GTOK_E_INVAL;
   const bool u16 = (p->flags & GTOK_SENT_U16) != 0;
   if (u16 && (p->pad_id < 0 || p->pad_id > 65535)) return GTOK_E_INVAL;   // (the id space itself is checked below: tokens are 16 bits inside the kernels anyway)
   const int K = sent_epochs(p);
@@ -104,6 +108,12 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   const int maxe = g->max_edges > 0 ? g->max_edges : 1;
   const int which = choose_sent_kernel(g, p);
   if (which < 0) return GTOK_E_INVAL;       // a reordered batch the lane-per-graph kernel cannot take
+  if (pd) {   // rows appended to a packed buffer by the walk itself: the lane-per-graph molecule kernel, rows that start on 16-byte boundaries
+    if (which != 0) return GTOK_E_UNSUPPORTED;
+    if (!pd->packed || !pd->row_start || !pd->state || pd->capacity < 0) return GTOK_E_INVAL;
+    if (ld > (u16 ? 2040 : 1020)) return GTOK_E_TOO_LARGE;    // (a row's 16-byte pieces are counted in 8 bits)
+    if (ld % (u16 ? 8 : 4) != 0 || (reinterpret_cast<uintptr_t>(out_ids) & 15u) || (reinterpret_cast<uintptr_t>(pd->packed) & 15u)) return GTOK_E_INVAL;
+  }
   // padding with non-temporal stores once the slab outgrows the memory-side cache (256 MB on MI355X): gtok_sent_lane.hpp
   int pad_nt = (int64_t)g->num_graphs * K * ld * (u16 ? 2 : 4) > ((int64_t)256 << 20);
   if (const char *cs = std::getenv("GTOK_PAD_NT")) pad_nt = cs[0] != '0';   // tuning knob
@@ -148,6 +158,12 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
   if (lane_path) {
     SentLaneArgs a;
     a.g = *g; a.p = *p; a.maxn = maxn; a.out = out_ids; a.ld = ld; a.out_len = out_len;
+    a.pack_out = pd ? pd->packed : nullptr;
+    a.pack_start = pd ? pd->row_start : nullptr;
+    a.pack_state = pd ? reinterpret_cast<unsigned long long *>(pd->state) : nullptr;
+    a.pack_region_cap = 0; a.pack_regions = 1;
+    a.pack_scratch = pd && (p->flags & GTOK_SENT_PACK_ONLY) ? 1 : 0;
+    if (a.pack_scratch) a.p.flags |= GTOK_SENT_NO_PAD;                   // (nobody reads the staging rows' tails)
     // staging sized by the largest 64-graph chunk when the host told us, else by the per-graph maxima
     a.cap_n = g->chunk_nodes > 0 ? g->chunk_nodes : 64 * maxn;
     a.cap_e = g->chunk_edges > 0 ? g->chunk_edges : 64 * maxe;
@@ -176,6 +192,14 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     KF kern = !p->labeled ? GTOK_LANE_K(false, false) : p->remap_zinc ? GTOK_LANE_K(true, true) : GTOK_LANE_K(true, false);
 #undef GTOK_LANE_K
 #undef GTOK_LANE_K2
+    if (pd) {   // gtok_sent_packed: the instantiations that append to the packed buffer (batches with the byte mirror only)
+      if (!pk) return GTOK_E_UNSUPPORTED;
+#define GTOK_LANE_KP2(LAB, REMAP, U) (p3 ? (KF)sent_lane_kernel<LAB, 4, REMAP, true, U, true> : (KF)sent_lane_kernel<LAB, 6, REMAP, true, U, true>)
+#define GTOK_LANE_KP(LAB, REMAP) (u16 ? GTOK_LANE_KP2(LAB, REMAP, true) : GTOK_LANE_KP2(LAB, REMAP, false))
+      kern = !p->labeled ? GTOK_LANE_KP(false, false) : p->remap_zinc ? GTOK_LANE_KP(true, true) : GTOK_LANE_KP(true, false);
+#undef GTOK_LANE_KP
+#undef GTOK_LANE_KP2
+    }
     const int dev = device_scope.dev, ncu = device_cu_count(dev);
     int occ = -1;                                 // occupancy of one-wave workgroups: only the fallback launch below asks
     if (const char *cs = std::getenv("GTOK_LANE_BLOCKS_PER_CU")) {   // tuning knob
@@ -190,6 +214,12 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     a.epoch_major = 0;     // set below, once the launch shape is known
     if ((int64_t)a.units * K > 0x7FFFFFFF / 64) return GTOK_E_TOO_LARGE;
     const int vunits = a.units * K;               // (unit, epoch) pairs the launch walks
+    if (pd) {   // regions of the packed buffer: as many as leave every region >= 64 pairs (they fill evenly: pairs are dealt by rank in walk length)
+      int m = GTOK_PACK_REGIONS;
+      while (m > 1 && vunits < 64 * m) m >>= 1;
+      a.pack_regions = m;
+      a.pack_region_cap = (pd->capacity / m) & ~(int64_t)7;
+    }
     // order of the pairs: unit-major (the K walks of a unit side by side: the deal stays sorted by walk length) for splits that
     // need several epochs to fill the chip; epoch-major (epoch 0 of every unit, then epoch 1, ...) when one epoch fills half of
     // the resident waves or more - the first round is then the tuned one-epoch deal (249,456 molecules x 2 epochs, int32 padded:
@@ -237,6 +267,7 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
     }
     int nb = ncu * occ;
     if (nb > vunits) nb = vunits;
+    if (a.pack_scratch && nb > ncu * 16) nb = ncu * 16;     // (the staging space is 64 rows for each of 16 waves per CU)
     hipLaunchKernelGGL(kern, dim3(nb), dim3(64), (size_t)a.lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
   }
@@ -338,6 +369,25 @@ extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *
 // ---------------------------------------------------------------------------------------------
 // adjacency bit-matrix mirror (include/gtok.h: gtok_csr_adjbits)
 // ---------------------------------------------------------------------------------------------
+extern "C" int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids,
+                         int32_t ld, int32_t *out_len, void *stream) {
+  return sent_impl(g, p, out_ids, ld, out_len, nullptr, stream);
+}
+
+extern "C" int gtok_sent_packed(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids, int32_t ld, int32_t *out_len,
+                                void *packed, int64_t capacity, int64_t *row_start, int64_t *state, void *stream) {
+  if (!g || !p) return GTOK_E_INVAL;
+  if (g->num_graphs == 0) return GTOK_OK;
+  const PackDest pk{packed, capacity, row_start, state};
+  return sent_impl(g, p, out_ids, ld, out_len, &pk, stream);
+}
+
+extern "C" int64_t gtok_sent_pack_scratch_rows(void *stream) {
+  gtok::DeviceScope device_scope((hipStream_t)stream);
+  if (!device_scope.ok()) return GTOK_E_NO_DEVICE;
+  return (int64_t)64 * 16 * device_cu_count(device_scope.dev);
+}
+
 extern "C" int gtok_csr_adjbits(const gtok_csr *g, int32_t words, uint64_t *rows, uint64_t *planes, int32_t *info, void *stream) {
   gtok::DeviceScope device_scope((hipStream_t)stream);
   if (!device_scope.ok()) return GTOK_E_NO_DEVICE;

@@ -155,6 +155,18 @@ __device__ __forceinline__ void store_win2(uint16_t *p, uint64_t w0, uint64_t w1
   *reinterpret_cast<I32x4 *>(p) = I32x4{(int)(uint32_t)w0, (int)(uint32_t)(w0 >> 32), (int)(uint32_t)w1, (int)(uint32_t)(w1 >> 32)};
 }
 
+// inclusive prefix sum over the wave's 64 lanes in the DPP network (no LDS round trips): within rows of 16 lanes, then the
+// rows' totals broadcast into the rows behind them
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 constexpr int kLaneWgShared = 256;   // bytes of workgroup-shared LDS behind the waves' slices (per-CU launch)
 
 struct SentLaneArgs {
@@ -173,12 +185,21 @@ struct SentLaneArgs {
   int prio_cut[3];   // reordered batch: units below these ranks (in 64ths of the stored order) run at priority 3 / 2 / 1
   int pad_nt;        // padding leaves with non-temporal stores (slabs larger than the memory-side cache)
   int epoch_major;   // order of the (unit, epoch) pairs: 0 = unit-major (pair v = unit v / K), 1 = epoch-major (pair v = unit v mod units)
+  // gtok_sent_packed (NULL otherwise): rows are also appended, 16-byte aligned, to pack_out behind the fill mark pack_state[0]
+  void *pack_out;
+  int64_t *pack_start;              // [K * G] first id of row (epoch, graph) in pack_out; -1: did not fit
+  unsigned long long *pack_state;   // GTOK_PACK_STATE_WORDS words: [0] status bits, [FILL + STRIDE * r] ids used in region r
+  int64_t pack_region_cap;          // ids per region (a multiple of 8)
+  int pack_regions;                 // a power of two <= GTOK_PACK_REGIONS
+  int pack_scratch;                 // GTOK_SENT_PACK_ONLY: `out` is staging space, 64 rows per resident wave
 };
 
 // PK: the batch carries the byte-packed rowptr / col mirror (gtok_csr.rowptr8 / col8): a unit is staged with 12
 // 16-byte loads per lane, all in flight at once, and no packing instructions
 // U16: the GTOK_SENT_U16 slab - rows of 16-bit ids, the token windows stored as they stand
-template <bool LAB, int P, bool REMAP, bool PK, bool U16>
+// PACK: gtok_sent_packed - a finished unit's rows are also appended to the packed buffer (an instantiation of its own: the plain
+// kernel's register allocation is not to be touched)
+template <bool LAB, int P, bool REMAP, bool PK, bool U16, bool PACK = false>
 __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
   using out_t = typename std::conditional<U16, uint16_t, int32_t>::type;
   constexpr int EV = U16 ? 8 : 4;            // ids per 16-byte store
@@ -340,7 +361,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     else pad_rows_impl(std::false_type{});
   };
 #ifdef GTOK_PHASE_TIMING   // profiling build only: cycle stamps per phase, left in the last 8 columns of the unit's first row
-  uint64_t ts[5] = {0, 0, 0, 0, 0};
+  uint64_t ts[5] = {0, 0, 0, 0, 0}, pkt[2] = {0, 0};
   uint32_t rt0 = 0, iters = 0;
   auto stamps_out = [&]() __attribute__((always_inline)) {
     if (!U16 && lane == 0 && ld >= 16 && done_row >= 0) {
@@ -348,6 +369,7 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       row[0] = (int32_t)(ts[1] - ts[0]); row[1] = (int32_t)(ts[2] - ts[1]); row[2] = (int32_t)(ts[3] - ts[2]);
       row[3] = (int32_t)(ts[4] - ts[3]); row[4] = (int32_t)rt0; row[5] = (int32_t)__builtin_amdgcn_s_memrealtime();
       row[6] = (int32_t)iters; row[7] = (int32_t)blockIdx.x;
+      if (PACK) { row[6] = (int32_t)pkt[0]; row[7] = (int32_t)pkt[1]; }   // gtok_sent_packed: cycles until the atomic answered / of the copy
     }
   };
 #endif
@@ -547,7 +569,11 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     // ---- walk (per lane; mirrors oracle_sent step for step)
     const uint64_t gid = (uint64_t)(a.p.graph_base + g);
     const uint32_t gid_lo = (uint32_t)gid, gid_hi = (uint32_t)(gid >> 32);
-    out_t *__restrict__ orow = out_base + ((int64_t)(epoch - epoch0) * G + g) * ld;
+    // (gtok_sent_packed with GTOK_SENT_PACK_ONLY: the slab is only this wave's staging area - 64 rows that every unit of the wave
+    // reuses, so that the row stores stay in the caches and what reaches memory is the packed copy)
+    const int64_t srow = PACK && a.pack_scratch ? (int64_t)((int)blockIdx.x * (int)(blockDim.x >> 6) + wave) * 64 + lane
+                                                 : (int64_t)(epoch - epoch0) * G + g;
+    out_t *__restrict__ orow = out_base + srow * ld;
     set_t vis = 0, live = 0;
     uint64_t wlo = 0;
     int nvis = 0, pos = 0, fl = 0, d = 0, cur = 0;
@@ -769,8 +795,94 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     }
 
     lw = padfrom;
-    done_row = valid ? orow_idx : -1;
+    done_row = valid ? (int)srow : -1;
     done_cnt = h.gl - h.g0;
+    // ---- gtok_sent_packed: the unit's rows are appended to the packed buffer as well, each from a 16-byte boundary.  The
+    // buffer is cut into a.pack_regions equal regions with a fill mark each (one mark for everybody serves ~50-90 units per
+    // microsecond: measured, it cost as much as the walk); pair vu appends to region vu mod regions - the units are stored by
+    // walk length, so every region receives the same mix and fills evenly - and learns where from ONE atomic add, issued ahead
+    // of the copy's loads.  The copy is cooperative: 16 lanes per row, four rows per pass (whole lines of the rows this wave
+    // has just written).  Rows are ordered by completion: row_start says where each went.
+    // (Nothing of this may stay live across the walk: the register file is full.)
+    if constexpr (PACK) {
+#ifdef GTOK_PHASE_TIMING
+      const uint64_t tp0 = __builtin_amdgcn_s_memtime();
+      uint64_t tp1 = tp0;
+#endif
+      const int nid = valid ? min(tot, ld) : 0;
+      const int np = (nid + EV - 1) / EV;
+      const int inc = wave_incl_scan_dpp(np);
+      const int total = __builtin_amdgcn_readlane(inc, kWave - 1);
+      const int region = vu & (a.pack_regions - 1);
+      const int cnt = h.gl - h.g0;
+      const int q = lane & 15, grp = lane >> 4;
+      const int my_row = valid ? (int)srow : -1, my_offnp = ((inc - np) << 8) | np;   // (np <= 255: the launcher checks ld)
+      const int my_row0 = __builtin_amdgcn_readfirstlane((int)srow);               // (a row of this unit: lane 0 is always valid)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the rows read below were written by other lanes of this wave)
+      // A sweep = 16-byte piece 16 sweep + q of every row, in two batches of eight passes of four rows (what the register file has
+      // room for at a unit's end; variants measured slower or equal: the copy behind the next unit's staging loads - its state
+      // lives across the walk and spills -, double-buffered batches of four, passes 8-15 landed in LDS by global_load_lds)
+      constexpr int KF = 8;
+      bool fits = true, placed = false;
+      gtok_v4i *dstbase = nullptr;
+      for (int sweep = 0;; ++sweep) {
+        const int t = sweep * 16 + q;
+        _Pragma("clang loop unroll(disable)")
+        for (int b0 = 0; b0 < 16; b0 += KF) {
+          if (b0 * 4 >= cnt) break;
+          gtok_v4i v[KF];
+          int doff[KF];
+#pragma unroll
+          for (int k = 0; k < KF; ++k) {
+            const int rn = ((b0 + k) * 4 + grp) << 2;
+            const int r_idx = __builtin_amdgcn_ds_bpermute(rn, my_row);
+            const int r_on = __builtin_amdgcn_ds_bpermute(rn, my_offnp);
+            const bool on = r_idx >= 0 && t < (r_on & 255);
+            doff[k] = on ? (r_on >> 8) + t : -1;
+            // (an address is always formed - a row of this unit for the lanes that have nothing to fetch - so that the loads leave
+            // back to back instead of each behind a branch of its own)
+#ifndef GTOK_PACK_ABLATE_COPY
+            v[k] = reinterpret_cast<const gtok_v4i *>(out_base + (int64_t)(on ? r_idx : my_row0) * ld)[on ? t : 0];
+#else
+            v[k] = gtok_v4i{r_idx, r_on, t, k};
+#endif
+          }
+          if (!placed) {
+            // the fill mark is asked BEHIND the first loads: one wait covers the unit's row stores draining, the loads and the atomic
+            placed = true;
+            unsigned long long base = 0;
+#ifndef GTOK_PACK_ABLATE_ATOMIC
+            if (lane == 0)
+              base = __hip_atomic_fetch_add(a.pack_state + GTOK_PACK_STATE_FILL + GTOK_PACK_STATE_STRIDE * region, (unsigned long long)total * EV,
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+#else
+            base = (unsigned long long)(vu / a.pack_regions) * 64 * 96;
+#endif
+            fits = base + (unsigned long long)total * EV <= (unsigned long long)a.pack_region_cap;
+            const int64_t rstart = (int64_t)region * a.pack_region_cap + (int64_t)base;
+            dstbase = reinterpret_cast<gtok_v4i *>(reinterpret_cast<out_t *>(a.pack_out) + rstart);
+            if (valid) a.pack_start[orow_idx] = fits ? rstart + (int64_t)(inc - np) * EV : (int64_t)-1;
+            if (!fits && lane == 0 && total > 0) atomicOr(a.pack_state, 2ull);
+#ifdef GTOK_PHASE_TIMING
+            tp1 = __builtin_amdgcn_s_memtime();
+#endif
+          }
+#ifdef GTOK_PACK_ABLATE_COPY
+          if (total == 0x7654321)
+#endif
+          if (fits) {
+#pragma unroll
+            for (int k = 0; k < KF; ++k) if (doff[k] >= 0) dstbase[doff[k]] = v[k];
+          }
+        }
+        if (__ballot(np > 16 * (sweep + 1)) == 0) break;
+      }
+#ifdef GTOK_PHASE_TIMING
+      pkt[0] = tp1 - tp0; pkt[1] = __builtin_amdgcn_s_memtime() - tp1;
+#endif
+    }
 #ifdef GTOK_PHASE_TIMING
     ts[4] = __builtin_amdgcn_s_memtime();
 #endif

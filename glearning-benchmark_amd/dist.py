@@ -38,7 +38,8 @@ def shard_of(batch, rank: int = None, world: int = None):
 
 
 def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: int, force: bool = False,
-                  compact: bool = False, elem_bytes: int = 2, capacity: int = None, rows_impl=None, stats: dict = None):
+                  compact: bool = False, elem_bytes: int = 2, capacity: int = None, rows_impl=None, stats: dict = None,
+                  packed=None, ld: int = None):
     """All-gather the per-rank [G_local, ld] slabs + lengths into the full [G, ld] slab on every rank.
 
     Ranks hold blocks from block_bounds(); the last blocks may be short, so every rank pads its
@@ -58,12 +59,25 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     all pad: gtok_unpack_rows never reads beyond a rank's segment).  Without a caller-given capacity a nonzero status
     raises - on every rank, after the collectives, so nobody is left waiting in one; with it, stats["status"] holds the
     verdict as a device tensor for the caller to read when it likes.
+    packed (with compact=True): the ops.PackedRows that ops.sent(..., packed=) filled together with `ids` - this rank's rows are
+    packed already (by the walk itself: gtok_sent_packed), so nothing is packed here; every rank must pass a buffer of the SAME
+    capacity (that is the agreed size: no size exchange), each row's start travels with its length, and gtok_unpack_rows_at
+    re-pads.  Verdict as with a caller-given capacity: stats["status"].  `ids` may then be None (ops.sent(..., slab=False) wrote
+    no slab): pass the slab width as `ld`.
     rows_impl: the module providing row_offsets / pack_rows / unpack_rows (default: ops, i.e. the HIP kernels; the CPU
     tests of the collective pass the oracle's).  stats: a dict that receives the bytes each rank contributed."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return ids, ln
     world = dist.get_world_size()
     per = -(-num_graphs // world)
+    if ids is None:
+        if packed is None or not compact or ld is None:
+            raise ValueError("gather_tokens without a slab needs compact=True, packed= and ld=")
+        if ln.numel() < per:
+            ln = torch.cat([ln.reshape(-1), torch.zeros(per - ln.numel(), dtype=ln.dtype, device=ln.device)])
+        if rows_impl is None:
+            from . import ops as rows_impl
+        return _gather_prepacked(None, ln.reshape(-1).contiguous(), num_graphs, pad_id, packed, rows_impl, stats, world, per, int(ld))
     ld = ids.shape[1]
     if ids.shape[0] < per:
         fill = per - ids.shape[0]
@@ -80,6 +94,8 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
         return all_ids[:num_graphs], all_ln[:num_graphs]
     if rows_impl is None:
         from . import ops as rows_impl
+    if packed is not None:
+        return _gather_prepacked(ids, ln, num_graphs, pad_id, packed, rows_impl, stats, world, per, ld)
     pack = rows_impl.pack_rows_u16 if ids.dtype == torch.int16 else rows_impl.pack_rows
     caller_bound = capacity is not None
     row_ptr = None
@@ -112,6 +128,32 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     if stats is not None:
         stats.update(bytes_sent_per_rank=capacity * packed.element_size() + (ln.numel() + 1) * 4, compact=True,
                      elem_bytes=elem_bytes, capacity=capacity, status=verdict)
+    return all_ids[:num_graphs], all_ln[:num_graphs]
+
+
+def _gather_prepacked(ids, ln, num_graphs, pad_id, packed, rows_impl, stats, world, per, ld):
+    """the compact exchange of rows the walk has packed already (gather_tokens(packed=)): packed buffer + (row starts, lengths,
+    status) of every rank, two collectives, one re-padding pass"""
+    dev = ln.device
+    capacity = int(packed.capacity)
+    start = packed.row_start[:per]
+    if start.numel() < per:                                   # a short last block: rows of length 0
+        start = torch.cat([start, torch.zeros(per - start.numel(), dtype=torch.int64, device=dev)])
+    all_packed = torch.empty(world * capacity, dtype=packed.buf.dtype, device=dev)
+    dist.all_gather_into_tensor(all_packed.view(torch.uint8), packed.buf[:capacity].view(torch.uint8))
+    ext = torch.cat([start, ln.to(torch.int64), packed.status().to(torch.int64).reshape(1)])     # starts + lengths + status, one collective
+    all_ext = torch.empty((world, 2 * per + 1), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_ext.view(-1), ext)
+    all_start = all_ext[:, :per].contiguous().view(-1)
+    all_ln = all_ext[:, per:2 * per].to(torch.int32).contiguous().view(-1)
+    ustatus = torch.zeros(1, dtype=torch.int32, device=dev)
+    u16 = packed.buf.dtype == torch.int16
+    all_ids = rows_impl.unpack_rows_at(all_packed, all_start, all_ln, ld, pad_id, segment_rows=per, segment_stride=capacity, status=ustatus,
+                                       **({"u16": True} if u16 else {}))
+    verdict = torch.maximum(all_ext[:, 2 * per].max().to(torch.int32).reshape(1), ustatus)
+    if stats is not None:
+        stats.update(bytes_sent_per_rank=capacity * packed.buf.element_size() + (2 * per + 1) * 8, compact=True,
+                     elem_bytes=packed.buf.element_size(), capacity=capacity, status=verdict, prepacked=True)
     return all_ids[:num_graphs], all_ln[:num_graphs]
 
 

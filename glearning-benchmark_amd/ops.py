@@ -269,10 +269,40 @@ def adjbits(batch: GraphBatch) -> bool:
     return True
 
 
+PACK_STATE_FILL, PACK_STATE_STRIDE, PACK_REGIONS = 16, 16, 64       # include/gtok.h: GTOK_PACK_STATE_*
+PACK_STATE_WORDS = PACK_STATE_FILL + PACK_STATE_STRIDE * PACK_REGIONS
+
+
+class PackedRows:
+    """The packed twin of a SENT launch's rows (ops.sent(..., packed=PackedRows(...)): gtok_sent_packed).  buf: `capacity` ids of
+    the slab's width, every row from a 16-byte boundary; row_start int64 [rows]: where row (epoch, graph) starts in buf, -1 for a row
+    that did not fit (rows lie in the order their 64-graph units finished, inside up to 64 regions of the buffer that fill side by
+    side, not in dataset order - readers go through row_start: ops.unpack_rows_at, ops.collate_packed(buf, row_start, ...)); state
+    int64 [PACK_STATE_WORDS]: the status word and the regions' fill marks (include/gtok.h).  Size the buffer as the expected total
+    + a few per cent.  fused: whether the walk kernel itself wrote it (else gtok_sent + gtok_pack_rows_scan did: dataset order)."""
+    __slots__ = ("buf", "row_start", "state", "capacity", "fused")
+
+    def __init__(self, rows: int, capacity: int, u16: bool, device):
+        self.capacity = max(8, -(-int(capacity) // 8) * 8)
+        self.buf = torch.empty(self.capacity, dtype=torch.int16 if u16 else torch.int32, device=device)
+        self.row_start = torch.empty(max(1, int(rows)), dtype=torch.int64, device=device)
+        self.state = torch.zeros(PACK_STATE_WORDS, dtype=torch.int64, device=device)
+        self.fused = None
+
+    def status(self) -> torch.Tensor:
+        """int32 [1] on the device: the pack_rows status bits of this fill (bit 1: the buffer was too small for some rows)."""
+        return self.state[0:1].to(torch.int32)
+
+    def used(self) -> torch.Tensor:
+        """int64 scalar on the device: ids the fill took (the regions' fill marks added up; skipped rows included)."""
+        return self.state[PACK_STATE_FILL::PACK_STATE_STRIDE].sum()
+
+
 def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: int = 0, labeled: bool = False,
          num_node_types: int = 0, num_edge_types: int = 0, remap_zinc: bool = False, pad_id: int = SENT_PAD,
          graph_base: int = 0, query: Optional[torch.Tensor] = None,
-         ld: Optional[int] = None, out=None, pad: bool = True, epochs: int = 1, u16: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+         ld: Optional[int] = None, out=None, pad: bool = True, epochs: int = 1, u16: bool = False,
+         packed: Optional[PackedRows] = None, slab: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """SENT trail walk.  Returns (ids int32 [G, ld], len int32 [G]); len > ld flags a too-narrow slab.
     pad=False (GTOK_SENT_NO_PAD): rows are only written up to their length - for consumers that go through `len`
     (ops.collate does); the rest of the slab keeps whatever it held.
@@ -280,7 +310,13 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
     (ids [K, G, ld], len [K, G]); slice e is what a call with epoch + e returns.  The trainer re-tokenizes its splits every
     epoch (trainer/train_agtt.py:246-250): K epochs of a small split fill the chip where one cannot.
     u16=True (GTOK_SENT_U16): the slab holds 16-bit ids (torch.int16 storage, to be read as unsigned: every SENT id fits) -
-    half the bytes; readers: ops.collate_packed / ops.unpack_rows with row_ptr=None, ops.pack_rows_u16."""
+    half the bytes; readers: ops.collate_packed / ops.unpack_rows with row_ptr=None, ops.pack_rows_u16.
+    packed=PackedRows(K * G, capacity, u16, device): the rows are ALSO appended to packed.buf (a fresh fill: its state is
+    zeroed first) - by the walk kernel itself where the batch runs sent_lane_kernel (gtok_sent_packed: no second pass over the
+    rows), else by gtok_pack_rows_scan behind the walk; either way packed.row_start / packed.state describe the result.
+    slab=False (with packed=; GTOK_SENT_PACK_ONLY): the caller reads the packed rows alone - no [K, G, ld] slab is written or
+    allocated (the walk stages its rows in a per-device scratch of 64 rows per resident wave: 92 MB on an MI355X whatever K is) and
+    the first return value is None."""
     _need_gpu(batch.col, "sent")
     dev = batch.device
     K = max(1, int(epochs))
@@ -291,7 +327,12 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
     if ld is None:
         ld = sent_safe_ld(batch, labeled, max_len, query is not None)
     G = batch.num_graphs
-    if out is not None:
+    if not slab:
+        if packed is None or out is not None:
+            raise ValueError("slab=False goes with packed= (and without out=)")
+        ids = None
+        ln = torch.empty((K * G,), dtype=torch.int32, device=dev)
+    elif out is not None:
         ids, ln = out
         want = torch.int16 if u16 else torch.int32
         if ids.dtype != want or ln.dtype != torch.int32 or ids.numel() != K * G * ld or ln.numel() != K * G \
@@ -331,11 +372,61 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
             cs = sb.c_struct()
     global _LAST_SENT
     _LAST_SENT = (cs, p)
-    check(lib().gtok_sent(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)),
-          "gtok_sent")
+    rc = _lib.E_UNSUPPORTED
+    if packed is not None:
+        if _lib.library_version() < 6:
+            raise _lib.GtokError(f"the loaded library has ABI version {_lib.library_version()}: packed= needs version 6")
+        if packed.buf.dtype != (torch.int16 if u16 else torch.int32) or packed.row_start.numel() < K * G or packed.buf.device != ln.device:
+            raise ValueError("packed: a PackedRows of this launch's rows, id width and device")
+        packed.state.zero_()
+        if G and ld % (8 if u16 else 4) == 0:
+            dst, pp = ids, p
+            if not slab:
+                dst = _pack_scratch(dev, ld, u16)
+                pp = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc), pad_id,
+                                    flags | _lib.SENT_PACK_ONLY, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
+                                    None if query is None else query.data_ptr(), K, 0)
+            rc = lib().gtok_sent_packed(ctypes.byref(cs), ctypes.byref(pp), dst.data_ptr(), ld, ln.data_ptr(), packed.buf.data_ptr(),
+                                        packed.capacity, packed.row_start.data_ptr(), packed.state.data_ptr(), _stream(dev))
+            if rc != _lib.E_UNSUPPORTED:
+                check(rc, "gtok_sent_packed")
+        packed.fused = rc == 0
+    if rc == _lib.E_UNSUPPORTED:
+        if ids is None:             # another kernel walks: it needs the slab after all (a temporary one)
+            ids = torch.empty((K * G, ld), dtype=torch.int16 if u16 else torch.int32, device=dev)
+        check(lib().gtok_sent(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), ld, ln.data_ptr(), _stream(dev)),
+              "gtok_sent")
+        if packed is not None and G:           # another kernel walked: the one-pass pack behind it (dataset order)
+            ptr = torch.empty(K * G + 1, dtype=torch.int64, device=dev)
+            st = torch.empty(1, dtype=torch.int32, device=dev)
+            eb = 2 if u16 else 4
+            check(lib().gtok_pack_rows_scan(ids.data_ptr(), eb, ld, ln.data_ptr(), K * G, 8, eb, packed.buf.data_ptr(), packed.capacity,
+                                            ptr.data_ptr(), st.data_ptr(), _stream(dev)), "gtok_pack_rows_scan")
+            packed.row_start[:K * G].copy_(ptr[:-1])
+            packed.state[PACK_STATE_FILL:PACK_STATE_FILL + 1].copy_(ptr[-1:])
+            packed.state[0:1].copy_(st.to(torch.int64) & 2)
+    if not slab:
+        return None, (ln.view(K, G) if K > 1 else ln.view(G))
     if K > 1:
         return ids.view(K, G, ld), ln.view(K, G)
     return ids.view(G, ld), ln.view(G)
+
+
+_PACK_SCRATCH = {}
+
+
+def _pack_scratch(dev, ld: int, u16: bool) -> torch.Tensor:
+    """the staging rows of GTOK_SENT_PACK_ONLY launches: one buffer per (device, width, id size), grown on demand, shared by every
+    launch on that device (launches on one stream follow each other; callers with several streams pass their own slab)"""
+    key = (torch.device(dev).index or 0, bool(u16))
+    rows = int(lib().gtok_sent_pack_scratch_rows(_stream(dev)))
+    if rows < 0:
+        check(rows, "gtok_sent_pack_scratch_rows")
+    t = _PACK_SCRATCH.get(key)
+    if t is None or t.numel() < rows * ld:
+        t = torch.empty(rows * ld, dtype=torch.int16 if u16 else torch.int32, device=dev)
+        _PACK_SCRATCH[key] = t
+    return t
 
 
 _LAST_SENT = None
@@ -540,6 +631,27 @@ def unpack_rows(packed: torch.Tensor, row_ptr: Optional[torch.Tensor], ln: torch
     check(fn(packed.data_ptr(), eb, None if row_ptr is None else row_ptr.data_ptr(), ln.data_ptr(), rows,
              int(segment_rows), int(segment_stride), int(packed.numel()), int(pad_id), ids.data_ptr(), int(ld),
              None if status is None else status.data_ptr(), _stream(dev)), "gtok_unpack_rows")
+    return ids
+
+
+def unpack_rows_at(packed: torch.Tensor, row_start: torch.Tensor, ln: torch.Tensor, ld: int, pad_id: int, segment_rows: int = 0,
+                   segment_stride: int = 0, out: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None,
+                   u16: bool = False) -> torch.Tensor:
+    """unpack_rows for rows with explicit starts (gtok_unpack_rows_at; what ops.sent(..., packed=) writes): row r's ids start at
+    element (r // segment_rows) * segment_stride + row_start[r] (segment_rows == 0: at row_start[r]); a negative start or a row
+    beyond its segment comes out as all pad, status bit 1."""
+    _need_gpu(packed, "unpack_rows_at")
+    dev, rows = packed.device, int(ln.numel())
+    eb = packed.element_size()
+    if eb not in (2, 4) or row_start.dtype != torch.int64 or int(row_start.numel()) < rows or not row_start.is_contiguous():
+        raise ValueError("unpack_rows_at expects int16 / int32 storage and one contiguous int64 start per row")
+    want = torch.int16 if u16 else torch.int32
+    ids = torch.empty((rows, ld), dtype=want, device=dev) if out is None else out
+    if ids.dtype != want:
+        raise ValueError(f"out must be {want}")
+    check(lib().gtok_unpack_rows_at(packed.data_ptr(), eb, row_start.data_ptr(), ln.data_ptr(), rows, int(segment_rows), int(segment_stride),
+                                    int(packed.numel()), int(pad_id), ids.data_ptr(), 2 if u16 else 4, int(ld),
+                                    None if status is None else status.data_ptr(), _stream(dev)), "gtok_unpack_rows_at")
     return ids
 
 

@@ -96,6 +96,9 @@ extern "C" {
                                    "sent_blane_kernel", "ibtt_zinc_lane_kernel", gtok_pack_rows_scan) keep one per captured launch for as long as the capturing graph
                                    (and the executable graphs made from it) exist - destroying a graph returns its blocks   */
 
+#define GTOK_E_UNSUPPORTED (-6) /* the request is valid but not for the kernel this batch runs (gtok_sent_packed on a batch that
+                                   gtok_sent_kernel_name() does not answer "sent_lane_kernel" for): use the two-call route    */
+
 #define GTOK_MAX_NODES 512 /* SENT adjacency bit-matrix rows per wave (LDS)  */
 
 /* flags: properties the CALLER has verified for the whole batch (on the host, or with gtok_csr_check on the device) */
@@ -325,6 +328,35 @@ typedef struct gtok_sent_params {
 int gtok_sent(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids,
               int32_t ld, int32_t *out_len, void *stream);
 
+/* gtok_sent whose walk ALSO appends every row to a packed buffer (ABI v6): the payload of the compact all-gather and of the
+ * per-epoch D2H copy without a second pass over the rows.  `packed` holds `capacity` ids of the slab's width (16-bit with
+ * GTOK_SENT_U16, else 32-bit).  The library cuts it into R <= GTOK_PACK_REGIONS equal regions of (capacity / R rounded down to a
+ * multiple of 8) ids, each with a fill mark of its own - one mark for all 64-graph units costs as much as the walk - and deals
+ * the units to the regions so that they fill evenly (R = the largest power of two that leaves every region >= 64 (unit, epoch)
+ * pairs; a ZINC-full epoch: 32 regions that end within 1 % of each other): size `capacity` as the expected total + a few
+ * per cent.  state (int64 [GTOK_PACK_STATE_WORDS], ZEROED BY THE CALLER before every launch): [0] collects status bits (bit 1:
+ * a unit's rows did not fit its region; they are skipped and their row_start is -1), [GTOK_PACK_STATE_FILL + GTOK_PACK_STATE_STRIDE * r]
+ * is region r's fill mark in ids (it counts skipped units too).  row_start[e * G + g] (int64 [K * G]) = first id of that row in
+ * `packed`: rows start on 16-byte boundaries and lie in the order in which the units finished, NOT in dataset order - readers go
+ * through row_start (gtok_unpack_rows_at, gtok_collate_packed with row_ptr = row_start).  Row r holds min(out_len[r], ld) ids;
+ * the slab itself is written as gtok_sent writes it (pass GTOK_SENT_NO_PAD when nobody reads its pad tails).  Needs ld % 8 == 0
+ * (% 4 for 32-bit ids), 16-byte aligned out_ids / packed, and a batch that runs the lane-per-graph molecule kernel (else
+ * GTOK_E_UNSUPPORTED, nothing is launched: call gtok_sent + gtok_pack_rows_scan).                                           */
+#define GTOK_SENT_PACK_ONLY 4 /* gtok_sent_params.flags, gtok_sent_packed only: the caller reads the PACKED rows alone - out_ids is then staging
+                                space of gtok_sent_pack_scratch_rows() rows x ld ids (contents unspecified afterwards) instead of a
+                                [K, G, ld] slab: every resident wave reuses its 64 rows for all of its units, the row stores stay in
+                                the caches and K epochs need 92 MB of staging on an MI355X instead of K slabs.  Implies
+                                GTOK_SENT_NO_PAD.                                                                              */
+#define GTOK_PACK_REGIONS 64
+#define GTOK_PACK_STATE_FILL 16    /* the fill marks start one cache line behind the status word ... */
+#define GTOK_PACK_STATE_STRIDE 16  /* ... and keep a cache line each                                   */
+#define GTOK_PACK_STATE_WORDS (GTOK_PACK_STATE_FILL + GTOK_PACK_STATE_STRIDE * GTOK_PACK_REGIONS)
+int gtok_sent_packed(const gtok_csr *g, const gtok_sent_params *p, int32_t *out_ids, int32_t ld, int32_t *out_len,
+                     void *packed, int64_t capacity, int64_t *row_start, int64_t *state, void *stream);
+/* rows of staging space a GTOK_SENT_PACK_ONLY launch on the stream's device needs (64 per wave the device can hold: 262,144 on an
+ * MI355X), or a negative GTOK_E_* code                                                                                          */
+int64_t gtok_sent_pack_scratch_rows(void *stream);
+
 /* remap_zinc_tokens over the first len[g] ids of every row, in place or not. */
 int gtok_remap_zinc(const int32_t *in_ids, int32_t *out_ids, int32_t ld,
                     const int32_t *len, int32_t num_rows, int32_t idx_offset,
@@ -406,6 +438,13 @@ int gtok_pack_rows_u16(const uint16_t *ids16, int32_t ld, const int32_t *len, in
 int gtok_unpack_rows_u16(const void *packed, int32_t elem_bytes, const int64_t *row_ptr, const int32_t *len,
                          int64_t num_rows, int32_t segment_rows, int64_t segment_stride, int64_t packed_elems,
                          int32_t pad_id, uint16_t *out_ids16, int32_t ld, int32_t *status, void *stream);
+/* gtok_unpack_rows_checked / _u16 for rows with EXPLICIT starts (ABI v6; what gtok_sent_packed writes): row r's ids start at
+ * element (r / segment_rows) * segment_stride + row_start[r] of `packed` (segment_rows == 0: at row_start[r]); a negative start,
+ * or a row that would end beyond its segment / packed_elems (> 0), comes out as all pad and is flagged in status (bit 1).
+ * out_bytes: 4 = an int32 slab, 2 = a slab of 16-bit ids.                                                                  */
+int gtok_unpack_rows_at(const void *packed, int32_t elem_bytes, const int64_t *row_start, const int32_t *len, int64_t num_rows,
+                        int32_t segment_rows, int64_t segment_stride, int64_t packed_elems, int32_t pad_id, void *out_ids,
+                        int32_t out_bytes, int32_t ld, int32_t *status, void *stream);
 /* gtok_row_offsets + gtok_pack_rows (src_bytes 4: an int32 slab) / gtok_pack_rows_u16 (src_bytes 2: a GTOK_SENT_U16 slab) in
  * ONE pass (ABI v5): row_ptr (int64 [num_rows + 1], OUT) and the packed rows are written by the same kernel - tiles of 256
  * rows, each tile learning its start from the tiles before it (single-pass prefix sum, the tile's closing row_ptr slot is its
@@ -534,7 +573,7 @@ const char *gtok_ibtt_zinc_kernel_name(const gtok_csr *g);
  * mirrors - a binding checks it before passing structs; 3 adds the packed-row entry points; 4: gtok_sent_params carries
  * epoch_count, GTOK_SENT_U16, the strided / checked packed-row readers; 5 adds gtok_csr_check / gtok_csr_lane_sort -
  * structs unchanged) and build target string ("gfx950").                     */
-#define GTOK_ABI_VERSION 5
+#define GTOK_ABI_VERSION 6
 int gtok_version(void);
 const char *gtok_target(void);
 

@@ -17,8 +17,9 @@ host = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d[
 b = host.to(dev)
 ld = 216
 kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+pk = gtok.ops.PackedRows(G, G * 104, False, dev) if os.environ.get("GTOK_PT_PACKED") == "1" else None     # gtok_sent_packed: the copy's cycles too
 for k in range(3):
-    ids, ln = gtok.ops.sent(b, 37, 1024, 0, k, ld=ld, **kw)
+    ids, ln = gtok.ops.sent(b, 37, 1024, 0, k, ld=ld, packed=pk, **kw)
 torch.cuda.synchronize()
 assert int(ln.max()) <= ld - 8
 sb = b.lane_sorted          # the reordered copy ops.sent walks by default (GTOK_NO_LANE_SORT=1: the batch as stored)
@@ -31,6 +32,9 @@ for i, nme in enumerate(names):
     print(f"{nme:14s} mean {ph[:, i].mean():10.0f} cycles  max {ph[:, i].max():10.0f}  share {ph[:, i].sum() / tot:.3f}")
 print("mean cycles per unit", ph[:, :4].sum(1).mean(), " iterations mean", ph[:, 6].mean(), "max", ph[:, 6].max(),
       " walk cycles per iteration", ph[:, 2].sum() / ph[:, 6].sum())
+if pk is not None:
+    assert pk.fused and int(pk.status()) == 0
+    print(f"gtok_sent_packed (inside 'row end'): until the atomic has answered mean {ph[:, 6].mean():.0f} cycles (max {ph[:, 6].max()}), copy mean {ph[:, 7].mean():.0f} (max {ph[:, 7].max()})")
 rt0 = (ph[:, 4] & 0xFFFFFFFF); rt1 = (ph[:, 5] & 0xFFFFFFFF)
 base = rt0.min()
 s0, s1 = (rt0 - base) / 100.0, (rt1 - base) / 100.0          # us on the 100 MHz clock

@@ -37,7 +37,12 @@ for K in [int(a) for a in sys.argv[1:]] or [1, 16]:
     t_pack = ev(lambda: gtok.ops.pack_rows_u16(ids, ln, ptr, elem_bytes=2, capacity=cap, check_status=False))
     t_scan = ev(lambda: gtok.ops.pack_rows_scan(ids, ln, 2, cap))
     t_both = ev(lambda: (walk(), gtok.ops.pack_rows_scan(ids, ln, 2, cap)))
+    pk = gtok.ops.PackedRows(K * G, K * G * 96, True, dev)
+    fused = lambda: gtok.ops.sent(b, b.max_nodes, 1024, 0, 0, ld=ld, out=(ids, ln), pad=False, epochs=K, u16=True, packed=pk, **kw)
+    t_fused = ev(fused)
+    assert pk.fused and int(pk.status()) == 0
     mb = 2 * tokens * 2 / 1e6
     print(f"K={K:2d} rows {K * G} tokens {tokens}: walk {t_walk:.4f} ms | row_offsets {t_off:.4f} | pack_rows_u16 {t_pack:.4f} | pack_rows_scan {t_scan:.4f} "
-          f"({mb / t_scan / 1e3:.2f} TB/s of {mb:.0f} MB in+out) | walk + scan {t_both:.4f}; per epoch: walk {t_walk / K:.5f} scan {t_scan / K:.5f}")
+          f"({mb / t_scan / 1e3:.2f} TB/s of {mb:.0f} MB in+out) | walk + scan {t_both:.4f} | walk that packs (gtok_sent_packed, + zeroing its state) {t_fused:.4f}; per epoch: walk {t_walk / K:.5f} scan {t_scan / K:.5f} "
+          f"fused {t_fused / K:.5f} (+{(t_fused - t_walk) / K * 1e3:.2f} us over the walk)")
     del ids, ln

@@ -47,6 +47,51 @@ class _OracleRows:
         return torch.from_numpy(out.astype(np.uint16).view(np.int16)) if u16 else torch.from_numpy(out)     # (gtok_unpack_rows_u16: a 16-bit slab)
 
 
+    @staticmethod
+    def unpack_rows_at(packed, row_start, ln, ld, pad_id, segment_rows=0, segment_stride=0, status=None, u16=False):
+        """rows with explicit starts, relative to their rank's segment (gtok_unpack_rows_at): a plain numpy loop"""
+        p = packed.numpy()
+        p = p.view(np.uint16) if p.dtype == np.int16 else p
+        st, n = row_start.numpy(), np.clip(ln.numpy(), 0, ld)
+        out = np.full((n.size, ld), pad_id, dtype=np.int32)
+        for r in range(n.size):
+            seg = r // segment_rows if segment_rows else 0
+            if st[r] < 0 or (segment_rows and st[r] + n[r] > segment_stride):
+                if n[r] and status is not None:
+                    status |= 2
+                continue
+            at = seg * segment_stride + st[r]
+            out[r, :n[r]] = p[at:at + n[r]]
+        return torch.from_numpy(out.astype(np.uint16).view(np.int16)) if u16 else torch.from_numpy(out)
+
+
+class _Prepacked:
+    """what ops.sent(..., packed=) leaves (ops.PackedRows), built by hand: rows in a scrambled order, each from an 8-id boundary,
+    in two regions of the buffer"""
+
+    def __init__(self, ids16, ln, capacity, seed, drop=()):
+        rows, ld = ids16.shape
+        self.capacity = capacity
+        buf = np.full(capacity, 0x7ABC, dtype=np.uint16)
+        self.row_start = torch.full((rows,), -1, dtype=torch.int64)
+        fill = [0, capacity // 2]
+        st = 0
+        for i, r in enumerate(np.random.default_rng(seed).permutation(rows)):
+            n = int(min(max(ln[r], 0), ld))
+            reg = i & 1
+            if r in drop or fill[reg] + n > (reg + 1) * (capacity // 2):
+                st |= 2
+                continue
+            buf[fill[reg]:fill[reg] + n] = ids16[r, :n]
+            self.row_start[r] = fill[reg]
+            fill[reg] += (n + 7) // 8 * 8
+        self.buf = torch.from_numpy(buf.view(np.int16))
+        self._st = st
+
+    def status(self):
+        return torch.tensor([self._st], dtype=torch.int32)
+
+
 def _worker(rank, world, port, G, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -78,6 +123,22 @@ def _worker(rank, world, port, G, q):
             p_ids, p_ln = gtok.dist.gather_tokens(i16, torch.from_numpy(ln), G, 5)
             ok = ok and u_ids.dtype == torch.int16 and p_ids.dtype == torch.int16 and torch.equal(u_ids, p_ids) and torch.equal(u_ln, full_ln) \
                 and np.array_equal(p_ids.numpy().view(np.uint16).astype(np.int32), full_ids.numpy()) and torch.equal(p_ln, full_ln)
+        # rows the walk has packed itself (ops.sent(..., packed=): completion order, explicit row starts) travel as they are
+        i16n = ids.astype(np.uint16)
+        cap = (int(orc.row_offsets(ref_ln[:-(-G // world)], 160)[-1]) + 64 * 8) // 16 * 16
+        st = {}
+        pp = _Prepacked(i16n, ln, cap, seed=rank)
+        f_ids, f_ln = gtok.dist.gather_tokens(torch.from_numpy(i16n.view(np.int16)), torch.from_numpy(ln), G, 5, compact=True, packed=pp,
+                                              rows_impl=_OracleRows, stats=st)
+        ok = ok and f_ids.dtype == torch.int16 and torch.equal(f_ln, full_ln) and int(st["status"]) == 0 and st["prepacked"] \
+            and np.array_equal(f_ids.numpy().view(np.uint16).astype(np.int32), full_ids.numpy())
+        pp = _Prepacked(i16n, ln, cap, seed=rank, drop=(3,) if rank == 1 else ())      # one rank skipped a row: every rank sees the verdict
+        d_ids, d_ln = gtok.dist.gather_tokens(torch.from_numpy(i16n.view(np.int16)), torch.from_numpy(ln), G, 5, compact=True, packed=pp,
+                                              rows_impl=_OracleRows, stats=st)
+        gone = gtok.dist.block_bounds(G, world)[1][0] + 3
+        keep = np.arange(G) != gone
+        ok = ok and int(st["status"]) == 2 and bool((d_ids[gone] == 5).all()) \
+            and np.array_equal(d_ids.numpy().view(np.uint16).astype(np.int32)[keep], full_ids.numpy()[keep])
         # a caller-given capacity that turns out too small: no rank reads beyond a segment, every rank sees the same verdict,
         # the rows that did not fit come out as pad, the others are right
         st = {}

@@ -289,3 +289,179 @@ def test_lane_kernel_one_nearly_full_round_into_the_padded_int32_slab(wg_waves, 
         for e in range(K):
             ref, rln = orc.sent(coo, 37, 1024, 17, 9 + e, ld=ids.shape[-1], nthreads=min(32, orc.num_threads()), query=q, **kw)
             _eq(ids.view(K, G, -1)[e], ln.view(K, G)[e], ref, rln, f"wg_waves={wg_waves or 'auto'} epoch {e} query={q is not None}")
+
+
+# ---- gtok_sent_packed (ABI v6): the walk appends its rows to a packed buffer; no second pass
+def _zinc_dev(G, seed):
+    d = gtok.synth.zinc_like(G, seed=seed)
+    coo = orc.Coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"])
+    b = gtok.GraphBatch.from_coo(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"]).to(DEV)
+    return d, coo, b
+
+
+def _check_packed(pk, ids, ln, ld, eb_ids, ev=None):
+    """every row's ids sit at row_start, rows start on 16-byte boundaries, do not overlap, and the fill mark is their sum"""
+    ids, ln = ids.reshape(-1, ld).cpu().numpy(), ln.reshape(-1).cpu().numpy()
+    if ids.dtype == np.int16:
+        ids = ids.view(np.uint16)
+    buf = pk.buf.cpu().numpy()
+    buf = buf.view(np.uint16) if buf.dtype == np.int16 else buf
+    st = pk.row_start[:ln.size].cpu().numpy()
+    n = np.clip(ln, 0, ld)
+    ev = ev or 16 // eb_ids
+    assert (st >= 0).all() and (st % ev == 0).all()
+    size = (n + ev - 1) // ev * ev
+    order = np.argsort(st, kind="stable")
+    ends = st[order] + size[order]
+    assert (st[order][1:] >= ends[:-1]).all(), "rows overlap"
+    assert int(pk.used()) == int(size.sum()) and int(pk.status()) == 0 and ends.max() <= pk.capacity
+    if pk.fused:                       # the regions fill evenly: the fullest one ends within a few per cent of the mean
+        fill = pk.state[gtok.ops.PACK_STATE_FILL::gtok.ops.PACK_STATE_STRIDE].cpu().numpy()
+        fill = fill[fill > 0]
+        assert fill.size in (1, 2, 4, 8, 16, 32, 64) and fill.max() <= 1.06 * fill.mean(), (fill.size, fill.max() / fill.mean())
+    cols = np.arange(ld)[None, :]
+    flat = buf[np.minimum(st[:, None] + cols, buf.size - 1)]
+    inside = cols < n[:, None]
+    assert np.array_equal(np.where(inside, flat, 0), np.where(inside, ids, 0))
+
+
+@pytest.mark.parametrize("u16", [True, False])
+@pytest.mark.parametrize("K", [1, 3])
+def test_sent_packed_rows_are_the_slab_rows_and_the_oracle_s(u16, K):
+    G, ld = 30016, 176
+    d, coo, b = _zinc_dev(G, seed=77)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    pk = gtok.ops.PackedRows(K * G, K * G * 112, u16, DEV)
+    guard = torch.full((4096,), 0x5A5A, dtype=pk.buf.dtype, device=DEV)
+    ids, ln = gtok.ops.sent(b, 37, 1024, seed=5, epoch=2, ld=ld, pad=False, epochs=K, u16=u16, packed=pk, **kw)
+    assert pk.fused and gtok.ops.last_sent_kernel() == "sent_lane_kernel"
+    _check_packed(pk, ids, ln, ld, 2 if u16 else 4)
+    # the packed rows are the oracle's (every row of the first and the last epoch slice)
+    lnv = ln.reshape(K, G).cpu().numpy()
+    st = pk.row_start[:K * G].reshape(K, G).cpu().numpy()
+    buf = pk.buf.cpu().numpy()
+    buf = buf.view(np.uint16) if u16 else buf
+    for e in sorted({0, K - 1}):
+        ref, rln = orc.sent(coo, 37, 1024, 5, 2 + e, ld=ld, **kw)
+        assert np.array_equal(lnv[e], rln)
+        cols = np.arange(ld)[None, :]
+        got = buf[np.minimum(st[e][:, None] + cols, buf.size - 1)]
+        inside = cols < rln[:, None]
+        assert np.array_equal(np.where(inside, got, 0), np.where(inside, ref, 0)), e
+    # and the re-padded slab (gtok_unpack_rows_at) is the padded launch's slab
+    full, fln = gtok.ops.sent(b, 37, 1024, seed=5, epoch=2, ld=ld, epochs=K, u16=u16, **kw)
+    stt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    back = gtok.ops.unpack_rows_at(pk.buf, pk.row_start, ln.reshape(-1), ld, 5, status=stt, u16=u16)
+    assert torch.equal(back, full.reshape(-1, ld)) and int(stt.item()) == 0 and torch.equal(fln, ln)
+    assert bool((guard == 0x5A5A).all())
+
+
+def test_sent_packed_too_small_a_buffer_skips_whole_units_and_says_so():
+    G, ld = 30016, 176
+    d, coo, b = _zinc_dev(G, seed=78)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    full, fln = gtok.ops.sent(b, 37, 1024, seed=1, ld=ld, u16=True, **kw)
+    need = int(((fln.clamp(0, ld) + 7) // 8 * 8).sum())
+    cap = need // 2 // 8 * 8
+    pk = gtok.ops.PackedRows(G, cap, True, DEV)
+    assert pk.capacity == cap
+    pk.buf.fill_(0x7777)
+    ids, ln = gtok.ops.sent(b, 37, 1024, seed=1, ld=ld, pad=False, u16=True, packed=pk, **kw)
+    assert pk.fused and int(pk.status()) == 2 and int(pk.used()) == need          # the fill marks count what did not fit as well
+    st = pk.row_start[:G].cpu().numpy()
+    n = fln.clamp(0, ld).cpu().numpy()
+    assert (st < 0).any() and (st >= 0).any()
+    assert ((st < 0) | (st + n <= cap)).all(), "a row that was written lies inside the buffer"
+    stt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    back = gtok.ops.unpack_rows_at(pk.buf, pk.row_start, ln, ld, 5, status=stt, u16=True)
+    kept = torch.from_numpy(st >= 0).to(DEV)
+    assert torch.equal(back[kept], full[kept]) and bool((back[~kept] == 5).all()) and int(stt.item()) == 2
+
+
+def test_sent_packed_falls_back_to_the_one_pass_pack_where_another_kernel_walks():
+    G, ld = 3000, 176                                          # too few walks for the lane kernel: sent_reg_kernel
+    d, coo, b = _zinc_dev(G, seed=79)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    for u16 in (True, False):
+        pk = gtok.ops.PackedRows(G, G * 120, u16, DEV)
+        ids, ln = gtok.ops.sent(b, 37, 1024, seed=3, ld=ld, pad=False, u16=u16, packed=pk, **kw)
+        assert pk.fused is False and gtok.ops.last_sent_kernel() == "sent_reg_kernel"
+        _check_packed(pk, ids, ln, ld, 2 if u16 else 4, ev=8)       # (gtok_pack_rows_scan aligns rows to 8 ids)
+        assert bool((pk.row_start[1:G] > pk.row_start[:G - 1]).all())      # this route packs in dataset order
+    # the C ABI says so instead of launching anything
+    import ctypes
+    L = gtok._lib.lib()
+    p = gtok._lib.GtokSentParams(37, 1, 9, 4, 1024, 1, 5, gtok._lib.SENT_U16, 0, 0, 0, None, 1, 0)
+    cs = b.c_struct()
+    pk = gtok.ops.PackedRows(G, G * 120, True, DEV)
+    pk.row_start.fill_(-7)
+    rc = L.gtok_sent_packed(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), ld, ln.data_ptr(), pk.buf.data_ptr(), pk.capacity,
+                            pk.row_start.data_ptr(), pk.state.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == gtok._lib.E_UNSUPPORTED and bool((pk.row_start == -7).all()) and not bool(pk.state.any())
+
+
+def test_sent_packed_through_the_c_abi_alone():
+    import ctypes
+    G, ld = 30016, 176
+    d, coo, b = _zinc_dev(G, seed=80)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    gtok.ops.sent(b, 37, 1024, seed=0, ld=ld, u16=True, **kw)            # builds the reordered copy
+    sb = b.lane_sorted
+    assert sb is not None
+    L = gtok._lib.lib()
+    cs = sb.c_struct()
+    pk = gtok.ops.PackedRows(2 * G, 2 * G * 112, True, DEV)
+    ids = torch.empty((2, G, ld), dtype=torch.int16, device=DEV)
+    ln = torch.empty((2, G), dtype=torch.int32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    p = gtok._lib.GtokSentParams(37, 1, 9, 4, 1024, 1, 5, gtok._lib.SENT_U16 | gtok._lib.SENT_NO_PAD, 9, 0, 0, None, 2, 0)
+    rc = L.gtok_sent_packed(ctypes.byref(cs), ctypes.byref(p), ids.data_ptr(), ld, ln.data_ptr(), pk.buf.data_ptr(), pk.capacity,
+                            pk.row_start.data_ptr(), pk.state.data_ptr(), st)
+    assert rc == 0
+    pk.fused = True
+    _check_packed(pk, ids, ln, ld, 2)
+    both_at_once, ln2 = gtok.ops.sent(b, 37, 1024, seed=9, epoch=0, ld=ld, epochs=2, u16=True, **kw)
+    back = gtok.ops.unpack_rows_at(pk.buf, pk.row_start, ln.reshape(-1), ld, 5, u16=True)
+    assert torch.equal(back, both_at_once.reshape(-1, ld)) and torch.equal(ln, ln2)
+    # misaligned or missing arguments are refused
+    args = lambda **o: [ctypes.byref(cs), ctypes.byref(p), o.get("ids", ids.data_ptr()), o.get("ld", ld), ln.data_ptr(), o.get("buf", pk.buf.data_ptr()),
+                        o.get("cap", pk.capacity), o.get("rs", pk.row_start.data_ptr()), o.get("state", pk.state.data_ptr()), st]
+    for bad in (dict(ld=172), dict(buf=pk.buf.data_ptr() + 2), dict(buf=None), dict(rs=None), dict(state=None), dict(cap=-1)):
+        assert L.gtok_sent_packed(*args(**bad)) == -1, bad
+
+
+@pytest.mark.parametrize("u16", [True, False])
+def test_sent_pack_only_stages_in_scratch_and_packs_the_same_rows(u16):
+    """GTOK_SENT_PACK_ONLY (ops.sent(..., packed=, slab=False)): no [K, G, ld] slab exists; every wave stages its units in its own
+    64 rows of a per-device scratch.  More (unit, epoch) pairs than resident waves, so every staging row is reused."""
+    import ctypes
+    G, ld, K = 30016, 176, 12
+    d, coo, b = _zinc_dev(G, seed=81)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    pk = gtok.ops.PackedRows(K * G, K * G * 104, u16, DEV)
+    none, ln = gtok.ops.sent(b, 37, 1024, seed=6, epoch=1, ld=ld, epochs=K, u16=u16, packed=pk, slab=False, **kw)
+    assert none is None and pk.fused and tuple(ln.shape) == (K, G)
+    full, fln = gtok.ops.sent(b, 37, 1024, seed=6, epoch=1, ld=ld, epochs=K, u16=u16, **kw)
+    _check_packed(pk, full, ln, ld, 2 if u16 else 4)
+    back = gtok.ops.unpack_rows_at(pk.buf, pk.row_start, ln.reshape(-1), ld, 5, u16=u16)
+    assert torch.equal(back, full.reshape(-1, ld)) and torch.equal(ln, fln)
+    for e in (0, K - 1):                                   # and the oracle's, first and last epoch
+        ref, rln = orc.sent(coo, 37, 1024, 6, 1 + e, ld=ld, **kw)
+        got = back.reshape(K, G, ld)[e].cpu().numpy()
+        got = got.view(np.uint16).astype(np.int32) if u16 else got
+        assert np.array_equal(got, ref) and np.array_equal(ln[e].cpu().numpy(), rln)
+    L = gtok._lib.lib()
+    rows = L.gtok_sent_pack_scratch_rows(None)
+    assert rows == 64 * 16 * torch.cuda.get_device_properties(0).multi_processor_count
+    # the flag belongs to gtok_sent_packed: gtok_sent refuses it
+    p = gtok._lib.GtokSentParams(37, 1, 9, 4, 1024, 1, 5, gtok._lib.SENT_PACK_ONLY | (gtok._lib.SENT_U16 if u16 else 0), 6, 1, 0, None, 1, 0)
+    cs = b.lane_sorted.c_struct()
+    assert L.gtok_sent(ctypes.byref(cs), ctypes.byref(p), full.data_ptr(), ld, fln.data_ptr(), None) == -1
+    # a batch another kernel walks: the same call falls back to a temporary slab + the one-pass pack
+    d2, coo2, b2 = _zinc_dev(2000, seed=82)
+    pk2 = gtok.ops.PackedRows(2000, 2000 * 120, u16, DEV)
+    none, ln2 = gtok.ops.sent(b2, 37, 1024, seed=6, ld=ld, u16=u16, packed=pk2, slab=False, **kw)
+    full2, _ = gtok.ops.sent(b2, 37, 1024, seed=6, ld=ld, u16=u16, **kw)
+    assert none is None and pk2.fused is False
+    assert torch.equal(gtok.ops.unpack_rows_at(pk2.buf, pk2.row_start, ln2, ld, 5, u16=u16), full2)
