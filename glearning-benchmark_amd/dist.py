@@ -132,8 +132,8 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
 
 
 def _gather_prepacked(ids, ln, num_graphs, pad_id, packed, rows_impl, stats, world, per, ld):
-    """the compact exchange of rows the walk has packed already (gather_tokens(packed=)): packed buffer + (row starts, lengths,
-    status) of every rank, two collectives, one re-padding pass"""
+    """the compact exchange of rows the walk has packed already (gather_tokens(packed=)): packed buffer, row starts, lengths + status of
+    every rank - three collectives, one re-padding pass"""
     dev = ln.device
     capacity = int(packed.capacity)
     start = packed.row_start[:per]
@@ -141,18 +141,19 @@ def _gather_prepacked(ids, ln, num_graphs, pad_id, packed, rows_impl, stats, wor
         start = torch.cat([start, torch.zeros(per - start.numel(), dtype=torch.int64, device=dev)])
     all_packed = torch.empty(world * capacity, dtype=packed.buf.dtype, device=dev)
     dist.all_gather_into_tensor(all_packed.view(torch.uint8), packed.buf[:capacity].view(torch.uint8))
-    ext = torch.cat([start, ln.to(torch.int64), packed.status().to(torch.int64).reshape(1)])     # starts + lengths + status, one collective
-    all_ext = torch.empty((world, 2 * per + 1), dtype=torch.int64, device=dev)
+    all_start = torch.empty(world * per, dtype=torch.int64, device=dev)                  # the row starts as they are (no widening,
+    dist.all_gather_into_tensor(all_start, start.contiguous())                          # no slicing on the way back) ...
+    ext = torch.cat([ln, packed.status().to(ln.dtype).reshape(1)])                       # ... lengths + this rank's status, one collective
+    all_ext = torch.empty((world, per + 1), dtype=ln.dtype, device=dev)
     dist.all_gather_into_tensor(all_ext.view(-1), ext)
-    all_start = all_ext[:, :per].contiguous().view(-1)
-    all_ln = all_ext[:, per:2 * per].to(torch.int32).contiguous().view(-1)
+    all_ln = all_ext[:, :per].reshape(-1).contiguous()
     ustatus = torch.zeros(1, dtype=torch.int32, device=dev)
     u16 = packed.buf.dtype == torch.int16
     all_ids = rows_impl.unpack_rows_at(all_packed, all_start, all_ln, ld, pad_id, segment_rows=per, segment_stride=capacity, status=ustatus,
                                        **({"u16": True} if u16 else {}))
-    verdict = torch.maximum(all_ext[:, 2 * per].max().to(torch.int32).reshape(1), ustatus)
+    verdict = torch.maximum(all_ext[:, per].max().to(torch.int32).reshape(1), ustatus)
     if stats is not None:
-        stats.update(bytes_sent_per_rank=capacity * packed.buf.element_size() + (2 * per + 1) * 8, compact=True,
+        stats.update(bytes_sent_per_rank=capacity * packed.buf.element_size() + per * 8 + (per + 1) * 4, compact=True,
                      elem_bytes=packed.buf.element_size(), capacity=capacity, status=verdict, prepacked=True)
     return all_ids[:num_graphs], all_ln[:num_graphs]
 

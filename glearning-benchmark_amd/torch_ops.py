@@ -259,6 +259,56 @@ _FRAG.impl("sent_epochs", sent_epochs, "CUDA")
 torch.library.register_fake("gtok::sent_epochs", _sent_epochs_fake, lib=_FRAG)
 
 
+def sent_packed(node_ptr: Tensor, edge_ptr: Tensor, rowptr: Tensor, col: Tensor, nattr: Optional[Tensor],
+                eattr: Optional[Tensor], query: Optional[Tensor], max_nodes: int, max_edges: int, max_num_nodes: int,
+                max_len: int, ld: int, seed: int, epoch: int, epochs: int, labeled: bool, num_node_types: int, num_edge_types: int,
+                remap_zinc: bool, pad_id: int, graph_base: int, u16: bool, capacity: int, graph_ids: Optional[Tensor] = None,
+                unit_ptr: Optional[Tensor] = None, unit_info: Optional[Tensor] = None, rowptr8: Optional[Tensor] = None,
+                col8: Optional[Tensor] = None, adj_rows: Optional[Tensor] = None, adj_planes: Optional[Tensor] = None,
+                lane_order: Optional[Tensor] = None, layout: Optional[List[int]] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """gtok_sent_packed with GTOK_SENT_PACK_ONLY (ABI v6): the walk of `epochs` epochs packs its rows itself and writes no slab ->
+    (len int32 [epochs * G], packed [capacity rounded up to 8] ids - int16 storage when u16 -, row_start int64 [epochs * G], state
+    int64 [2] = (ids used, status bits: 2 = rows did not fit)).  Readers: gtok::unpack_rows_at, gtok::collate_packed with row_ptr =
+    row_start.  Batches another kernel walks go through a temporary slab and gtok_pack_rows_scan (same outputs, dataset order)."""
+    b = _sent_batch(node_ptr, edge_ptr, rowptr, col, nattr, eattr, max_nodes, max_edges, graph_ids, unit_ptr, unit_info, rowptr8, col8,
+                    adj_rows, adj_planes, lane_order, layout)
+    rows = b.num_graphs * max(1, epochs)
+    pk = _ops.PackedRows(rows, capacity, u16, b.device)
+    _, ln = _ops.sent(b, max_num_nodes, max_len, seed, epoch, labeled=labeled, num_node_types=num_node_types,
+                      num_edge_types=num_edge_types, remap_zinc=remap_zinc, pad_id=pad_id, graph_base=graph_base,
+                      query=query, ld=ld, epochs=epochs, u16=u16, packed=pk, slab=False)
+    return ln.reshape(-1), pk.buf, pk.row_start[:rows], torch.stack([pk.used(), pk.state[0]])
+
+
+def _sent_packed_fake(node_ptr, edge_ptr, rowptr, col, nattr, eattr, query, max_nodes, max_edges, max_num_nodes, max_len, ld, seed,
+                      epoch, epochs, labeled, num_node_types, num_edge_types, remap_zinc, pad_id, graph_base, u16, capacity, graph_ids=None,
+                      unit_ptr=None, unit_info=None, rowptr8=None, col8=None, adj_rows=None, adj_planes=None, lane_order=None, layout=None):
+    rows = (node_ptr.shape[0] - 1) * max(1, epochs)
+    cap = max(8, -(-capacity // 8) * 8)
+    return (node_ptr.new_empty((rows,), dtype=torch.int32), node_ptr.new_empty((cap,), dtype=torch.int16 if u16 else torch.int32),
+            node_ptr.new_empty((rows,), dtype=torch.int64), node_ptr.new_empty((2,), dtype=torch.int64))
+
+
+_FRAG.define("sent_packed(Tensor node_ptr, Tensor edge_ptr, Tensor rowptr, Tensor col, Tensor? nattr, Tensor? eattr, Tensor? query, int max_nodes, "
+             "int max_edges, int max_num_nodes, int max_len, int ld, int seed, int epoch, int epochs, bool labeled, int num_node_types, "
+             "int num_edge_types, bool remap_zinc, int pad_id, int graph_base, bool u16, int capacity, " + _PREPARED_SCHEMA
+             + ") -> (Tensor, Tensor, Tensor, Tensor)")
+_FRAG.impl("sent_packed", sent_packed, "CUDA")
+torch.library.register_fake("gtok::sent_packed", _sent_packed_fake, lib=_FRAG)
+
+
+@torch.library.custom_op("gtok::unpack_rows_at", mutates_args=(), device_types="cuda")
+def unpack_rows_at(packed: Tensor, row_start: Tensor, lens: Tensor, ld: int, pad_id: int, segment_rows: int, segment_stride: int,
+                   u16: bool) -> Tensor:
+    """gtok_unpack_rows_at: rows with explicit starts (gtok::sent_packed's row_start) -> [rows, ld] slab, 16-bit when u16."""
+    return _ops.unpack_rows_at(packed, row_start, lens, ld, pad_id, segment_rows, segment_stride, u16=u16)
+
+
+@unpack_rows_at.register_fake
+def _(packed, row_start, lens, ld, pad_id, segment_rows, segment_stride, u16):
+    return packed.new_empty((lens.shape[0], ld), dtype=torch.int16 if u16 else torch.int32)
+
+
 @torch.library.custom_op("gtok::ibtt_zinc", mutates_args=(), device_types="cuda")
 def ibtt_zinc(node_ptr: Tensor, edge_ptr: Tensor, rowptr: Tensor, col: Tensor, eorder: Optional[Tensor],
               nattr: Optional[Tensor], eattr: Optional[Tensor], lut: Tensor, max_nodes: int, max_edges: int,

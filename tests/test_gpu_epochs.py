@@ -465,3 +465,31 @@ def test_sent_pack_only_stages_in_scratch_and_packs_the_same_rows(u16):
     full2, _ = gtok.ops.sent(b2, 37, 1024, seed=6, ld=ld, u16=u16, **kw)
     assert none is None and pk2.fused is False
     assert torch.equal(gtok.ops.unpack_rows_at(pk2.buf, pk2.row_start, ln2, ld, 5, u16=u16), full2)
+
+
+def test_sent_packed_through_the_torch_custom_ops():
+    """torch.ops.gtok.sent_packed -> (len, packed, row_start, state); unpack_rows_at / collate_packed read it; the fake kernels
+    give the same shapes; a small batch (another kernel) goes the two-pass way behind the same op."""
+    for G, K, fused_kernel in ((30016, 2, True), (700, 3, False)):
+        d = gtok.synth.zinc_like(G, seed=56)
+        batch, coo = both(d)
+        b = batch.to(DEV)
+        args = (b.node_ptr, b.edge_ptr, b.rowptr, b.col, b.nattr, b.eattr, None, b.max_nodes, b.max_edges, 37, 1024, 176, 9, 2, K, True, 9, 4,
+                True, 5, 0, True, K * G * 112)
+        ln, packed, start, state = torch.ops.gtok.sent_packed(*args)
+        assert packed.dtype == torch.int16 and tuple(ln.shape) == (K * G,) and tuple(start.shape) == (K * G,) and state.tolist()[1] == 0
+        assert (gtok.ops.last_sent_kernel() == "sent_lane_kernel") == fused_kernel
+        assert state.tolist()[0] == int(((ln.clamp(0, 176) + 7) // 8 * 8).sum())
+        slab = torch.ops.gtok.unpack_rows_at(packed, start, ln, 176, 5, 0, 0, True)
+        for e in range(K):
+            ref, rln = orc.sent(coo, 37, 1024, 9, 2 + e, ld=176, labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+            _eq(slab[e * G:(e + 1) * G], ln[e * G:(e + 1) * G], ref, rln, f"torch.ops.gtok.sent_packed slice {e}")
+        idx = torch.arange(0, K * G, 11, device=DEV)
+        X, A = torch.ops.gtok.collate_packed(packed, start, ln, 176, idx, 5, 176)
+        X2, A2 = gtok.ops.collate(torch.ops.gtok.unpack_rows(slab, None, ln, 176, 5, 0, 0), ln, idx, 5, 176)
+        assert torch.equal(X, X2) and torch.equal(A, A2)
+        from torch._subclasses.fake_tensor import FakeTensorMode
+        with FakeTensorMode() as mode:
+            fk = [mode.from_tensor(a) if isinstance(a, torch.Tensor) else a for a in args]
+            f = torch.ops.gtok.sent_packed(*fk)
+        assert [tuple(t.shape) for t in f] == [tuple(t.shape) for t in (ln, packed, start, state)] and [t.dtype for t in f] == [t.dtype for t in (ln, packed, start, state)]
