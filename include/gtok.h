@@ -17,13 +17,15 @@
  *                      trainer/train_agtt.py:250 (SENT walk; spec in DESIGN.md,
  *                      upstream parity unpinned), optionally fused with
  *                      remap_zinc_tokens (:171-244) and the query append (:257-267)
+ *   gtok_sent_packed   gtok_sent whose walk also appends every row to a packed buffer (the payload of the all-gather behind the
+ *                      val / test loaders, trainer/train_agtt.py:602-607, and of the D2H copy behind :246-273) - no second pass
  *   gtok_sent_decode   the SENT spec read backwards (token rows -> graphs in visit-index space)
  *   gtok_remap_zinc    trainer/train_agtt.py:171-244 on an existing token slab
  *   gtok_collate       data_loader.py:488-497 and trainer/train_agtt.py:276-302
  *                      (gather rows of a batch, pad to the batch max, bool mask)
  *   gtok_parse_graph_text  graph_token_dataset_autograph.py:14-158 (text -> edges, query, label)
  *   gtok_find_token    the `<q>` search of trainer/train_ibtt.py:88-103 on a collated batch
- *   gtok_row_offsets / gtok_pack_rows / gtok_pack_rows_u16 / gtok_pack_rows_scan / gtok_unpack_rows / gtok_unpack_rows_checked / gtok_unpack_rows_u16 / gtok_collate_packed
+ *   gtok_row_offsets / gtok_pack_rows / gtok_pack_rows_u16 / gtok_pack_rows_scan / gtok_unpack_rows / gtok_unpack_rows_checked / gtok_unpack_rows_u16 / gtok_unpack_rows_at / gtok_collate_packed
  *                      (no reference counterpart) the packed form of a token slab - rows back to back, 16 or 32
  *                      bits per id - for the copies that leave the GPU: the all-gather that reassembles the rows of
  *                      every rank in dataset order (val/test loaders, trainer/train_agtt.py:602-607) and the D2H
@@ -572,7 +574,8 @@ const char *gtok_ibtt_zinc_kernel_name(const gtok_csr *g);
 /* ABI version (GTOK_ABI_VERSION of the header the library was built from: 2 since gtok_csr carries the optional
  * mirrors - a binding checks it before passing structs; 3 adds the packed-row entry points; 4: gtok_sent_params carries
  * epoch_count, GTOK_SENT_U16, the strided / checked packed-row readers; 5 adds gtok_csr_check / gtok_csr_lane_sort -
- * structs unchanged) and build target string ("gfx950").                     */
+ * structs unchanged; 6 adds gtok_sent_packed / GTOK_SENT_PACK_ONLY / gtok_unpack_rows_at / GTOK_E_UNSUPPORTED - structs
+ * unchanged) and build target string ("gfx950").                     */
 #define GTOK_ABI_VERSION 6
 int gtok_version(void);
 const char *gtok_target(void);
