@@ -192,6 +192,13 @@ def boundary_section(d, G, dev, max_nodes, max_len):
         t, n = clock(lambda: loader_epoch(dl))
         out["agtt_dataloader_batch_sampler"] = dict(items_per_sec=round(n / t, 1), batch_size=128, items=n, shuffle=True,
                                                     note="DataLoader(ds, batch_sampler=agtt.EpochBatchSampler(len(ds), 128, shuffle=True), num_workers=0, collate_fn=agtt.collate_fn)")
+        # ... and with the sampler announcing its batches to the dataset: one gtok_collate_epoch call per epoch, a batch is three views
+        dl = DataLoader(ds, batch_sampler=gtok.agtt.EpochBatchSampler(len(ds), 128, shuffle=True, dataset=ds), num_workers=0, collate_fn=gtok.agtt.collate_fn)
+        clock(lambda: loader_epoch(dl))
+        t, n = clock(lambda: loader_epoch(dl))
+        out["agtt_dataloader_planned"] = dict(items_per_sec=round(n / t, 1), batch_size=128, items=n, shuffle=True,
+                                              note="DataLoader(ds, batch_sampler=agtt.EpochBatchSampler(len(ds), 128, shuffle=True, dataset=ds), num_workers=0, "
+                                                   "collate_fn=agtt.collate_fn): the loader's two lines of trainer/train_agtt.py:599-601 with the sampler swapped")
 
         def batches(with_data, bs=128):
             n = 0

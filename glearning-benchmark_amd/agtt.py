@@ -40,6 +40,7 @@ class TokenizedGraphDataset(Dataset):
         self._slab = None                      # (ids16 [K, G, ld], len [K, G], first epoch, padded): the last K-epoch launch
         self._slab_sig = None                  # ... and what it was made with (tokenizer configuration, remap switch, query table)
         self._served = None                    # __getitems__: which rows of the current epoch went out already
+        self._plan = None                      # plan_epoch: the announced batches of an epoch and, once asked for, their arenas
         self._y_dev = None                     # labels on the device (batch-level fetch)
         self._lens_h = None                    # the current epoch's row lengths on the host (batch-level fetch)
 
@@ -181,6 +182,11 @@ class TokenizedGraphDataset(Dataset):
         self._graphs()
         if self._mixed_query:
             return [self[i] for i in indices]
+        plan = self._plan
+        if plan is not None:
+            k = plan["ids"].get(id(indices))
+            if k is not None and plan["lists"][k] is indices:
+                return self._planned_batch(plan, k)
         idx = np.asarray(indices, dtype=np.int64)
         if len(set(indices)) != idx.size:
             # a sampler with replacement put an item into the batch twice: in the reference every fetch of an item is a new
@@ -195,6 +201,39 @@ class TokenizedGraphDataset(Dataset):
         # the index list stays on the host: it rides in the launch's arguments, and the labels come out of the same launch
         X, A, Y = _ops.collate_batch(self._ids, None, self._lens, self._ids.shape[1], idx, PAD, lmax, self._labels_on_device())
         return CollatedBatch(self, idx, X, A, Y, self._epoch)
+
+    def plan_epoch(self, order: np.ndarray, batch_size: int, drop_last: bool = False):
+        """The batches of one epoch, announced before they are asked for (EpochBatchSampler(..., dataset=this) does it): returns the
+        index lists to hand to the DataLoader; when __getitems__ later receives one of these very list objects it serves the batch out
+        of ONE gtok_collate_epoch call over the whole plan (made when the plan's first batch is asked for - that is also when the
+        next epoch's trails are taken, as a batch that revisits a served row would) - three views per batch, no launch.  Lists that
+        are not the plan's (or a plan abandoned half-way) take the per-batch path as before."""
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        n = order.size - (order.size % batch_size if drop_last else 0)
+        lists = [order[s:s + batch_size].tolist() for s in range(0, n, batch_size)]
+        self._plan = dict(order=order[:n], bs=int(batch_size), lists=lists, ids={id(l): k for k, l in enumerate(lists)}, arenas=None)
+        return lists
+
+    def _planned_batch(self, plan, k):
+        ar = plan["arenas"]
+        if ar is None:
+            order = plan["order"]
+            if len(np.unique(order)) != order.size:
+                self._plan = None                           # (a plan with repeats: every fetch of an item is a new trail - per-batch path)
+                return self.__getitems__(list(plan["lists"][k]))
+            if self._served is None or self._ids is None or self._ids.dtype != torch.int16 or self._served[order].any():
+                self.tokenize_epoch_u16(self._epoch + 1)
+                self._served = np.zeros(len(self), dtype=bool)
+                self._lens_h = self._lens.cpu().numpy()
+            self._served[order] = True
+            od = torch.from_numpy(order).to(self._ids.device)
+            X, A, lmax, off = _ops.collate_epoch(self._ids, None, self._lens, self._ids.shape[1], od, plan["bs"], PAD)
+            ar = plan["arenas"] = (X, A, lmax, off, self._labels_on_device()[od], self._epoch)
+        X, A, lmax, off, y, epoch = ar
+        s = k * plan["bs"]
+        lst = plan["lists"][k]
+        B, L, o = len(lst), lmax[k], off[k]
+        return CollatedBatch(self, lst, X.as_strided((B, L), (L, 1), o), A.as_strided((B, L), (L, 1), o), y[s:s + B], epoch)
 
     def device_batches(self, batch_size: int, epoch: int, shuffle: bool = False,
                        generator: Optional[torch.Generator] = None, with_data: bool = True):
@@ -224,11 +263,14 @@ class EpochBatchSampler(torch.utils.data.Sampler):
     shuffle=True), collate_fn=collate_fn)`.  The stock `shuffle=True` loader draws its indices one Python int at a time through two
     generator frames - 38 us per batch of 128 on the bench host before the dataset is asked for anything, i.e. at most 3.4 x 10^6
     items/s whatever the dataset does (`profiles/r05/time_loader.txt`); this sampler hands the same kind of lists over at ~3 us per
-    batch.  Same distribution as RandomSampler without replacement (a fresh `torch.randperm` per epoch, from `generator` if given)."""
+    batch.  Same distribution as RandomSampler without replacement (a fresh `torch.randperm` per epoch, from `generator` if given).
+    dataset=<the TokenizedGraphDataset>: the sampler also announces every epoch's batches to the dataset (`plan_epoch`), which then
+    collates the whole epoch in one launch and serves each batch as views."""
 
     def __init__(self, num_items: int, batch_size: int, shuffle: bool = False, drop_last: bool = False,
-                 generator: Optional[torch.Generator] = None):
+                 generator: Optional[torch.Generator] = None, dataset=None):
         self.n, self.batch_size, self.shuffle, self.drop_last, self.generator = int(num_items), int(batch_size), shuffle, drop_last, generator
+        self.dataset = dataset if hasattr(dataset, "plan_epoch") else None
 
     def __len__(self):
         return self.n // self.batch_size if self.drop_last else -(-self.n // self.batch_size)
@@ -236,6 +278,11 @@ class EpochBatchSampler(torch.utils.data.Sampler):
     def __iter__(self):
         order = (torch.randperm(self.n, generator=self.generator) if self.shuffle else torch.arange(self.n)).numpy()
         bs = self.batch_size
+        if self.dataset is not None:
+            # the dataset learns the epoch's batches before the loader asks for them: it collates them all in one call and answers
+            # each list with views (TokenizedGraphDataset.plan_epoch)
+            yield from self.dataset.plan_epoch(order, bs, self.drop_last)
+            return
         for s in range(0, self.n - (self.n % bs if self.drop_last else 0), bs):
             yield order[s:s + bs].tolist()
 
@@ -263,7 +310,7 @@ class CollatedBatch(Sequence):
 
     def __init__(self, owner, idx, X, A, Y, epoch):
         self._owner, self._idx, self.epoch = owner, idx, epoch
-        self.collated = (X, A, Y, LazyDataList(owner.pyg_dataset, idx.tolist()))
+        self.collated = (X, A, Y, LazyDataList(owner.pyg_dataset, idx if isinstance(idx, list) else idx.tolist()))
         self._items = None
 
     def __len__(self):

@@ -414,6 +414,33 @@ def test_device_batches_collate_the_epoch_in_one_call_and_the_slab_follows_the_t
         assert X.is_cuda and X.shape[0] == len(datas) == Y.shape[0] and abs(float(Y[0]) - float(datas[0].y)) < 1e-6
         seen += X.shape[0]
     assert seen == G
+    # the sampler that announces its batches (dataset=ds): the whole epoch is collated by ONE call when its first batch is asked for,
+    # every batch is three views - same tensors as the per-batch route over the same epoch's rows, labels and Data objects included
+    gen = torch.Generator().manual_seed(11)
+    bs_plan = agtt.EpochBatchSampler(G, 96, shuffle=True, generator=gen, dataset=ds)
+    loader = DataLoader(ds, batch_sampler=bs_plan, num_workers=0, collate_fn=agtt.collate_fn)
+    epochs_seen = []
+    for rep in range(2):
+        got = [(X, A, Y, float(datas[0].y), len(datas)) for X, A, Y, datas in loader]
+        lists = ds._plan["lists"]
+        assert len(got) == len(lists) == -(-G // 96) and sorted(i for l in lists for i in l) == list(range(G))
+        epochs_seen.append(ds._epoch)
+        ld_ = ds._ids.shape[1]
+        for (X, A, Y, y0, n), l in zip(got, lists):
+            idx = torch.tensor(l, device=DEV)
+            lmax = int(ds._lens[idx].clamp(max=ld_).max())
+            rX, rA = gtok.ops.collate_packed(ds._ids, None, ds._lens, ld_, idx, 5, lmax)
+            assert n == len(l) and torch.equal(X, rX) and torch.equal(A, rA) and torch.equal(Y, ds._labels_on_device()[idx]) and abs(y0 - float(Y[0])) < 1e-6
+    assert epochs_seen[1] == epochs_seen[0] + 1                      # a new plan = the next epoch's trails
+    # a list that is not the plan's own object goes the per-batch way (and, its rows being served already, starts the next epoch)
+    cb = ds.__getitems__(list(ds._plan["lists"][0]))
+    assert isinstance(cb, agtt.CollatedBatch) and ds._epoch == epochs_seen[1] + 1
+    assert len(list(agtt.EpochBatchSampler(G, 96, drop_last=True, dataset=ds))) == G // 96
+    # an abandoned plan: the loader is dropped after two batches, the next iteration plans again
+    it = iter(loader)
+    next(it); next(it)
+    del it
+    assert sum(X.shape[0] for X, _, _, _ in loader) == G
     # (pin_memory=True is not supported over device batches - the loader pins what collate_fn returns, and CUDA tensors cannot be
     # pinned; the reference's loaders do not set it, INTEGRATION.md says so.)  The fetcher's own object passes a pin request through:
     cb = ds.__getitems__([1, 2, 5])

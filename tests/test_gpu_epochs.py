@@ -493,3 +493,22 @@ def test_sent_packed_through_the_torch_custom_ops():
             fk = [mode.from_tensor(a) if isinstance(a, torch.Tensor) else a for a in args]
             f = torch.ops.gtok.sent_packed(*fk)
         assert [tuple(t.shape) for t in f] == [tuple(t.shape) for t in (ln, packed, start, state)] and [t.dtype for t in f] == [t.dtype for t in (ln, packed, start, state)]
+
+
+@pytest.mark.parametrize("G,K", [(31182, 16), (31182, 8), (62364, 8), (249456, 1)])
+def test_sent_packed_regions_fill_evenly_at_the_shapes_the_exchange_uses(G, K):
+    """An eighth / a quarter of ZINC-full at the epochs per launch the strong-scaling leg picks, and the whole corpus: a buffer of the
+    rows' total + 4 % (+ 4096 ids) holds them - no region overflows (bench.py sizes its buffers by that rule)."""
+    d = gtok.synth.zinc_like(G, seed=1000)
+    b = gtok.GraphBatch.from_coo_device(d["node_counts"], d["edge_counts"], d["src"], d["dst"], d["x"], d["edge_attr"], device=DEV)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    _, ln0 = gtok.ops.sent(b, 37, 1024, seed=0, epoch=0, ld=176, pad=False, epochs=K, u16=True, **kw)
+    need = int(((ln0.reshape(-1).clamp(0, 176) + 7) // 8 * 8).sum())
+    pk = gtok.ops.PackedRows(K * G, int(need * 1.04) + 4096, True, DEV)
+    for epoch in (0, 5 * K):                                    # the epochs the buffer was sized on, and later ones
+        _, ln = gtok.ops.sent(b, 37, 1024, seed=0, epoch=epoch, ld=176, epochs=K, u16=True, packed=pk, slab=False, **kw)
+        fill = pk.state[gtok.ops.PACK_STATE_FILL::gtok.ops.PACK_STATE_STRIDE].cpu().numpy()
+        fill = fill[fill > 0]
+        assert pk.fused and int(pk.status()) == 0 and bool((pk.row_start[:K * G] >= 0).all()), (fill.size, fill.max() / fill.mean())
+        assert fill.max() <= 1.03 * fill.mean(), (fill.size, fill.max() / fill.mean())
+    assert torch.equal(ln.reshape(-1)[:G], gtok.ops.sent(b, 37, 1024, seed=0, epoch=5 * K, ld=176, u16=True, pad=False, **kw)[1])
