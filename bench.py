@@ -886,10 +886,12 @@ def main():
             spk = {}
 
             def sstep(k, gather):
-                if gather == "compact":    # the walk packs the rows itself and writes no slab (gtok_sent_packed, GTOK_SENT_PACK_ONLY); capacity = the first launch's largest rank + 4 %
+                if gather in ("compact", "compact_packed"):
+                    # the walk packs the rows itself and writes no slab (gtok_sent_packed, GTOK_SENT_PACK_ONLY); capacity = the first launch's largest rank + 4 %;
+                    # compact_packed: the gathered rows are not re-padded either (absolute row starts: what the collate kernels read in place)
                     _, cln = gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k * Es, ld=ld, epochs=Es, u16=True, packed=spk["pk"], slab=False, **kws)
                     return gtok.dist.gather_tokens(None, cln.reshape(-1), Gt * Es, 5, force=True, compact=True, packed=spk["pk"], ld=ld,
-                                                   stats=gstats.setdefault("compact", {}))
+                                                   as_packed=gather == "compact_packed", stats=gstats.setdefault(gather, {}))
                 gtok.ops.sent(mine, max_nodes, max_len, seed=0, epoch=k * Es, ld=ld, out=(sids, sln), pad=False, epochs=Es, u16=True, **kws)
                 if gather == "padded":      # the 16-bit slab as it is (pad tails and all: they are not written, the bytes still travel)
                     return gtok.dist.gather_tokens(sids, sln, Gt * Es, 5, force=True, stats=gstats.setdefault("padded", {}))
@@ -898,7 +900,7 @@ def main():
                                                    stats=gstats.setdefault("compact_scan", {}))
             res = {}
             n_sl = max(2, -(-args.steps // Es))
-            for gather in (None, "padded", "compact_scan", "compact"):
+            for gather in (None, "padded", "compact_scan", "compact", "compact_packed"):
                 if gather == "compact_scan":
                     sstep(0, gather)                              # sized by an all-reduce once ...
                     gstats["cap"] = int(gstats["compact_scan"]["capacity"] * 1.04) + 4096      # ... then a fixed bound, the same on every rank
@@ -920,6 +922,9 @@ def main():
                         and bool((c_ids[~inside] == 5).all())) and int(gstats["compact"]["status"].item()) == 0
             s_ids, s_ln = sstep(args.warmup, "compact_scan")
             same = same and torch.equal(s_ln, c_ln) and torch.equal(s_ids, c_ids) and int(gstats["compact_scan"]["status"].item()) == 0
+            (k_buf, k_start), k_ln = sstep(args.warmup, "compact_packed")          # the rows that stayed packed, re-padded here for the comparison only
+            k_ids = gtok.ops.unpack_rows_at(k_buf, k_start.contiguous(), k_ln.contiguous(), ld, 5, u16=True)
+            same = same and torch.equal(k_ln, c_ln) and torch.equal(k_ids, c_ids) and int(gstats["compact_packed"]["status"].item()) == 0
             epochs_timed = n_sl * Es
             per_epoch = lambda t: round(t / epochs_timed * 1e3, 5)
             out["strong_scaling"] = dict(
@@ -935,6 +940,10 @@ def main():
                 compact=dict(ms_per_epoch=per_epoch(res["compact"]), exchange_ms_per_epoch=per_epoch(res["compact"] - res[None]),
                              bytes_sent_per_rank_per_epoch=gstats["compact"]["bytes_sent_per_rank"] // Es,
                              bytes_gathered_per_rank_per_epoch=world * gstats["compact"]["bytes_sent_per_rank"] // Es),
+                compact_packed=dict(ms_per_epoch=per_epoch(res["compact_packed"]), exchange_ms_per_epoch=per_epoch(res["compact_packed"] - res[None]),
+                                    bytes_sent_per_rank_per_epoch=gstats["compact_packed"]["bytes_sent_per_rank"] // Es,
+                                    note="as compact, and the gathered rows stay packed (dist.gather_tokens(..., as_packed=True) -> (buffer, absolute row starts), lengths): "
+                                         "gtok_collate_packed / _batch / _epoch read them in place, nothing is re-padded"),
                 compact_scan=dict(ms_per_epoch=per_epoch(res["compact_scan"]), exchange_ms_per_epoch=per_epoch(res["compact_scan"] - res[None]),
                                   bytes_sent_per_rank_per_epoch=gstats["compact_scan"]["bytes_sent_per_rank"] // Es,
                                   note="the rows packed in a second pass (gtok_pack_rows_scan), lengths only beside them"),

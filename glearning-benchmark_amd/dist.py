@@ -39,7 +39,7 @@ def shard_of(batch, rank: int = None, world: int = None):
 
 def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: int, force: bool = False,
                   compact: bool = False, elem_bytes: int = 2, capacity: int = None, rows_impl=None, stats: dict = None,
-                  packed=None, ld: int = None):
+                  packed=None, ld: int = None, as_packed: bool = False):
     """All-gather the per-rank [G_local, ld] slabs + lengths into the full [G, ld] slab on every rank.
 
     Ranks hold blocks from block_bounds(); the last blocks may be short, so every rank pads its
@@ -63,7 +63,10 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     packed already (by the walk itself: gtok_sent_packed), so nothing is packed here; every rank must pass a buffer of the SAME
     capacity (that is the agreed size: no size exchange), each row's start travels with its length, and gtok_unpack_rows_at
     re-pads.  Verdict as with a caller-given capacity: stats["status"].  `ids` may then be None (ops.sent(..., slab=False) wrote
-    no slab): pass the slab width as `ld`.
+    no slab): pass the slab width as `ld`.  as_packed=True (with packed=): the gathered rows are NOT re-padded - the call returns
+    ((all_packed, row_start), len) with row_start[r] the absolute position of global row r in all_packed (what gtok_collate_packed /
+    gtok_collate_batch / gtok_collate_epoch read in place through row_ptr = row_start, and gtok_unpack_rows_at re-pads if a slab is
+    wanted after all); rows a rank had to skip come back with length 0.
     rows_impl: the module providing row_offsets / pack_rows / unpack_rows (default: ops, i.e. the HIP kernels; the CPU
     tests of the collective pass the oracle's).  stats: a dict that receives the bytes each rank contributed."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
@@ -77,7 +80,7 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
             ln = torch.cat([ln.reshape(-1), torch.zeros(per - ln.numel(), dtype=ln.dtype, device=ln.device)])
         if rows_impl is None:
             from . import ops as rows_impl
-        return _gather_prepacked(None, ln.reshape(-1).contiguous(), num_graphs, pad_id, packed, rows_impl, stats, world, per, int(ld))
+        return _gather_prepacked(None, ln.reshape(-1).contiguous(), num_graphs, pad_id, packed, rows_impl, stats, world, per, int(ld), as_packed)
     ld = ids.shape[1]
     if ids.shape[0] < per:
         fill = per - ids.shape[0]
@@ -95,7 +98,7 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     if rows_impl is None:
         from . import ops as rows_impl
     if packed is not None:
-        return _gather_prepacked(ids, ln, num_graphs, pad_id, packed, rows_impl, stats, world, per, ld)
+        return _gather_prepacked(ids, ln, num_graphs, pad_id, packed, rows_impl, stats, world, per, ld, as_packed)
     pack = rows_impl.pack_rows_u16 if ids.dtype == torch.int16 else rows_impl.pack_rows
     caller_bound = capacity is not None
     row_ptr = None
@@ -131,7 +134,7 @@ def gather_tokens(ids: torch.Tensor, ln: torch.Tensor, num_graphs: int, pad_id: 
     return all_ids[:num_graphs], all_ln[:num_graphs]
 
 
-def _gather_prepacked(ids, ln, num_graphs, pad_id, packed, rows_impl, stats, world, per, ld):
+def _gather_prepacked(ids, ln, num_graphs, pad_id, packed, rows_impl, stats, world, per, ld, as_packed=False):
     """the compact exchange of rows the walk has packed already (gather_tokens(packed=)): packed buffer, row starts, lengths + status of
     every rank - three collectives, one re-padding pass"""
     dev = ln.device
@@ -147,6 +150,17 @@ def _gather_prepacked(ids, ln, num_graphs, pad_id, packed, rows_impl, stats, wor
     all_ext = torch.empty((world, per + 1), dtype=ln.dtype, device=dev)
     dist.all_gather_into_tensor(all_ext.view(-1), ext)
     all_ln = all_ext[:, :per].reshape(-1).contiguous()
+    if as_packed:
+        # the rows stay where the collective put them: a row's absolute start = its rank's segment + its start there
+        seg = torch.arange(world, dtype=torch.int64, device=dev).mul_(capacity).repeat_interleave(per)
+        skipped = all_start < 0
+        all_start = torch.where(skipped, all_start, all_start + seg)
+        all_ln = torch.where(skipped, torch.zeros_like(all_ln), all_ln)
+        verdict = all_ext[:, per].max().to(torch.int32).reshape(1)
+        if stats is not None:
+            stats.update(bytes_sent_per_rank=capacity * packed.buf.element_size() + per * 8 + (per + 1) * 4, compact=True,
+                         elem_bytes=packed.buf.element_size(), capacity=capacity, status=verdict, prepacked=True, as_packed=True)
+        return (all_packed, all_start[:num_graphs]), all_ln[:num_graphs]
     ustatus = torch.zeros(1, dtype=torch.int32, device=dev)
     u16 = packed.buf.dtype == torch.int16
     all_ids = rows_impl.unpack_rows_at(all_packed, all_start, all_ln, ld, pad_id, segment_rows=per, segment_stride=capacity, status=ustatus,

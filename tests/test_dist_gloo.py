@@ -132,6 +132,11 @@ def _worker(rank, world, port, G, q):
                                               rows_impl=_OracleRows, stats=st)
         ok = ok and f_ids.dtype == torch.int16 and torch.equal(f_ln, full_ln) and int(st["status"]) == 0 and st["prepacked"] \
             and np.array_equal(f_ids.numpy().view(np.uint16).astype(np.int32), full_ids.numpy())
+        # ... or stay packed on the receiving side too (as_packed=True): absolute row starts into the gathered buffer
+        (g_buf, g_start), g_ln = gtok.dist.gather_tokens(None, torch.from_numpy(ln), G, 5, compact=True, packed=pp, ld=160, as_packed=True,
+                                                         rows_impl=_OracleRows, stats=st)
+        back = _OracleRows.unpack_rows_at(g_buf, g_start, g_ln, 160, 5, u16=True)
+        ok = ok and st["as_packed"] and torch.equal(g_ln, full_ln) and np.array_equal(back.numpy().view(np.uint16).astype(np.int32), full_ids.numpy())
         pp = _Prepacked(i16n, ln, cap, seed=rank, drop=(3,) if rank == 1 else ())      # one rank skipped a row: every rank sees the verdict
         d_ids, d_ln = gtok.dist.gather_tokens(torch.from_numpy(i16n.view(np.int16)), torch.from_numpy(ln), G, 5, compact=True, packed=pp,
                                               rows_impl=_OracleRows, stats=st)
@@ -139,6 +144,9 @@ def _worker(rank, world, port, G, q):
         keep = np.arange(G) != gone
         ok = ok and int(st["status"]) == 2 and bool((d_ids[gone] == 5).all()) \
             and np.array_equal(d_ids.numpy().view(np.uint16).astype(np.int32)[keep], full_ids.numpy()[keep])
+        (g_buf, g_start), g_ln = gtok.dist.gather_tokens(None, torch.from_numpy(ln), G, 5, compact=True, packed=pp, ld=160, as_packed=True,
+                                                         rows_impl=_OracleRows, stats=st)
+        ok = ok and int(st["status"]) == 2 and int(g_ln[gone]) == 0 and int(g_start[gone]) < 0 and torch.equal(g_ln[torch.from_numpy(keep)], full_ln[torch.from_numpy(keep)])
         # a caller-given capacity that turns out too small: no rank reads beyond a segment, every rank sees the same verdict,
         # the rows that did not fit come out as pad, the others are right
         st = {}

@@ -512,3 +512,27 @@ def test_sent_packed_regions_fill_evenly_at_the_shapes_the_exchange_uses(G, K):
         assert pk.fused and int(pk.status()) == 0 and bool((pk.row_start[:K * G] >= 0).all()), (fill.size, fill.max() / fill.mean())
         assert fill.max() <= 1.03 * fill.mean(), (fill.size, fill.max() / fill.mean())
     assert torch.equal(ln.reshape(-1)[:G], gtok.ops.sent(b, 37, 1024, seed=0, epoch=5 * K, ld=176, u16=True, pad=False, **kw)[1])
+
+
+def test_collates_read_the_rows_packed_by_the_walk_in_place():
+    """gtok_collate_packed / gtok_collate_batch / gtok_collate_epoch over gtok_sent_packed's buffer through row_ptr = row_start give
+    what they give over the slab: packed rows need no re-padding before the trainer's collate."""
+    G, ld = 30016, 176
+    d, coo, b = _zinc_dev(G, seed=83)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    pk = gtok.ops.PackedRows(G, G * 104, True, DEV)
+    _, ln = gtok.ops.sent(b, 37, 1024, seed=2, epoch=4, ld=ld, u16=True, packed=pk, slab=False, **kw)
+    slab, sln = gtok.ops.sent(b, 37, 1024, seed=2, epoch=4, ld=ld, u16=True, pad=False, **kw)
+    assert pk.fused and torch.equal(ln, sln)
+    order = torch.randperm(G, generator=torch.Generator().manual_seed(1)).to(DEV)
+    idx = order[:333]
+    lmax = int(ln[idx].max())
+    X, A = gtok.ops.collate_packed(pk.buf, pk.row_start, ln, ld, idx, 5, lmax)
+    rX, rA = gtok.ops.collate_packed(slab, None, ln, ld, idx, 5, lmax)
+    assert torch.equal(X, rX) and torch.equal(A, rA)
+    y = torch.arange(G, dtype=torch.float32, device=DEV)
+    X, A, Y = gtok.ops.collate_batch(pk.buf, pk.row_start, ln, ld, idx.cpu().numpy(), 5, lmax, y)
+    assert torch.equal(X, rX) and torch.equal(A, rA) and torch.equal(Y, y[idx])
+    Xa, Aa, lm, off = gtok.ops.collate_epoch(pk.buf, pk.row_start, ln, ld, order, 128, 5)
+    Xs, As, lms, offs = gtok.ops.collate_epoch(slab, None, ln, ld, order, 128, 5)
+    assert lm == lms and off == offs and torch.equal(Xa, Xs) and torch.equal(Aa, As)
