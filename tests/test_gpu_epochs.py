@@ -454,6 +454,13 @@ def test_sent_pack_only_stages_in_scratch_and_packs_the_same_rows(u16):
     L = gtok._lib.lib()
     rows = L.gtok_sent_pack_scratch_rows(None)
     assert rows == 64 * 16 * torch.cuda.get_device_properties(0).multi_processor_count
+    # one epoch of the same batch: 469 units on one-wave workgroups (the launch shape of small batches) - a wave's staging rows follow its
+    # workgroup index there
+    pk1 = gtok.ops.PackedRows(G, G * 104, u16, DEV)
+    _, ln1 = gtok.ops.sent(b, 37, 1024, seed=6, epoch=3, ld=ld, u16=u16, packed=pk1, slab=False, **kw)
+    one, oln = gtok.ops.sent(b, 37, 1024, seed=6, epoch=3, ld=ld, u16=u16, **kw)
+    assert pk1.fused and int(pk1.status()) == 0 and torch.equal(ln1, oln)
+    assert torch.equal(gtok.ops.unpack_rows_at(pk1.buf, pk1.row_start, ln1, ld, 5, u16=u16), one)
     # the flag belongs to gtok_sent_packed: gtok_sent refuses it
     p = gtok._lib.GtokSentParams(37, 1, 9, 4, 1024, 1, 5, gtok._lib.SENT_PACK_ONLY | (gtok._lib.SENT_U16 if u16 else 0), 6, 1, 0, None, 1, 0)
     cs = b.lane_sorted.c_struct()
