@@ -63,6 +63,23 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
             inside = np.arange(ref[e][0].shape[1])[None, :] < ref[e][1][:, None] if not pad else np.ones_like(ref[e][0], bool)   # GTOK_SENT_NO_PAD: rows equal inside their lengths
             if not (np.array_equal(ln[e].cpu().numpy(), ref[e][1]) and np.array_equal(np.where(inside, got, 0), np.where(inside, ref[e][0], 0))):
                 fails += 1; print(f"MISMATCH sent it={it} kind={kind} pin={pin or 'auto'} G={coo.G} max_len={max_len} query={query is not None} pad={pad} K={K} e={e} u16={u16}", flush=True)
+        # the same launch with its rows packed as well (gtok_sent_packed where the lane kernel walks, else the one-pass pack behind the
+        # walk), beside the slab or alone (GTOK_SENT_PACK_ONLY): re-padded through row_start, the rows are the oracle's
+        if coo.G and rng.integers(0, 2):
+            ldp = ids.shape[2]
+            need = int(sum(int(((np.minimum(r[1], ldp) + 7) // 8 * 8).sum()) for r in ref))
+            pk = gtok.ops.PackedRows(K * coo.G, int(need * 1.15) + 8 * 64 * 64, u16, DEV)
+            alone = bool(rng.integers(0, 2))
+            _, pln = gtok.ops.sent(fresh, nn, max_len, sd, ep, graph_base=base, query=None if query is None else torch.from_numpy(query), pad=pad,
+                                   epochs=K, u16=u16, packed=pk, slab=not alone, ld=ldp, **kw)
+            back = gtok.ops.unpack_rows_at(pk.buf, pk.row_start, pln.reshape(-1), ldp, 5, u16=u16).view(K, coo.G, ldp)
+            for e in range(K):
+                got = back[e].cpu().numpy()
+                got = got.view(np.uint16).astype(np.int32) if u16 else got
+                if int(pk.status()) or not (np.array_equal(pln.view(K, coo.G)[e].cpu().numpy(), ref[e][1]) and np.array_equal(got, ref[e][0])):
+                    fails += 1; print(f"MISMATCH packed it={it} kind={kind} pin={pin or 'auto'} fused={pk.fused} alone={alone} G={coo.G} max_len={max_len} "
+                                      f"query={query is not None} K={K} e={e} u16={u16} status={int(pk.status())}", flush=True)
+            npacked = globals().get("npacked", 0) + 1; nfused = globals().get("nfused", 0) + int(bool(pk.fused))
     for k in ("GTOK_SENT_KERNEL", "GTOK_NO_LANE_SORT", "GTOK_NO_PACK8", "GTOK_BLANE_ORDER"):
         os.environ[k] = "" if k == "GTOK_SENT_KERNEL" else ("1" if k == "GTOK_BLANE_ORDER" else "0")
     if labeled:
@@ -87,5 +104,6 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         cmp(f"ibtt_synth it={it} G={coo.G} max_len={max_len}", ids, ln, *orc.ibtt_synth(coo, lut.numpy(), q, max_len, 0, ids.shape[1], nthreads=T))
     if it % 5 == 0:
         print(f"it {it} done, {fails} mismatches, {time.time() - t0:.0f}s", flush=True)
+print(f"packed launches {globals().get('npacked', 0)}, of them fused {globals().get('nfused', 0)}")
 print("TOTAL mismatches", fails)
 sys.exit(1 if fails else 0)
