@@ -543,3 +543,25 @@ def test_collates_read_the_rows_packed_by_the_walk_in_place():
     Xa, Aa, lm, off = gtok.ops.collate_epoch(pk.buf, pk.row_start, ln, ld, order, 128, 5)
     Xs, As, lms, offs = gtok.ops.collate_epoch(slab, None, ln, ld, order, 128, 5)
     assert lm == lms and off == offs and torch.equal(Xa, Xs) and torch.equal(Aa, As)
+
+
+def test_sent_packed_captured_in_a_hip_graph_and_replayed():
+    """The walk that packs takes no library-owned counters: the zeroing of its fill marks and the launch are captured together and
+    every replay refills the buffer with the same rows (pack-only: the staging scratch exists before the capture)."""
+    G, ld, K = 30016, 176, 4
+    d, coo, b = _zinc_dev(G, seed=84)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    pk = gtok.ops.PackedRows(K * G, K * G * 104, True, DEV)
+    gtok.ops.sent(b, 37, 1024, seed=3, epoch=8, ld=ld, epochs=K, u16=True, packed=pk, slab=False, **kw)     # warm-up: layout, scratch
+    torch.cuda.synchronize()
+    holder = {}
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        holder["ln"] = gtok.ops.sent(b, 37, 1024, seed=3, epoch=8, ld=ld, epochs=K, u16=True, packed=pk, slab=False, **kw)[1]
+    full, fln = gtok.ops.sent(b, 37, 1024, seed=3, epoch=8, ld=ld, epochs=K, u16=True, **kw)
+    for rep in range(3):
+        pk.buf.fill_(0x1111); pk.row_start.fill_(-9); holder["ln"].fill_(-1)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(pk.status()) == 0 and torch.equal(holder["ln"], fln)
+        assert torch.equal(gtok.ops.unpack_rows_at(pk.buf, pk.row_start, holder["ln"].reshape(-1), ld, 5, u16=True), full.reshape(-1, ld)), rep
