@@ -385,8 +385,10 @@ __global__ void __launch_bounds__(256) pack_scan_kernel(const PackScanArgs a) {
 template <typename E, typename O>
 __global__ void __launch_bounds__(256) unpack_rows_kernel(const RowsArgs a) {
   const int tpr = 1 << a.tpr_shift, sub = (int)threadIdx.x & (tpr - 1);
-  const int64_t r = (int64_t)blockIdx.x * (256 >> a.tpr_shift) + ((int)threadIdx.x >> a.tpr_shift);
-  if (r >= a.rows) return;
+  const int rpb = 256 >> a.tpr_shift;
+  // (a workgroup walks row groups with the grid's stride: at one group of 8 rows per workgroup, 4 M rows were half a million
+  // workgroups of 2.8 KB each and the pass ran at 2.4 TB/s of in + out)
+  for (int64_t r = (int64_t)blockIdx.x * rpb + ((int)threadIdx.x >> a.tpr_shift); r < a.rows; r += (int64_t)gridDim.x * rpb) {
   int n = a.len[r];
   n = n < 0 ? 0 : (n > a.ld ? a.ld : n);
   const int64_t start = packed_start(a.row_ptr, r, a.segment_rows, a.segment_stride, a.ld, a.at);
@@ -431,6 +433,7 @@ __global__ void __launch_bounds__(256) unpack_rows_kernel(const RowsArgs a) {
     } else {
       for (int k = i; k < a.ld && k < i + 8; ++k) row[k] = (O)(k < n ? (int32_t)src[k] : pad);
     }
+  }
   }
 }
 
@@ -692,6 +695,11 @@ extern "C" int gtok_row_offsets(const int32_t *len, int64_t num_rows, int32_t ld
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
 }
 
+#ifndef GTOK_UNPACK_WG_PER_CU
+#define GTOK_UNPACK_WG_PER_CU 32
+#endif
+constexpr int kUnpackWgPerCu = GTOK_UNPACK_WG_PER_CU;   // workgroups per CU of the re-padding pass; beyond that they stride over the rows (tuning knob)
+
 static int rows_launch(bool pack, const void *ids, int src_bytes, void *out_ids, int out_bytes, int32_t ld, const int32_t *len, int64_t num_rows,
                        const int64_t *row_ptr, int32_t segment_rows, int64_t segment_stride, int32_t elem_bytes,
                        void *packed, int64_t capacity, int32_t pad_id, int32_t *status, void *stream, int at = 0) {
@@ -706,6 +714,13 @@ static int rows_launch(bool pack, const void *ids, int src_bytes, void *out_ids,
   a.ids = ids; a.out_ids = out_ids; a.len = len; a.row_ptr = row_ptr; a.packed = packed; a.status = status;
   a.rows = num_rows; a.ld = ld; a.pad_id = pad_id; a.segment_rows = segment_rows; a.segment_stride = segment_stride; a.capacity = capacity;
   a.tpr_shift = tpr_shift_for(ld);
+  if (!pack) {
+    // the re-padding pass: half as many threads per row as it has 16-byte pieces, two pieces each (ZINC-full x 16 epochs into a
+    // 16-bit slab: 0.52 ms against 0.67 with a thread per piece - 22 pieces on 32 threads left a third of the lanes idle)
+    int less = 1;
+    if (const char *cs = std::getenv("GTOK_UNPACK_TPR_LESS")) less = std::atoi(cs);     // tuning knob
+    while (less-- > 0 && a.tpr_shift > 0) --a.tpr_shift;
+  }
   a.at = at;
   const int rpb = 256 >> a.tpr_shift;
   const int64_t nb = (num_rows + rpb - 1) / rpb;
@@ -719,12 +734,16 @@ static int rows_launch(bool pack, const void *ids, int src_bytes, void *out_ids,
     if (elem_bytes == 2) hipLaunchKernelGGL((pack_rows_kernel<int32_t, uint16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((pack_rows_kernel<int32_t, int32_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
   } else {
+    int per_cu = kUnpackWgPerCu;
+    if (const char *cs = std::getenv("GTOK_UNPACK_WG_PER_CU")) { const int c = std::atoi(cs); if (c >= 0) per_cu = c; }   // tuning knob: 0 = one row group per workgroup
+    const int64_t cap_wg = per_cu > 0 ? (int64_t)device_cu_count(device_scope.dev) * per_cu : nb;
+    const unsigned nu = (unsigned)(nb < cap_wg ? nb : cap_wg);
     if (out_bytes == 2) {
-      if (elem_bytes == 2) hipLaunchKernelGGL((unpack_rows_kernel<uint16_t, uint16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((unpack_rows_kernel<int32_t, uint16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+      if (elem_bytes == 2) hipLaunchKernelGGL((unpack_rows_kernel<uint16_t, uint16_t>), dim3(nu), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((unpack_rows_kernel<int32_t, uint16_t>), dim3(nu), dim3(256), 0, s, a);
     } else {
-      if (elem_bytes == 2) hipLaunchKernelGGL((unpack_rows_kernel<uint16_t, int32_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((unpack_rows_kernel<int32_t, int32_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+      if (elem_bytes == 2) hipLaunchKernelGGL((unpack_rows_kernel<uint16_t, int32_t>), dim3(nu), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((unpack_rows_kernel<int32_t, int32_t>), dim3(nu), dim3(256), 0, s, a);
     }
   }
   return hipGetLastError() == hipSuccess ? GTOK_OK : GTOK_E_LAUNCH;
