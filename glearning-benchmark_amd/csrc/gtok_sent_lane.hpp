@@ -800,8 +800,8 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
     // ---- gtok_sent_packed: the unit's rows are appended to the packed buffer as well, each from a 16-byte boundary.  The
     // buffer is cut into a.pack_regions equal regions with a fill mark each (one mark for everybody serves ~50-90 units per
     // microsecond: measured, it cost as much as the walk); pair vu appends to region vu mod regions - the units are stored by
-    // walk length, so every region receives the same mix and fills evenly - and learns where from ONE atomic add, issued ahead
-    // of the copy's loads.  The copy is cooperative: 16 lanes per row, four rows per pass (whole lines of the rows this wave
+    // walk length, so every region receives the same mix and fills evenly - and learns where from ONE atomic add, issued behind
+    // the copy's first loads.  The copy is cooperative: 16 lanes per row, four rows per pass (whole lines of the rows this wave
     // has just written).  Rows are ordered by completion: row_start says where each went.
     // (Nothing of this may stay live across the walk: the register file is full.)
     if constexpr (PACK) {
