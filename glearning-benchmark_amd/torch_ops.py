@@ -498,6 +498,41 @@ def _(packed, row_ptr, lens, ld, pad_id, segment_rows, segment_stride):
     return packed.new_empty((lens.shape[0], ld), dtype=torch.int32)
 
 
+@torch.library.custom_op("gtok::collate_batch", mutates_args=(), device_types="cuda")
+def collate_batch(packed: Tensor, row_ptr: Optional[Tensor], lens: Tensor, ld: int, index: List[int], pad_id: int, out_ld: int,
+                  y: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """gtok_collate_batch: collate_packed for a row list held on the HOST (what a sampler yields) - the indices ride in the launch's
+    arguments; y (labels, 4- or 8-byte elements) gathered by the same launch (an empty tensor comes back when y is None)."""
+    import numpy as _np
+    X, A, Y = _ops.collate_batch(packed, row_ptr, lens, ld, _np.asarray(index, dtype=_np.int64), pad_id, out_ld, y)
+    return X, A, Y if Y is not None else packed.new_empty((0,), dtype=torch.float32)
+
+
+@collate_batch.register_fake
+def _(packed, row_ptr, lens, ld, index, pad_id, out_ld, y):
+    B = len(index)
+    return (packed.new_empty((B, out_ld), dtype=torch.int64), packed.new_empty((B, out_ld), dtype=torch.bool),
+            packed.new_empty((B,), dtype=y.dtype) if y is not None else packed.new_empty((0,), dtype=torch.float32))
+
+
+@torch.library.custom_op("gtok::collate_epoch", mutates_args=(), device_types="cuda")
+def collate_epoch(packed: Tensor, row_ptr: Optional[Tensor], lens: Tensor, ld: int, order: Tensor, batch_size: int,
+                  pad_id: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """gtok_collate_epoch_plan + gtok_collate_epoch: every batch of an epoch collated by one call -> (X int64 arena, attn bool arena,
+    lmax int32 [batches], off int64 [batches + 1], the last two on the host): batch b = X.as_strided((B_b, lmax[b]), (lmax[b], 1), off[b])."""
+    X, A, lmax, off = _ops.collate_epoch(packed, row_ptr, lens, ld, order, batch_size, pad_id)
+    return X, A, torch.tensor(lmax, dtype=torch.int32), torch.tensor(off, dtype=torch.int64)
+
+
+@collate_epoch.register_fake
+def _(packed, row_ptr, lens, ld, order, batch_size, pad_id):
+    n = order.shape[0]
+    nb = -(-n // batch_size) if n else 0
+    total = torch.library.get_ctx().new_dynamic_size()
+    return (packed.new_empty((total,), dtype=torch.int64), packed.new_empty((total,), dtype=torch.bool),
+            torch.empty((nb,), dtype=torch.int32), torch.empty((nb + 1,), dtype=torch.int64))
+
+
 @torch.library.custom_op("gtok::collate_packed", mutates_args=(), device_types="cuda")
 def collate_packed(packed: Tensor, row_ptr: Optional[Tensor], lens: Tensor, ld: int, index: Tensor, pad_id: int,
                    out_ld: int) -> Tuple[Tensor, Tensor]:

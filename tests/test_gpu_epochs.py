@@ -565,3 +565,21 @@ def test_sent_packed_captured_in_a_hip_graph_and_replayed():
         torch.cuda.synchronize()
         assert int(pk.status()) == 0 and torch.equal(holder["ln"], fln)
         assert torch.equal(gtok.ops.unpack_rows_at(pk.buf, pk.row_start, holder["ln"].reshape(-1), ld, 5, u16=True), full.reshape(-1, ld)), rep
+
+
+def test_collate_batch_and_collate_epoch_as_torch_custom_ops():
+    G, ld = 5000, 176
+    d, coo, b = _zinc_dev(G, seed=85)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    slab, ln = gtok.ops.sent(b, 37, 1024, seed=2, epoch=0, ld=ld, u16=True, pad=False, **kw)
+    idx = [int(i) for i in torch.randperm(G, generator=torch.Generator().manual_seed(3))[:77]]
+    lmax = int(ln[torch.tensor(idx, device=DEV)].max())
+    y = torch.arange(G, dtype=torch.float32, device=DEV) * 0.5
+    X, A, Y = torch.ops.gtok.collate_batch(slab, None, ln, ld, idx, 5, lmax, y)
+    rX, rA = gtok.ops.collate_packed(slab, None, ln, ld, torch.tensor(idx, device=DEV), 5, lmax)
+    assert torch.equal(X, rX) and torch.equal(A, rA) and torch.equal(Y, y[torch.tensor(idx, device=DEV)])
+    assert torch.ops.gtok.collate_batch(slab, None, ln, ld, idx, 5, lmax, None)[2].numel() == 0
+    order = torch.randperm(G, generator=torch.Generator().manual_seed(4)).to(DEV)
+    Xa, Aa, lm, off = torch.ops.gtok.collate_epoch(slab, None, ln, ld, order, 128, 5)
+    rXa, rAa, rlm, roff = gtok.ops.collate_epoch(slab, None, ln, ld, order, 128, 5)
+    assert torch.equal(Xa, rXa) and torch.equal(Aa, rAa) and lm.tolist() == rlm and off.tolist() == roff and not lm.is_cuda
