@@ -583,3 +583,23 @@ def test_collate_batch_and_collate_epoch_as_torch_custom_ops():
     Xa, Aa, lm, off = torch.ops.gtok.collate_epoch(slab, None, ln, ld, order, 128, 5)
     rXa, rAa, rlm, roff = gtok.ops.collate_epoch(slab, None, ln, ld, order, 128, 5)
     assert torch.equal(Xa, rXa) and torch.equal(Aa, rAa) and lm.tolist() == rlm and off.tolist() == roff and not lm.is_cuda
+
+
+@pytest.mark.parametrize("u16", [True, False])
+def test_sent_packed_with_a_slab_too_narrow_for_some_rows(u16):
+    """ld below the longest rows: a packed row holds the first ld ids (as the slab row does), out_len keeps the true length."""
+    G, ld = 30016, 72
+    d, coo, b = _zinc_dev(G, seed=86)
+    kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
+    slab, sln = gtok.ops.sent(b, 37, 1024, seed=4, epoch=1, ld=ld, u16=u16, **kw)
+    assert int((sln > ld).sum()) > 1000 and int((sln <= ld).sum()) > 1000
+    for alone in (False, True):
+        pk = gtok.ops.PackedRows(G, G * 80, u16, DEV)
+        ids, ln = gtok.ops.sent(b, 37, 1024, seed=4, epoch=1, ld=ld, u16=u16, packed=pk, slab=not alone, **kw)
+        assert pk.fused and int(pk.status()) == 0 and torch.equal(ln, sln)
+        assert torch.equal(gtok.ops.unpack_rows_at(pk.buf, pk.row_start, ln, ld, 5, u16=u16), slab)
+        if not alone:
+            assert torch.equal(ids, slab)
+    ref, rln = orc.sent(coo, 37, 1024, 4, 1, ld=ld, **kw)
+    got = slab.cpu().numpy()
+    assert np.array_equal(got.view(np.uint16).astype(np.int32) if u16 else got, ref) and np.array_equal(sln.cpu().numpy(), rln)
