@@ -818,7 +818,12 @@ __global__ void __launch_bounds__(1024) sent_lane_kernel(const SentLaneArgs a) {
       const int q = lane & 15, grp = lane >> 4;
       const int my_row = valid ? (int)srow : -1, my_offnp = ((inc - np) << 8) | np;   // (np <= 255: the launcher checks ld)
       const int my_row0 = __builtin_amdgcn_readfirstlane((int)srow);               // (a row of this unit: lane 0 is always valid)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the rows read below were written by other lanes of this wave)
+      // The rows read below were written by this wave (other lanes of it).  A CU's stores and loads go through the one vector cache,
+      // which must keep a work-item's own store -> load coherent (a write hit updates or drops the line) and does so per address,
+      // not per lane; behind it both travel the same in-order path to the L2.  So plain loads see the rows - also where
+      // GTOK_SENT_PACK_ONLY reads the same staging rows unit after unit.  (Measured alternatives that do not rely on this: an
+      // agent-scope acquire fence or a bare buffer_inv before the loads +2-13 us per epoch, sc1 loads +11 us per epoch at K = 16.)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       // A sweep = 16-byte piece 16 sweep + q of every row, in two batches of eight passes of four rows (what the register file has
       // room for at a unit's end; variants measured slower or equal: the copy behind the next unit's staging loads - its state
       // lives across the walk and spills -, double-buffered batches of four, passes 8-15 landed in LDS by global_load_lds)
