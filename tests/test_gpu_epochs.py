@@ -436,7 +436,7 @@ def test_sent_pack_only_stages_in_scratch_and_packs_the_same_rows(u16):
     """GTOK_SENT_PACK_ONLY (ops.sent(..., packed=, slab=False)): no [K, G, ld] slab exists; every wave stages its units in its own
     64 rows of a per-device scratch.  More (unit, epoch) pairs than resident waves, so every staging row is reused."""
     import ctypes
-    G, ld, K = 30016, 176, 12
+    G, ld, K = 30016, 176, 28                              # 13,132 pairs on 4,096 resident waves: staging rows reused three times and more
     d, coo, b = _zinc_dev(G, seed=81)
     kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
     pk = gtok.ops.PackedRows(K * G, K * G * 104, u16, DEV)
