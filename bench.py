@@ -956,7 +956,8 @@ def main():
             if args.scaling == "strong":      # make the configured workload the headline of this run
                 out.update(value=out["strong_scaling"]["tokenize_and_allgather_graphs_per_sec"], scaling="strong",
                            ms_per_step=out["strong_scaling"]["tokenize_and_allgather_ms_per_epoch"])
-                out["config"]["parallelism"] = f"one corpus block-sharded x{world} + RCCL all-gather of the padded slab"
+                out["config"]["parallelism"] = (f"one corpus block-sharded x{world} + compact RCCL all-gather (16-bit rows packed by the walk, row starts, lengths), "
+                                                "re-padded into the full slab on every rank")
                 out["config"]["graphs_per_gpu"] = hi - lo
 
     try:
