@@ -267,8 +267,10 @@ class EpochBatchSampler(torch.utils.data.Sampler):
     dataset=<the TokenizedGraphDataset>: the sampler also announces every epoch's batches to the dataset (`plan_epoch`), which then
     collates the whole epoch in one launch and serves each batch as views."""
 
-    def __init__(self, num_items: int, batch_size: int, shuffle: bool = False, drop_last: bool = False,
+    def __init__(self, num_items, batch_size: int, shuffle: bool = False, drop_last: bool = False,
                  generator: Optional[torch.Generator] = None, dataset=None):
+        if dataset is None and hasattr(num_items, "plan_epoch"):        # EpochBatchSampler(ds, 128, shuffle=True): the dataset itself
+            dataset, num_items = num_items, len(num_items)
         self.n, self.batch_size, self.shuffle, self.drop_last, self.generator = int(num_items), int(batch_size), shuffle, drop_last, generator
         self.dataset = dataset if hasattr(dataset, "plan_epoch") else None
 

@@ -436,6 +436,8 @@ def test_device_batches_collate_the_epoch_in_one_call_and_the_slab_follows_the_t
     cb = ds.__getitems__(list(ds._plan["lists"][0]))
     assert isinstance(cb, agtt.CollatedBatch) and ds._epoch == epochs_seen[1] + 1
     assert len(list(agtt.EpochBatchSampler(G, 96, drop_last=True, dataset=ds))) == G // 96
+    short = agtt.EpochBatchSampler(ds, 96, shuffle=True)                 # the dataset in place of its length
+    assert short.dataset is ds and short.n == G and len(short) == -(-G // 96)
     # an abandoned plan: the loader is dropped after two batches, the next iteration plans again
     it = iter(loader)
     next(it); next(it)
