@@ -280,14 +280,32 @@ class PackedRows:
     side, not in dataset order - readers go through row_start: ops.unpack_rows_at, ops.collate_packed(buf, row_start, ...)); state
     int64 [PACK_STATE_WORDS]: the status word and the regions' fill marks (include/gtok.h).  Size the buffer as the expected total
     + a few per cent.  fused: whether the walk kernel itself wrote it (else gtok_sent + gtok_pack_rows_scan did: dataset order)."""
-    __slots__ = ("buf", "row_start", "state", "capacity", "fused")
+    __slots__ = ("buf", "row_start", "_ring", "_slot", "capacity", "fused")
+    RING = 32          # state blocks (8 KB each) zeroed together: a launch takes the next one instead of paying a memset of its own
 
     def __init__(self, rows: int, capacity: int, u16: bool, device):
         self.capacity = max(8, -(-int(capacity) // 8) * 8)
         self.buf = torch.empty(self.capacity, dtype=torch.int16 if u16 else torch.int32, device=device)
         self.row_start = torch.empty(max(1, int(rows)), dtype=torch.int64, device=device)
-        self.state = torch.zeros(PACK_STATE_WORDS, dtype=torch.int64, device=device)
+        self._ring = torch.zeros((self.RING, PACK_STATE_WORDS), dtype=torch.int64, device=device)
+        self._slot = 0
         self.fused = None
+
+    @property
+    def state(self) -> torch.Tensor:
+        """int64 [PACK_STATE_WORDS]: the status word and the fill marks of the LAST fill (include/gtok.h)"""
+        return self._ring[self._slot]
+
+    def _fresh_state(self) -> torch.Tensor:
+        """a zeroed state block for the next launch: the next one of the ring (all of them are zeroed again, in one launch, when the
+        ring wraps); under stream capture the block is zeroed inside the capture - replays reuse it"""
+        if torch.cuda.is_current_stream_capturing():
+            self.state.zero_()
+            return self.state
+        self._slot = (self._slot + 1) % self.RING
+        if self._slot == 0:
+            self._ring.zero_()
+        return self.state
 
     def status(self) -> torch.Tensor:
         """int32 [1] on the device: the pack_rows status bits of this fill (bit 1: the buffer was too small for some rows)."""
@@ -378,7 +396,7 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
             raise _lib.GtokError(f"the loaded library has ABI version {_lib.library_version()}: packed= needs version 6")
         if packed.buf.dtype != (torch.int16 if u16 else torch.int32) or packed.row_start.numel() < K * G or packed.buf.device != ln.device:
             raise ValueError("packed: a PackedRows of this launch's rows, id width and device")
-        packed.state.zero_()
+        packed._fresh_state()
         if G and ld % (8 if u16 else 4) == 0:
             dst, pp = ids, p
             if not slab:
