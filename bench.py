@@ -206,9 +206,10 @@ def boundary_section(d, G, dev, max_nodes, max_len):
                 n += X.shape[0]
             return n
         clock(lambda: batches(True))
-        t, n = clock(lambda: batches(True))
-        t_nd, _ = clock(lambda: batches(False))
-        out["agtt_device_batches"] = dict(items_per_sec=round(n / t, 1), items_per_sec_without_data_list=round(n / t_nd, 1), batch_size=128, items=n,
+        # (median of three epochs: an epoch is ~9 ms of host work, and one allocator or collector hiccup in it halved single samples)
+        t, n = sorted(clock(lambda: batches(True)) for _ in range(3))[1]
+        t_nd, _ = sorted(clock(lambda: batches(False)) for _ in range(3))[1]
+        out["agtt_device_batches"] = dict(items_per_sec=round(n / t, 1), items_per_sec_without_data_list=round(n / t_nd, 1), batch_size=128, items=n, epochs_timed=3,
                                           note="agtt.TokenizedGraphDataset.device_batches(128): the whole epoch collated by one gtok_collate_epoch call, batches are views; X / attn / labels stay on the device; "
                                                "the list of Data objects collate_fn returns is fetched item by item unless with_data=False")
         # IBTT: strings -> TokenDataset (train_ibtt.py:229-235, :395-397) and the string-free route
