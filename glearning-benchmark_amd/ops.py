@@ -334,7 +334,7 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
     rows), else by gtok_pack_rows_scan behind the walk; either way packed.row_start / packed.state describe the result.
     slab=False (with packed=; GTOK_SENT_PACK_ONLY): the caller reads the packed rows alone - no [K, G, ld] slab is written or
     allocated (the walk stages its rows in a per-device scratch of 64 rows per resident wave: 92 MB on an MI355X whatever K is) and
-    the first return value is None."""
+    the first return value is None; out=(staging, len) then names the caller's own staging space (or None) and length tensor."""
     _need_gpu(batch.col, "sent")
     dev = batch.device
     K = max(1, int(epochs))
@@ -345,11 +345,20 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
     if ld is None:
         ld = sent_safe_ld(batch, labeled, max_len, query is not None)
     G = batch.num_graphs
+    staging = None
     if not slab:
-        if packed is None or out is not None:
-            raise ValueError("slab=False goes with packed= (and without out=)")
+        if packed is None:
+            raise ValueError("slab=False goes with packed=")
         ids = None
-        ln = torch.empty((K * G,), dtype=torch.int32, device=dev)
+        if out is not None:           # (staging rows of the caller's own - launches on several streams must not share the module's - , lengths)
+            staging, ln = out
+            if staging is not None and (staging.dtype != (torch.int16 if u16 else torch.int32) or not staging.is_contiguous()
+                                        or staging.device != torch.device(dev)):
+                raise ValueError("out[0] with slab=False: contiguous staging space of the rows' id width on the batch's device (or None)")
+            if ln.dtype != torch.int32 or ln.numel() != K * G or not ln.is_contiguous():
+                raise ValueError("out[1]: contiguous int32 [K * G]")
+        else:
+            ln = torch.empty((K * G,), dtype=torch.int32, device=dev)
     elif out is not None:
         ids, ln = out
         want = torch.int16 if u16 else torch.int32
@@ -400,7 +409,10 @@ def sent(batch: GraphBatch, max_num_nodes: int, max_len: int, seed: int, epoch: 
         if G and ld % (8 if u16 else 4) == 0:
             dst, pp = ids, p
             if not slab:
-                dst = _pack_scratch(dev, ld, u16)
+                need = int(lib().gtok_sent_pack_scratch_rows(_stream(dev))) * ld
+                if staging is not None and staging.numel() < need:
+                    raise ValueError(f"out[0] with slab=False: {need} ids of staging space (gtok_sent_pack_scratch_rows() x ld)")
+                dst = staging if staging is not None else _pack_scratch(dev, ld, u16)
                 pp = GtokSentParams(max_num_nodes, int(labeled), num_node_types, num_edge_types, max_len, int(remap_zinc), pad_id,
                                     flags | _lib.SENT_PACK_ONLY, seed & (2 ** 64 - 1), epoch & (2 ** 64 - 1), graph_base,
                                     None if query is None else query.data_ptr(), K, 0)

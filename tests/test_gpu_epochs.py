@@ -461,6 +461,18 @@ def test_sent_pack_only_stages_in_scratch_and_packs_the_same_rows(u16):
     one, oln = gtok.ops.sent(b, 37, 1024, seed=6, epoch=3, ld=ld, u16=u16, **kw)
     assert pk1.fused and int(pk1.status()) == 0 and torch.equal(ln1, oln)
     assert torch.equal(gtok.ops.unpack_rows_at(pk1.buf, pk1.row_start, ln1, ld, 5, u16=u16), one)
+    # the caller's own staging space and length tensor (launches on several streams must not share the module's scratch)
+    mine = torch.empty(L_rows * ld if (L_rows := gtok._lib.lib().gtok_sent_pack_scratch_rows(None)) else 0, dtype=pk1.buf.dtype, device=DEV)
+    ln_out = torch.empty(G, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        none2, ln2b = gtok.ops.sent(b, 37, 1024, seed=6, epoch=3, ld=ld, u16=u16, packed=pk1, slab=False, out=(mine, ln_out), **kw)
+        back2 = gtok.ops.unpack_rows_at(pk1.buf, pk1.row_start, ln_out, ld, 5, u16=u16)
+    torch.cuda.current_stream().wait_stream(side)
+    assert none2 is None and ln2b.data_ptr() == ln_out.data_ptr() and torch.equal(back2, one)
+    with pytest.raises(ValueError):
+        gtok.ops.sent(b, 37, 1024, seed=6, epoch=3, ld=ld, u16=u16, packed=pk1, slab=False, out=(mine[:1000], ln_out), **kw)
     # the flag belongs to gtok_sent_packed: gtok_sent refuses it
     p = gtok._lib.GtokSentParams(37, 1, 9, 4, 1024, 1, 5, gtok._lib.SENT_PACK_ONLY | (gtok._lib.SENT_U16 if u16 else 0), 6, 1, 0, None, 1, 0)
     cs = b.lane_sorted.c_struct()
