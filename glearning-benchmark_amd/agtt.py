@@ -228,12 +228,11 @@ class TokenizedGraphDataset(Dataset):
             self._served[order] = True
             od = torch.from_numpy(order).to(self._ids.device)
             X, A, lmax, off = _ops.collate_epoch(self._ids, None, self._lens, self._ids.shape[1], od, plan["bs"], PAD)
-            ar = plan["arenas"] = (X, A, lmax, off, self._labels_on_device()[od], self._epoch)
-        X, A, lmax, off, y, epoch = ar
-        s = k * plan["bs"]
+            ar = plan["arenas"] = (X, A, lmax, off, self._labels_on_device()[od].split(plan["bs"]), self._epoch)
+        X, A, lmax, off, ys, epoch = ar
         lst = plan["lists"][k]
         B, L, o = len(lst), lmax[k], off[k]
-        return CollatedBatch(self, lst, X.as_strided((B, L), (L, 1), o), A.as_strided((B, L), (L, 1), o), y[s:s + B], epoch)
+        return CollatedBatch(self, lst, X.as_strided((B, L), (L, 1), o), A.as_strided((B, L), (L, 1), o), ys[k], epoch)
 
     def device_batches(self, batch_size: int, epoch: int, shuffle: bool = False,
                        generator: Optional[torch.Generator] = None, with_data: bool = True):
@@ -250,11 +249,11 @@ class TokenizedGraphDataset(Dataset):
         # the whole epoch collated by one call (gtok_collate_epoch): a batch is three views of the epoch's arenas - no launch, no
         # allocation, no host-side maximum per batch (round 4: one gtok_collate_packed launch + a lens[idx].max() per batch)
         X, A, lmax, off = _ops.collate_epoch(ids, None, lens, ids.shape[1], order_d, batch_size, PAD)
-        y_perm = y[order_d]
+        ys = y[order_d].split(batch_size)                    # every batch's labels in one call
         order_l = order.tolist() if with_data else None
         for b, s in enumerate(range(0, n, batch_size)):
             B, L, o = min(batch_size, n - s), lmax[b], off[b]
-            yield (X.as_strided((B, L), (L, 1), o), A.as_strided((B, L), (L, 1), o), y_perm[s:s + B],
+            yield (X.as_strided((B, L), (L, 1), o), A.as_strided((B, L), (L, 1), o), ys[b],
                    LazyDataList(ds, order_l[s:s + B]) if with_data else [])
 
 
