@@ -112,7 +112,12 @@ def boundary_section(d, G, dev, max_nodes, max_len):
         pyg = gtok.synth.InMemoryLike(d)
         sync = torch.cuda.synchronize
 
+        import gc
+
         def clock(f):
+            # (a full collection BEFORE the clock starts: a leg then runs against the young generations only - the corpus objects of the
+            # earlier legs, millions of them, made a generation-2 pass inside a 9 ms leg cost several times the leg)
+            gc.collect()
             sync(); t0 = time.perf_counter(); r = f(); sync()
             return time.perf_counter() - t0, r
         # CSR ingestion (once per split)
