@@ -21,7 +21,17 @@ ids, ln = gtok.ops.ibtt_zinc(dev, lut, 1024, vocab["<pad>"], ld=240)
 ref, rln = orc.ibtt_zinc(coo, lut.numpy(), 1024, vocab["<pad>"], 240, nthreads=T)
 assert np.array_equal(ln.cpu().numpy(), rln) and np.array_equal(ids.cpu().numpy(), ref)
 print("IBTT bit-exact", flush=True)
-flavours = [("sent int32 padded (the documented slab)", lambda: gtok.ops.sent(dev, 37, 1024, 5, 1, ld=200, **kw)),
+# rows packed by the walk (gtok_sent_packed, no slab): four rounds of resident waves reuse the staging rows; re-padded, the rows are the oracle's
+need = int(((torch.from_numpy(rln_sent := orc.sent(coo, 37, 1024, 5, 1, ld=200, nthreads=T, **kw)[1]).clamp(0, 200) + 7) // 8 * 8).sum())
+pk = gtok.ops.PackedRows(G, int(need * 1.04) + 4096, True, "cuda:0")
+_, pln = gtok.ops.sent(dev, 37, 1024, 5, 1, ld=200, u16=True, packed=pk, slab=False, **kw)
+back = gtok.ops.unpack_rows_at(pk.buf, pk.row_start, pln, 200, 5, u16=True).cpu().numpy().view(np.uint16).astype(np.int32)
+assert pk.fused and int(pk.status()) == 0 and np.array_equal(pln.cpu().numpy(), rln_sent) and np.array_equal(back, orc.sent(coo, 37, 1024, 5, 1, ld=200, nthreads=T, **kw)[0])
+print("SENT packed by the walk bit-exact (no slab)", flush=True)
+del back
+flavours = [("sent 16-bit rows packed by the walk, no slab (gtok_sent_packed + GTOK_SENT_PACK_ONLY)",
+             lambda: gtok.ops.sent(dev, 37, 1024, 5, 1, ld=200, u16=True, packed=pk, slab=False, **kw)),
+            ("sent int32 padded (the documented slab)", lambda: gtok.ops.sent(dev, 37, 1024, 5, 1, ld=200, **kw)),
             ("sent int32 unpadded", lambda: gtok.ops.sent(dev, 37, 1024, 5, 1, ld=200, pad=False, **kw)),
             ("sent 16-bit rows padded", lambda: gtok.ops.sent(dev, 37, 1024, 5, 1, ld=200, u16=True, **kw)),
             ("sent 16-bit rows unpadded", lambda: gtok.ops.sent(dev, 37, 1024, 5, 1, ld=200, u16=True, pad=False, **kw)),
