@@ -100,7 +100,9 @@ class Graph2TrailTokenizer:
                                   # are staged and padded while other waves walk cost less than those of a one-round launch, and the
                                   # launch's ragged end is shared by more epochs (ZINC-full as 16-bit rows, per epoch: 0.0653 ms at one
                                   # epoch per launch, 0.0573 at 4, 0.0535 at 8, 0.0516 at 16)
-    EPOCH_SLAB_BYTES = 2 << 30    # ... as long as the K-epoch slab of 16-bit rows stays below this (125 k graph-token graphs x 1,032 ids: 8)
+    EPOCH_SLAB_BYTES = 4 << 30    # ... as long as the K-epoch slab of 16-bit rows stays below this - 1.5 % of the device's 288 GB (125 k
+                                  # graph-token graphs x 608 ids: 28 epochs, 0.290 / 0.327 ms per epoch on the ER / family-mix corpora against
+                                  # 0.299 / 0.337 at the 14 epochs a 2 GiB bound allowed; x 1,040 ids: 16)
 
     @classmethod
     def epochs_for_shape(cls, num_graphs: int, ld: Optional[int] = None) -> int:

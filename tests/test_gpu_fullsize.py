@@ -174,7 +174,7 @@ def test_sent_zinc_full_sixteen_epochs_per_launch_as_16_bit_rows(zinc_full):
     d, host, dev, coo = zinc_full
     K, ld = 16, 192
     tok = gtok.Graph2TrailTokenizer(dataset_names=[], max_length=1024, labeled_graph=True)
-    assert tok.epochs_for(ZINC_FULL, ld) == K == tok.epochs_for(ZINC_FULL) and tok.epochs_for(125000, 1040) == 8 and tok.epochs_for(12000, 208) == 32
+    assert tok.epochs_for(ZINC_FULL, ld) == K == tok.epochs_for(ZINC_FULL) and tok.epochs_for(125000, 1040) == 16 and tok.epochs_for(12000, 208) == 32
     kw = dict(labeled=True, num_node_types=9, num_edge_types=4, remap_zinc=True)
     ids, ln = gtok.ops.sent(dev, 37, 1024, 7, 100, ld=ld, epochs=K, u16=True, pad=False, **kw)
     assert ids.dtype == torch.int16 and tuple(ids.shape) == (K, ZINC_FULL, ld) and int(ln.max()) <= ld
@@ -215,20 +215,20 @@ def test_large_graphs_eight_epochs_per_launch():
 
 def test_config5_share_at_the_epochs_per_launch_the_dataset_classes_use():
     """A 125,000-graph share of BASELINE config 5 (10..256 nodes, max_len 600) the way the dataset classes tokenize it:
-    epochs_for(125000, 608) = 14 epochs in one gtok_sent launch (the 2 GiB slab bound), 16-bit rows without padding, 1.75 M walks
+    epochs_for(125000, 608) = 28 epochs in one gtok_sent launch (the 4 GiB slab bound), 16-bit rows without padding, 3.5 M walks
     through sent_blane_kernel with every pair beyond the first round drawn from the ticket counters - first, a middle and the last
     slice bit-exact against the oracle inside the row lengths, lengths of every slice equal, rows cut at max_len decode to a part
     of their graph."""
     G, ld = 125000, 608
     tok = gtok.Graph2TrailTokenizer(dataset_names=[], max_length=600, labeled_graph=False)
     K = tok.epochs_for(G, ld)
-    assert K == 14
+    assert K == 28
     d = gtok.synth.er_batch_device(G, torch.device(DEV), seed=1000)
     batch, coo = both(d, False)
     dev = batch.to(DEV)
     ids, ln = gtok.ops.sent(dev, 256, 600, 5, 20, ld=ld, epochs=K, u16=True, pad=False)
     assert gtok.ops.sent_kernel_name(dev, 256, 600, epochs=K) == "sent_blane_kernel<W=4>" and tuple(ids.shape) == (K, G, ld)
-    for e in (0, 6, K - 1):
+    for e in (0, 13, K - 1):
         ref, rln = orc.sent(coo, 256, 600, 5, 20 + e, ld=ld, nthreads=THREADS)
         assert np.array_equal(ln[e].cpu().numpy(), rln), e
         got = ids[e].cpu().numpy().view(np.uint16)
